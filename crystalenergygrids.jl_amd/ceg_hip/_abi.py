@@ -1,0 +1,125 @@
+"""ctypes view of ``include/ceg_hip.h`` (types + function prototypes).
+
+This is the Python twin of the ``ccall`` stubs in ``julia/CEGHip.jl``: plain pointers
+and sizes only.  Loading is strict: if ``libceg_hip.so`` is missing the import of the
+product path fails loudly -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+RULE_DTYPE = np.dtype([('kind', '<i4'), ('_pad', '<i4'), ('p', '<f8', (3,)), ('shift', '<f8')],
+                      align=True)
+assert RULE_DTYPE.itemsize == 40
+
+PKG_DIR = Path(__file__).resolve().parent.parent          # crystalenergygrids.jl_amd/
+REPO_DIR = PKG_DIR.parent
+LIB_PATH = PKG_DIR / "csrc" / "libceg_hip.so"
+
+c_double_p = C.POINTER(C.c_double)
+c_float_p = C.POINTER(C.c_float)
+c_int32_p = C.POINTER(C.c_int32)
+c_int64_p = C.POINTER(C.c_int64)
+
+# name -> (restype, argtypes); every symbol include/ceg_hip.h declares
+PROTOTYPES = {
+    "ceg_abi_version": (C.c_int, []),
+    "ceg_device_count": (C.c_int, []),
+    "ceg_last_error": (C.c_char_p, []),
+    "ceg_grid_vdw": (C.c_int, [
+        c_double_p, c_int64_p, C.c_int64, c_double_p, c_double_p,
+        C.c_int32, C.c_double, C.c_double,
+        C.c_void_p, c_int32_p, C.c_int32,
+        c_int32_p, c_double_p, c_double_p, c_double_p,
+        C.c_double, C.c_double, c_float_p, C.c_int32]),
+    "ceg_grid_coulomb": (C.c_int, [
+        c_double_p, c_double_p, C.c_int64, c_double_p, c_double_p,
+        C.c_int32, C.c_double, C.c_double, C.c_double,
+        c_int32_p, c_double_p, c_double_p, c_double_p,
+        C.c_double, C.c_double, c_float_p, C.c_int32]),
+    "ceg_plan_create": (C.c_int, [
+        C.POINTER(C.c_void_p), C.c_int32,
+        c_double_p, c_int64_p, c_double_p, C.c_int64,
+        c_double_p, c_double_p, C.c_int32, C.c_double, C.c_double,
+        C.c_void_p, c_int32_p, C.c_int32, C.c_double,
+        c_int32_p, c_double_p, c_double_p, c_double_p]),
+    "ceg_plan_destroy": (C.c_int, [C.c_void_p]),
+    "ceg_plan_can_cull": (C.c_int, [C.c_void_p]),
+    "ceg_plan_num_images": (C.c_int64, [C.c_void_p]),
+    "ceg_plan_build_vdw": (C.c_int, [
+        C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_int32,
+        C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "ceg_plan_build_coulomb": (C.c_int, [
+        C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_int32,
+        C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "ceg_plan_build_fused": (C.c_int, [
+        C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double,
+        C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+        C.c_int32, C.c_void_p]),
+    "ceg_plan_eval_points": (C.c_int, [
+        C.c_void_p, C.c_int32, C.c_int32, c_double_p, C.c_int64, c_double_p]),
+}
+
+ALGO_AUTO, ALGO_BRUTEFORCE, ALGO_CULLED = 0, 1, 2
+
+
+class CegError(RuntimeError):
+    """Non-zero status from libceg_hip (message from ``ceg_last_error``)."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libceg_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_library(path: os.PathLike | None = None) -> C.CDLL:
+    """dlopen ``libceg_hip.so`` and bind every prototype.  Raises if it is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = Path(path) if path is not None else LIB_PATH
+    if not p.exists():
+        raise ImportError(
+            f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the grid build.")
+    lib = C.CDLL(str(p))
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.ceg_abi_version() != 1:
+        raise ImportError("libceg_hip.so ABI version mismatch")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(lib: C.CDLL, code: int) -> None:
+    if code != 0:
+        raise CegError(code, (lib.ceg_last_error() or b"").decode())
+
+
+def dptr(a: np.ndarray):
+    assert a.dtype == np.float64 and a.flags.c_contiguous
+    return a.ctypes.data_as(c_double_p)
+
+
+def i32ptr(a: np.ndarray):
+    assert a.dtype == np.int32 and a.flags.c_contiguous
+    return a.ctypes.data_as(c_int32_p)
+
+
+def i64ptr(a: np.ndarray):
+    assert a.dtype == np.int64 and a.flags.c_contiguous
+    return a.ctypes.data_as(c_int64_p)
+
+
+def fptr(a: np.ndarray):
+    assert a.dtype == np.float32
+    return a.ctypes.data_as(c_float_p)

@@ -1,0 +1,338 @@
+"""Energy grids: build, file format, interpolation, ``energy_point`` (host-side
+mirror of ``src/grids.jl``).
+
+The two loop nests that fill the grid -- ``create_grid_vdw`` (grids.jl:144-150) and
+``create_grid_coulomb`` (grids.jl:171-177) -- are replaced by one call each into
+``libceg_hip.so``; everything around them (geometry, ProbeSystem, lambda / threshold,
+the byte-exact ``.grid`` writer) follows the reference line by line.  The product
+path has no CPU fallback: without the HIP library these functions raise.
+"""
+from __future__ import annotations
+
+import math
+import os
+import struct
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _abi
+from .constants import COULOMBIC_CONVERSION_FACTOR, GRID_TO_KELVIN, tricubic_coeff
+from .coordinates import CellMatrix, GridCoordinatesSetup, offsetpoint
+from .ewald import EwaldFramework, compute_ewald, initialize_ewald
+from .forcefields import ForceField
+from .probes import ProbeSystem
+from .utils import find_supercell
+
+
+# ------------------------------------------------------------------ EnergyGrid
+@dataclass
+class EnergyGrid:
+    """grids.jl:10-16.  ``grid`` has numpy shape ``(8, nx, ny, nz)`` C-order, which is the
+    same memory as Julia's column-major ``Array{Cfloat,4}(nz, ny, nx, 8)``."""
+    csetup: Optional[GridCoordinatesSetup]
+    num_unitcell: Tuple[int, int, int]
+    ewald_precision: float       # -inf zero grid; +inf VdW grid; nan invalid grid
+    higherorder: bool
+    grid: np.ndarray
+
+    @classmethod
+    def trivial(cls, zero: bool) -> "EnergyGrid":
+        """``EnergyGrid(zero::Bool)`` grids.jl:17-19"""
+        return cls(None, (0, 0, 0), -math.inf if zero else math.nan, False,
+                   np.empty((0, 0, 0, 0), dtype=np.float32))
+
+
+def _setup_grid_common(framework, spacing: float, cutoff: float):
+    """grids.jl:102-106"""
+    csetup = GridCoordinatesSetup.from_cell(framework.mat, spacing)
+    num_unitcell = find_supercell(framework.mat, cutoff)
+    return csetup, num_unitcell
+
+
+def _create_grid_common(io, csetup: GridCoordinatesSetup, num_unitcell) -> None:
+    """grids.jl:108-116 -- 128-byte little-endian unpadded header."""
+    io.write(struct.pack("<d", float(csetup.spacing)))
+    io.write(struct.pack("<3i", *(int(x) for x in csetup.dims)))
+    io.write(struct.pack("<3d", *csetup.size))
+    io.write(struct.pack("<3d", *csetup.shift))
+    io.write(struct.pack("<3d", *csetup.delta))
+    io.write(struct.pack("<3d", *csetup.unitcell))
+    io.write(struct.pack("<3i", *(int(x) for x in num_unitcell)))
+
+
+def vdw_scaling():
+    """``λ = inv(GRID_TO_KELVIN)``, threshold ``GRID_TO_KELVIN*1e7`` (grids.jl:141-143,148)"""
+    lam_inv = GRID_TO_KELVIN
+    return 1.0 / lam_inv, lam_inv * 1e7
+
+
+def coulomb_scaling():
+    """``λ = COULOMBIC_CONVERSION_FACTOR/GRID_TO_KELVIN``, threshold ``inv(λ)*1e7``
+    (grids.jl:169-170)"""
+    lam = COULOMBIC_CONVERSION_FACTOR / GRID_TO_KELVIN
+    return lam, (1.0 / lam) * 1e7
+
+
+def _grid_args(cset: GridCoordinatesSetup):
+    dims = np.ascontiguousarray(cset.dims, dtype=np.int32)
+    size = np.ascontiguousarray(cset.size, dtype=np.float64)
+    shift = np.ascontiguousarray(cset.shift, dtype=np.float64)
+    delta = np.ascontiguousarray(cset.delta, dtype=np.float64)
+    return dims, size, shift, delta
+
+
+def _matT(m: np.ndarray) -> np.ndarray:
+    """column-major flattening of a 3x3 (what the C ABI expects)"""
+    return np.ascontiguousarray(np.asarray(m, dtype=np.float64).T.reshape(9))
+
+
+def build_vdw_array(probe: ProbeSystem, cset: GridCoordinatesSetup, ngpus: int = 1) -> np.ndarray:
+    """The loop nest of grids.jl:144-150 on the GPU (``ceg_grid_vdw``)."""
+    lib = _abi.load_library()
+    ff = probe.forcefield
+    ff.check_vdw_grid(probe.probe, np.unique(probe.atomkinds))
+    rules, offsets = ff.rule_table(probe.probe)
+    ortho, safemin2 = probe.periodic_setup()
+    lam, thr = vdw_scaling()
+    dims, size, shift, delta = _grid_args(cset)
+    nx, ny, nz = cset.npoints
+    grid = np.empty((8, nx, ny, nz), dtype=np.float32)
+    pos = np.ascontiguousarray(probe.positions, dtype=np.float64)
+    kinds = np.ascontiguousarray(probe.atomkinds, dtype=np.int64)
+    mat, invmat = _matT(probe.mat), _matT(probe.invmat)
+    rc = lib.ceg_grid_vdw(_abi.dptr(pos), _abi.i64ptr(kinds), len(kinds), _abi.dptr(mat), _abi.dptr(invmat),
+                          int(ortho), safemin2, probe.cutoff2,
+                          rules.ctypes.data, _abi.i32ptr(offsets), ff.nkinds,
+                          _abi.i32ptr(dims), _abi.dptr(size), _abi.dptr(shift), _abi.dptr(delta),
+                          lam, thr, _abi.fptr(grid), ngpus)
+    _abi.check(lib, rc)
+    return grid
+
+
+def build_coulomb_array(probe: ProbeSystem, alpha: float, cset: GridCoordinatesSetup, ngpus: int = 1) -> np.ndarray:
+    """The loop nest of grids.jl:171-177 on the GPU (``ceg_grid_coulomb``)."""
+    lib = _abi.load_library()
+    ortho, safemin2 = probe.periodic_setup()
+    lam, thr = coulomb_scaling()
+    dims, size, shift, delta = _grid_args(cset)
+    nx, ny, nz = cset.npoints
+    grid = np.empty((8, nx, ny, nz), dtype=np.float32)
+    pos = np.ascontiguousarray(probe.positions, dtype=np.float64)
+    q = np.ascontiguousarray(probe.charges, dtype=np.float64)
+    mat, invmat = _matT(probe.mat), _matT(probe.invmat)
+    rc = lib.ceg_grid_coulomb(_abi.dptr(pos), _abi.dptr(q), len(q), _abi.dptr(mat), _abi.dptr(invmat),
+                              int(ortho), safemin2, probe.cutoff2, alpha,
+                              _abi.i32ptr(dims), _abi.dptr(size), _abi.dptr(shift), _abi.dptr(delta),
+                              lam, thr, _abi.fptr(grid), ngpus)
+    _abi.check(lib, rc)
+    return grid
+
+
+def write_grid_file(file, cset: GridCoordinatesSetup, num_unitcell, grid: np.ndarray,
+                    ewald_precision: Optional[float] = None) -> None:
+    """File body of grids.jl:151-155 / :178-183."""
+    with open(file, "wb") as f:
+        _create_grid_common(f, cset, num_unitcell)
+        if ewald_precision is not None:
+            f.write(struct.pack("<d", float(ewald_precision)))
+        f.write(np.ascontiguousarray(grid, dtype="<f4").tobytes())
+        f.write(np.asarray(cset.cell.mat, dtype="<f8").T.tobytes())   # column-major 3x3, not part of RASPA grids
+
+
+def create_grid_vdw(file, framework, forcefield: ForceField, spacing: float, atom: str, ngpus: int = 1) -> np.ndarray:
+    """grids.jl:137-157"""
+    cset, num_unitcell = _setup_grid_common(framework, spacing, forcefield.cutoff)
+    probe_vdw = ProbeSystem.build(framework, forcefield, atom)
+    grid = build_vdw_array(probe_vdw, cset, ngpus)
+    write_grid_file(file, cset, num_unitcell, grid)
+    return grid
+
+
+def create_grid_coulomb(file, framework, forcefield: ForceField, spacing: float,
+                        _ewald: Optional[EwaldFramework] = None, ngpus: int = 1) -> np.ndarray:
+    """grids.jl:159-185"""
+    cset, num_unitcell = _setup_grid_common(framework, spacing, 12.0)
+    ewald = _ewald if isinstance(_ewald, EwaldFramework) else initialize_ewald(framework, num_unitcell)
+    probe_coulomb = ProbeSystem.build(framework, forcefield)
+    grid = build_coulomb_array(probe_coulomb, ewald.alpha, cset, ngpus)
+    write_grid_file(file, cset, num_unitcell, grid, ewald.precision)
+    return grid
+
+
+def parse_grid(file, iscoulomb: bool, mat=None) -> EnergyGrid:
+    """grids.jl:61-94.  The payload is multiplied by GRID_TO_KELVIN in Float32."""
+    with open(file, "rb") as io:
+        spacing, = struct.unpack("<d", io.read(8))
+        dims = np.array(struct.unpack("<3i", io.read(12)), dtype=np.int32)
+        size = np.array(struct.unpack("<3d", io.read(24)))
+        shift = np.array(struct.unpack("<3d", io.read(24)))
+        delta = np.array(struct.unpack("<3d", io.read(24)))
+        unitcell = np.array(struct.unpack("<3d", io.read(24)))
+        num_unitcell = struct.unpack("<3i", io.read(12))
+        ewald_precision = struct.unpack("<d", io.read(8))[0] if iscoulomb else math.inf
+        nx, ny, nz = (int(d) + 1 for d in dims)
+        n = 8 * nx * ny * nz
+        grid = np.frombuffer(io.read(4 * n), dtype="<f4").reshape(8, nx, ny, nz)
+        grid = (grid.astype(np.float64) * GRID_TO_KELVIN).astype(np.float32)
+        if mat is not None:
+            newmat = mat if isinstance(mat, CellMatrix) else CellMatrix.from_mat(mat)
+        else:
+            tail = io.read(72)
+            if len(tail) != 72:
+                raise ValueError("Missing `mat` argument to `parse_grid` not provided by the grid.")
+            newmat = CellMatrix.from_mat(np.frombuffer(tail, dtype="<f8").reshape(3, 3).T)
+    cs = GridCoordinatesSetup(newmat, spacing, dims, size, shift, unitcell, delta)
+    return EnergyGrid(cs, tuple(int(x) for x in num_unitcell), ewald_precision, True, grid)
+
+
+# ------------------------------------------------------------------ interpolation
+def interpolation_stencil(csetup: GridCoordinatesSetup, gridshape, point):
+    """grids.jl:215-221 -> (p0, p1, r), 1-based indices like the reference.
+    ``gridshape`` = (nx, ny, nz)."""
+    shifted = offsetpoint(point, csetup)
+    p0 = np.floor(shifted).astype(np.int64)
+    p1 = p0 + np.array([p0[0] != gridshape[0], p0[1] != gridshape[1], p0[2] != gridshape[2]], dtype=np.int64)
+    r = shifted - p0
+    return p0, p1, r
+
+
+def gather_corners(grid: np.ndarray, p0, p1) -> np.ndarray:
+    """grids.jl:227-244 -- X[8*c + corner], corner = x + 2y + 4z (x fastest)."""
+    x0, y0, z0 = (int(v) - 1 for v in p0)
+    x1, y1, z1 = (int(v) - 1 for v in p1)
+    X = np.empty(64, dtype=np.float64)
+    t = 0
+    for c in range(8):
+        for (z, y, x) in ((z0, y0, x0), (z0, y0, x1), (z0, y1, x0), (z0, y1, x1),
+                          (z1, y0, x0), (z1, y0, x1), (z1, y1, x0), (z1, y1, x1)):
+            X[t] = grid[c, x, y, z]
+            t += 1
+    return X
+
+
+def interpolate_from_corners(X: np.ndarray, r, is_vdw: bool) -> float:
+    """grids.jl:245-258"""
+    if is_vdw and np.any(X[:8] > 5e6):
+        return 1e100
+    a = tricubic_coeff() @ X
+    rx, ry, rz = (float(v) for v in r)
+    rxs = (1.0, rx, rx * rx, rx * rx * rx)
+    rys = (1.0, ry, ry * ry, ry * ry * ry)
+    rzs = (1.0, rz, rz * rz, rz * rz * rz)
+    ret = 0.0
+    for k in range(4):
+        for j in range(4):
+            for i in range(4):
+                ret += a[i + 4 * j + 16 * k] * rxs[i] * rys[j] * rzs[k]
+    return ret
+
+
+def interpolate_grid(g: EnergyGrid, point) -> float:
+    """grids.jl:212-273 (K)."""
+    if g.ewald_precision == -math.inf:
+        return 0.0
+    if math.isnan(g.ewald_precision):
+        raise ValueError("Invalid grid cannot be interpolated!")
+    _, nx, ny, nz = g.grid.shape
+    p0, p1, r = interpolation_stencil(g.csetup, (nx, ny, nz), point)
+    if not g.higherorder:
+        raise NotImplementedError("raw-value grids are not produced by this package")
+    X = gather_corners(g.grid, p0, p1)
+    return interpolate_from_corners(X, r, g.ewald_precision == math.inf)
+
+
+# ------------------------------------------------------------------ block files
+@dataclass
+class BlockFile:
+    """coordinates.jl:83-101"""
+    csetup: GridCoordinatesSetup
+    block: Optional[np.ndarray] = None     # bool[nx,ny,nz]
+
+    @property
+    def empty(self) -> bool:
+        return self.block is None or not self.block.any()
+
+    def __getitem__(self, pos) -> bool:
+        if self.empty:
+            return False
+        a, b, c = np.round(offsetpoint(pos, self.csetup)).astype(np.int64)   # RoundNearest ties-to-even, like Julia
+        return bool(self.block[a - 1, b - 1, c - 1])
+
+
+def parse_blockfile(file, csetup: GridCoordinatesSetup) -> BlockFile:
+    """coordinates.jl:112-167 (min-image sphere test on every grid point)."""
+    from .coordinates import inverse_offsetpoint
+    from .utils import prepare_periodic_distance_computations
+    with open(file) as f:
+        lines = f.read().splitlines()
+    num = int(lines.pop(0))
+    if num == 0:
+        return BlockFile(csetup)
+    a, b, c = (int(d) + 1 for d in csetup.dims)
+    mat, invmat = csetup.cell.mat, csetup.cell.invmat
+    ortho, safemin = prepare_periodic_distance_computations(mat)
+    safemin2 = safemin ** 2
+    ii, jj, kk = np.meshgrid(np.arange(1, a + 1), np.arange(1, b + 1), np.arange(1, c + 1), indexing="ij")
+    pts = (np.stack([ii, jj, kk], axis=-1).reshape(-1, 3) - 1) * csetup.delta + csetup.shift
+    block = np.zeros(a * b * c, dtype=bool)
+    for l in lines[:num]:
+        sl = l.split()
+        radius = float(sl.pop())
+        _center = mat @ np.array([float(x) for x in sl])
+        center = inverse_offsetpoint(offsetpoint(_center, csetup), csetup)
+        d = center[None, :] - pts
+        f = d @ invmat.T
+        f = (f + 0.5) - np.floor(f + 0.5) - 0.5
+        v = f @ mat.T
+        d2 = (v ** 2).sum(axis=1)
+        if not ortho:
+            need = d2 > safemin2
+            if need.any():
+                fn = f[need]
+                best = d2[need].copy()
+                found = np.zeros(len(best), dtype=bool)
+                for ax in range(3):
+                    for s in (1.0, -1.0):
+                        g = fn.copy()
+                        g[:, ax] += s
+                        w = g @ mat.T
+                        n2 = (w ** 2).sum(axis=1)
+                        take = (~found) & (n2 < d2[need])
+                        best[take] = n2[take]
+                        found |= take
+                d2[need] = best
+        block |= d2 < radius * radius
+    return BlockFile(csetup, block.reshape(a, b, c))
+
+
+# ------------------------------------------------------------------ CrystalEnergySetup
+@dataclass
+class CrystalEnergySetup:
+    """grids.jl:284-294"""
+    framework: object
+    molecule: object
+    coulomb: EnergyGrid
+    charges: List[float]
+    grids: List[EnergyGrid]
+    atomsidx: List[int]          # 0-based index into ``grids``
+    ewald: EwaldFramework
+    forcefield: ForceField
+    block: BlockFile
+
+
+def energy_point(setup: CrystalEnergySetup, positions) -> Tuple[float, float]:
+    """grids.jl:311-327 -> (vdw, coulomb) in K."""
+    positions = [np.asarray(p, dtype=np.float64) for p in positions]
+    for pos in positions:
+        if setup.block[pos]:
+            return 1e100, 0.0
+    num_atoms = len(setup.atomsidx)
+    vdw = sum(interpolate_grid(setup.grids[setup.atomsidx[i]], positions[i]) for i in range(num_atoms))
+    if setup.coulomb.ewald_precision == -math.inf:
+        return vdw, 0.0
+    coulomb_direct = sum(setup.charges[i] * interpolate_grid(setup.coulomb, positions[i]) for i in range(num_atoms))
+    newmolecule = setup.molecule.with_positions(positions)
+    coulomb_reciprocal = compute_ewald(setup.ewald, ((newmolecule,),))
+    return vdw, coulomb_direct + coulomb_reciprocal

@@ -1,0 +1,142 @@
+"""``setup_RASPA`` and the on-disk grid cache (mirror of ``src/raspa.jl:367-531``).
+These are the *callers* of the hot path: they are kept signature-compatible so code
+written against the reference's ``setup_RASPA`` / ``energy_point`` reads the same."""
+from __future__ import annotations
+
+import math
+import os
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from .ewald import EwaldFramework, initialize_ewald
+from .forcefields import ForceField
+from .grids import (BlockFile, CrystalEnergySetup, EnergyGrid, create_grid_coulomb, create_grid_vdw,
+                    parse_blockfile, parse_grid)
+from .coordinates import GridCoordinatesSetup
+from .raspa import (RASPASystem, _ff, _ffname, _ffpal, getdir_RASPA, load_framework_RASPA,
+                    load_molecule_RASPA)
+from .utils import find_supercell, get_atom_name
+
+
+def default_system(s, pff) -> RASPASystem:
+    """raspa.jl:367-381 (single atom defined in the framework force field)."""
+    forcefield = _ff(pff)
+    if isinstance(s, RASPASystem):
+        return s
+    symbol = get_atom_name(s)
+    if symbol not in forcefield.sdict:
+        return load_molecule_RASPA(s, "Default", forcefield)
+    pseudo = _ffpal(pff)[symbol]
+    return RASPASystem(np.diag([np.inf] * 3), np.zeros((1, 3)), [symbol], np.array([pseudo.mass]),
+                       np.array([pseudo.charge]), True)
+
+
+def decide_parse_block(blockfile, molecule: RASPASystem, framework_name) -> str:
+    """raspa.jl:383-395"""
+    if isinstance(framework_name, np.ndarray):
+        return ""
+    if isinstance(blockfile, (bool, str)):
+        newblockfile = blockfile
+    else:
+        newblockfile = not (len(molecule) == 1 and molecule.atomic_charge[0] > np.finfo(float).eps)
+    if isinstance(newblockfile, bool):
+        if not newblockfile:
+            return ""
+        return str(framework_name).split('_')[0]
+    return str(newblockfile)
+
+
+def parse_block(blockfile, framework_name, framework: RASPASystem, molecule: RASPASystem, spacing: float) -> BlockFile:
+    """raspa.jl:397-403"""
+    blockpath = decide_parse_block(blockfile, molecule, framework_name)
+    csetup = GridCoordinatesSetup.from_cell(framework.mat, spacing)
+    if not blockpath:
+        return BlockFile(csetup)
+    return parse_blockfile(os.path.join(getdir_RASPA(), "structures", "block", blockpath) + ".block", csetup)
+
+
+def grid_locations(framework, pff, forcefield: ForceField, atoms: List[str], gridstep: float, supercell):
+    """raspa.jl:405-420 (the hashed name used for non-string force fields is replaced by
+    the plain name: StableHashTraits is third-party and irrelevant to the hot path)."""
+    if isinstance(framework, np.ndarray):
+        return "", []
+    rawname = _ffname(pff)
+    raspa = getdir_RASPA()
+    rootdir = os.path.join(raspa, "grids", rawname, framework)
+    grid_dir = os.path.join(rootdir, "%.6f" % gridstep)
+    supercell_name = "x".join(str(x) for x in supercell)
+    coulomb_grid_path = os.path.join(grid_dir, supercell_name, framework + "_Electrostatics_Ewald.grid")
+    with open(os.path.join(raspa, "forcefield", rawname, "force_field_mixing_rules.def")) as f:
+        trunc_or_shift = next(l for l in f.read().splitlines() if not l.startswith('#')).strip()
+    vdws = [os.path.join(grid_dir, f"{framework}_{atom}_{trunc_or_shift}.grid") for atom in atoms]
+    return coulomb_grid_path, vdws
+
+
+def retrieve_or_create_grid(grid_path, syst_framework, forcefield: ForceField, gridstep, atom_or_eframework,
+                            mat, new: bool, cutoff: float, ngpus: int = 1) -> EnergyGrid:
+    """raspa.jl:420-439"""
+    if not grid_path or math.isinf(cutoff):
+        return EnergyGrid.trivial(False)
+    if cutoff != 12.0:
+        raise ValueError("Cutoff other than 12 Å or infinity is not supported.")
+    iscoulomb = isinstance(atom_or_eframework, EwaldFramework)
+    if not iscoulomb and not forcefield.needsvdwgrid(atom_or_eframework):
+        return EnergyGrid.trivial(True)
+    if new or not os.path.isfile(grid_path):
+        os.makedirs(os.path.dirname(grid_path), exist_ok=True)
+        if iscoulomb:
+            create_grid_coulomb(grid_path, syst_framework, forcefield, gridstep, atom_or_eframework, ngpus)
+        else:
+            create_grid_vdw(grid_path, syst_framework, forcefield, gridstep, atom_or_eframework, ngpus)
+    return parse_grid(grid_path, iscoulomb, mat)
+
+
+def setup_RASPA(framework, pff, molecule, ffname_molecule: Optional[str] = None, *, gridstep: float = 0.15,
+                supercell=None, blockfile=None, new: bool = False, cutoff: float = 12.0,
+                ngpus: int = 1) -> CrystalEnergySetup:
+    """raspa.jl:472-531.  ``molecule`` may be a molecule name (with ``ffname_molecule``),
+    a RASPASystem, or the name of a single atom of the framework force field."""
+    syst_framework = load_framework_RASPA(framework, pff)
+    if isinstance(molecule, RASPASystem):
+        syst_mol = molecule
+    elif ffname_molecule is not None:
+        syst_mol = load_molecule_RASPA(molecule, ffname_molecule, pff, syst_framework)
+    else:
+        syst_mol = default_system(molecule, pff)
+    if supercell is None:
+        supercell = (1, 1, 1) if math.isinf(cutoff) else find_supercell(syst_framework.mat, cutoff)
+    mat = syst_framework.mat
+    forcefield = _ff(pff, cutoff=cutoff)
+    block = parse_block(blockfile, framework, syst_framework, syst_mol, gridstep)
+
+    atomdict = {}
+    atoms = list(syst_mol.atomic_symbol)
+    for atom in atoms:
+        atomdict.setdefault(atom, len(atomdict))
+    atomsidx = [atomdict[a] for a in atoms]
+    rev_atomdict = [None] * len(atomdict)
+    for at, i in atomdict.items():
+        rev_atomdict[i] = at
+    coulomb_grid_path, vdws = grid_locations(framework, pff, forcefield, rev_atomdict, gridstep, supercell)
+
+    needcoulomb = any(q != 0 for q in syst_mol.atomic_charge)
+    if needcoulomb:
+        ewald = initialize_ewald(syst_framework, supercell)
+        if isinstance(framework, np.ndarray):
+            coulomb = EnergyGrid.trivial(True)
+        else:
+            coulomb = retrieve_or_create_grid(coulomb_grid_path, syst_framework, forcefield, gridstep, ewald,
+                                              mat, new, cutoff, ngpus)
+    else:
+        coulomb, ewald = EnergyGrid.trivial(True), EwaldFramework.empty(mat)
+
+    grids: List[EnergyGrid] = [None] * len(atomdict)  # type: ignore[list-item]
+    for atom, i in atomdict.items():
+        if isinstance(framework, np.ndarray):
+            grids[i] = EnergyGrid.trivial(True)
+        else:
+            grids[i] = retrieve_or_create_grid(vdws[i], syst_framework, forcefield, gridstep, atom, mat, new,
+                                               cutoff, ngpus)
+    charges = [float(q) for q in syst_mol.atomic_charge]
+    return CrystalEnergySetup(syst_framework, syst_mol, coulomb, charges, grids, atomsidx, ewald, forcefield, block)

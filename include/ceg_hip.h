@@ -1,0 +1,199 @@
+/*
+ * ceg_hip.h -- C ABI of libceg_hip.so, the MI355X (gfx950) energy-grid builder.
+ *
+ * Drop-in boundary for the grid-build hot path of CrystalEnergyGrids.jl.  The
+ * reference has no FFI of its own (it is 100 % Julia); the boundary is placed
+ * at the two loop nests that fill the grid array:
+ *
+ *     create_grid_vdw      src/grids.jl:144-150   (calls src/probes.jl:71-92)
+ *     create_grid_coulomb  src/grids.jl:171-177   (calls src/probes.jl:94-117)
+ *
+ * Everything above those loops (CIF / force-field parsing, ProbeSystem,
+ * GridCoordinatesSetup, initialize_ewald, unit constants, the .grid writer)
+ * stays in the host language and hands this library plain arrays.
+ *
+ * Conventions
+ *   - all pointers are borrowed for the duration of the call; nothing is retained
+ *     except inside a ceg_plan_t, which copies what it needs to the device;
+ *   - 3x3 matrices are column-major (Julia SMatrix order);
+ *   - return value 0 = ok, <0 = error, message via ceg_last_error() (thread-local);
+ *   - no physical constants live in the library: lambda / threshold / alpha are
+ *     arguments computed by the host (src/grids.jl:141-143,168-170, src/ewald.jl:198-204);
+ *   - there is NO CPU fallback: without a HIP device every compute entry point
+ *     returns CEG_ERR_NO_DEVICE.
+ */
+#ifndef CEG_HIP_H
+#define CEG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CEG_ABI_VERSION 1
+
+/* error codes */
+#define CEG_OK                 0
+#define CEG_ERR_INVALID       -1   /* bad argument (null pointer, negative size, ...)        */
+#define CEG_ERR_NO_DEVICE     -2   /* no HIP device / requested device not present           */
+#define CEG_ERR_HIP           -3   /* a HIP runtime call failed                              */
+#define CEG_ERR_RULE          -4   /* rule kind not valid in a VdW grid (mirrors the Julia
+                                      error()/throw sites of src/interactions.jl:442-467)    */
+#define CEG_ERR_UNSUPPORTED   -5
+
+/* Interaction kinds.  Numeric values = order of `@enum InteractionKind`,
+ * src/interactions.jl:23-33. */
+enum ceg_kind {
+    CEG_HARDSPHERE            = 0,
+    CEG_COULOMB_EWALD_DIRECT  = 1,
+    CEG_COULOMB               = 2,
+    CEG_LENNARDJONES          = 3,
+    CEG_BUCKINGHAM            = 4,
+    CEG_MONOMIAL              = 5,
+    CEG_EXPONENTIAL           = 6,
+    CEG_UNDEFINED_INTERACTION = 7,
+    CEG_NOINTERACTION         = 8
+};
+
+/* One InteractionRule (src/interactions.jl:232-237): kind, params (<=3), shift.
+ * An InteractionRuleSum (src/interactions.jl:557-583) is a run of these. */
+typedef struct ceg_rule {
+    int32_t kind;
+    int32_t _pad;
+    double  p[3];
+    double  shift;
+} ceg_rule_t;
+
+/* Algorithm selector for the build entry points. */
+enum ceg_algo {
+    CEG_ALGO_AUTO       = 0,  /* culled when the supercell allows it, else brute force   */
+    CEG_ALGO_BRUTEFORCE = 1,  /* every atom tested for every point, literal min-image
+                                 routine (src/utils.jl:210-246); reference loop shape    */
+    CEG_ALGO_CULLED     = 2   /* lattice-image list + spatial bins; same selection rule
+                                 as the reference, evaluated per image                   */
+};
+
+/* ---- library / device info ------------------------------------------------ */
+int         ceg_abi_version(void);
+int         ceg_device_count(void);         /* number of HIP devices, 0 if none   */
+const char* ceg_last_error(void);           /* thread-local, never NULL           */
+
+/* ---- one-shot host API ---------------------------------------------------- */
+/*
+ * Fills `grid` exactly like the loop nest of create_grid_vdw (src/grids.jl:144-150):
+ * for every (i,j,k) in 0:dims[0] x 0:dims[1] x 0:dims[2],
+ *   pos   = abc_to_xyz(i,j,k)                       src/coordinates.jl:72-76
+ *   deriv = compute_derivatives_vdw(probe, pos)     src/probes.jl:71-92
+ *   _set_gridpoint!(grid,i,j,k,delta,lambda,threshold,deriv)  src/grids.jl:118-135
+ *
+ *  pos       [3*natoms]  cartesian A, supercell-tiled ProbeSystem.positions (src/probes.jl:29-55)
+ *  atomkind  [natoms]    1-based force-field index   (src/probes.jl:23,54)
+ *  mat,invmat            supercell matrix / inverse  (src/probes.jl:27-28), column-major
+ *  ortho,safemin2        from prepare_periodic_distance_computations (src/utils.jl:146-155)
+ *  cutoff2               forcefield.cutoff^2         (src/probes.jl:75)
+ *  rules,rule_offset     rules[rule_offset[k-1] .. rule_offset[k]) = flattened
+ *                        forcefield.interactions[k, probe] (src/forcefields.jl:302-304);
+ *                        rule_offset has nkinds+1 entries
+ *  dims,size,shift,delta GridCoordinatesSetup fields (src/coordinates.jl:32-41), A
+ *  lambda,threshold      1/GRID_TO_KELVIN, GRID_TO_KELVIN*1e7 (src/grids.jl:141-143,148)
+ *  grid      [(dims[2]+1)*(dims[1]+1)*(dims[0]+1)*8] float, host memory,
+ *            column-major [z,y,x,channel] (src/grids.jl:126-133)
+ *  ngpus     1..ceg_device_count(): x-slabs are spread over that many devices
+ */
+int ceg_grid_vdw(const double* pos, const int64_t* atomkind, int64_t natoms,
+                 const double mat[9], const double invmat[9],
+                 int32_t ortho, double safemin2, double cutoff2,
+                 const ceg_rule_t* rules, const int32_t* rule_offset, int32_t nkinds,
+                 const int32_t dims[3], const double size[3], const double shift[3],
+                 const double delta[3],
+                 double lambda, double threshold,
+                 float* grid, int32_t ngpus);
+
+/*
+ * Same for create_grid_coulomb (src/grids.jl:171-177) with
+ * compute_derivatives_ewald (src/probes.jl:94-117) / derivatives_ewald
+ * (src/ewald.jl:299-312).
+ *  charge [natoms] e, alpha = ewald.alpha in 1/A,
+ *  lambda = COULOMBIC_CONVERSION_FACTOR/GRID_TO_KELVIN, threshold = 1e7/lambda
+ *  (src/grids.jl:169-170).
+ */
+int ceg_grid_coulomb(const double* pos, const double* charge, int64_t natoms,
+                     const double mat[9], const double invmat[9],
+                     int32_t ortho, double safemin2, double cutoff2, double alpha,
+                     const int32_t dims[3], const double size[3], const double shift[3],
+                     const double delta[3],
+                     double lambda, double threshold,
+                     float* grid, int32_t ngpus);
+
+/* ---- resident-plan API (device buffers, caller-owned stream) ---------------- */
+/*
+ * A plan is one ProbeSystem + one GridCoordinatesSetup made resident on one
+ * device: atom table, rule table, lattice-image list and spatial bins.  It is
+ * what a multi-process driver (one rank per GPU) uses: each rank builds its
+ * own x-slab [i_begin, i_end) into device memory on its own stream and the
+ * slabs are then exchanged by the caller (RCCL all-gather).
+ *
+ * rules/rule_offset/nkinds/atomkind may be NULL/0 for a Coulomb-only plan;
+ * charge may be NULL for a VdW-only plan.
+ */
+typedef struct ceg_plan ceg_plan_t;
+
+int ceg_plan_create(ceg_plan_t** plan, int32_t device,
+                    const double* pos, const int64_t* atomkind, const double* charge,
+                    int64_t natoms,
+                    const double mat[9], const double invmat[9],
+                    int32_t ortho, double safemin2, double cutoff2,
+                    const ceg_rule_t* rules, const int32_t* rule_offset, int32_t nkinds,
+                    double alpha,
+                    const int32_t dims[3], const double size[3], const double shift[3],
+                    const double delta[3]);
+int ceg_plan_destroy(ceg_plan_t* plan);
+
+/* 1 if the culled algorithm is valid for this plan (every perpendicular width of
+ * `mat` is >= 2*cutoff, which ProbeSystem guarantees, src/probes.jl:24), else 0. */
+int ceg_plan_can_cull(const ceg_plan_t* plan);
+
+/* number of lattice images kept by the culled algorithm (0 before first use) */
+int64_t ceg_plan_num_images(const ceg_plan_t* plan);
+
+/*
+ * Build x-planes i in [i_begin, i_end) (0 <= i_begin <= i_end <= dims[0]+1).
+ * Element (k,j,i,c) is written at
+ *     d_out[c*channel_stride + ((i - i_origin)*(dims[1]+1) + j)*(dims[2]+1) + k]
+ * so the same call serves a full grid buffer (i_origin = 0, channel_stride =
+ * full grid points) or a compact slab (i_origin = i_begin, channel_stride =
+ * slab points).  d_out is DEVICE memory on the plan's device; `stream` is a
+ * hipStream_t (NULL = default stream).  The call is asynchronous.
+ */
+int ceg_plan_build_vdw(ceg_plan_t* plan, double lambda, double threshold,
+                       int32_t i_begin, int32_t i_end,
+                       float* d_out, int64_t channel_stride, int32_t i_origin,
+                       int32_t algo, void* stream);
+int ceg_plan_build_coulomb(ceg_plan_t* plan, double lambda, double threshold,
+                           int32_t i_begin, int32_t i_end,
+                           float* d_out, int64_t channel_stride, int32_t i_origin,
+                           int32_t algo, void* stream);
+/* VdW and Coulomb grids of the same slab in one pass over the atoms (shared
+ * geometry work).  Same semantics as the two calls above. */
+int ceg_plan_build_fused(ceg_plan_t* plan,
+                         double lambda_vdw, double threshold_vdw,
+                         double lambda_coulomb, double threshold_coulomb,
+                         int32_t i_begin, int32_t i_end,
+                         float* d_out_vdw, float* d_out_coulomb,
+                         int64_t channel_stride, int32_t i_origin,
+                         int32_t algo, void* stream);
+
+/*
+ * Raw FP64 results of compute_derivatives_vdw / compute_derivatives_ewald
+ * (src/probes.jl:71-117) at arbitrary cartesian points, before
+ * _set_gridpoint!: out[8*p + 0..7] = value, d1x, d1y, d1z, d2xy, d2xz, d2yz, d3.
+ * points/out are HOST memory; synchronous.  which: 0 = vdw, 1 = coulomb.
+ */
+int ceg_plan_eval_points(ceg_plan_t* plan, int32_t which, int32_t algo,
+                         const double* points, int64_t npoints, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CEG_HIP_H */

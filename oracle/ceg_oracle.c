@@ -1,0 +1,439 @@
+/*
+ * ceg_oracle.c -- CPU restatement (plain C, FP64) of the grid-build hot path of
+ * CrystalEnergyGrids.jl.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the checker the HIP kernels are compared against.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may call it; the
+ * product path (libceg_hip.so) never links, loads or falls back to it.
+ *
+ * Pinning status: the Julia reference cannot run here (no Julia toolchain), and it
+ * ships no .grid golden file (grids are generated at test time, .gitignore:4-5).
+ * The restatement is therefore pinned to the reference only through the literals
+ * of test/runtests.jl (rtol 1e-3, see tests/test_reference_pins.py) plus analytic
+ * checks (tests/test_oracle_analytic.py).  At the 1e-6 level parity is
+ * oracle<->HIP only ("parity pinned at 1e-3 by the reference's own tests").
+ *
+ * Every function cites the reference lines it restates (paths relative to
+ * /root/reference).  Loop order, operation order and branch structure follow
+ * the Julia source; build with -ffp-contract=off so no FMA is introduced that
+ * the source does not spell.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../include/ceg_hip.h"   /* ceg_rule_t and the kind enum only */
+
+#define ORACLE_API __attribute__((visibility("default")))
+
+/* ---- src/utils.jl:226-246  periodic_distance2!(buffer, mat, ortho, safemin2, buffer2)
+ * mat is column-major: mat[i + 3*k] = M[i,k].
+ * On return buffer holds the cartesian image vector *as the reference leaves it*:
+ * on the fall-through path (no closer single-axis image found) that is the last
+ * trial image (f3 - 1), not the wrapped one, reproduced here. */
+static inline void matvec3(double out[3], const double m[9], const double v[3])
+{
+    /* StaticArrays mul!: out[i] = sum_k M[i,k]*v[k], k ascending */
+    for (int i = 0; i < 3; ++i)
+        out[i] = (m[i] * v[0] + m[i + 3] * v[1]) + m[i + 6] * v[2];
+}
+
+static inline double norm2_3(const double u[3])
+{
+    /* src/utils.jl:190-196 norm2(u): r2 += x^2 in order */
+    double r2 = 0.0;
+    r2 += u[0] * u[0];
+    r2 += u[1] * u[1];
+    r2 += u[2] * u[2];
+    return r2;
+}
+
+static double periodic_distance2(double buffer[3], const double mat[9], int ortho,
+                                 double safemin2, double buffer2[3])
+{
+    for (int i = 0; i < 3; ++i) {               /* utils.jl:227-230 */
+        double diff = buffer2[i] + 0.5;
+        buffer2[i] = diff - floor(diff) - 0.5;
+    }
+    matvec3(buffer, mat, buffer2);              /* :231 */
+    double ref2 = norm2_3(buffer);              /* :232 */
+    if (ortho || ref2 <= safemin2) return ref2; /* :233 */
+    for (int i = 0; i < 3; ++i) {               /* :234-244 */
+        buffer2[i] += 1;
+        matvec3(buffer, mat, buffer2);
+        double newnorm2 = norm2_3(buffer);
+        if (newnorm2 < ref2) return newnorm2;
+        buffer2[i] -= 2;
+        matvec3(buffer, mat, buffer2);
+        newnorm2 = norm2_3(buffer);
+        if (newnorm2 < ref2) return newnorm2;
+        buffer2[i] += 1;
+    }
+    return ref2;                                /* :245 */
+}
+
+/* ---- src/utils.jl:210-213 periodic_distance2_fromcartesian! */
+static double periodic_distance2_fromcartesian(double buffer[3], const double mat[9],
+                                               const double invmat[9], int ortho,
+                                               double safemin2, double buffer2[3])
+{
+    matvec3(buffer2, invmat, buffer);
+    return periodic_distance2(buffer, mat, ortho, safemin2, buffer2);
+}
+
+ORACLE_API double oracle_periodic_distance2_fromcartesian(double buffer[3], const double mat[9],
+                                                          const double invmat[9], int ortho,
+                                                          double safemin2)
+{
+    double buffer2[3];
+    return periodic_distance2_fromcartesian(buffer, mat, invmat, ortho, safemin2, buffer2);
+}
+
+/* ---- src/interactions.jl:432-472 derivativesGrid(rule::InteractionRule, d2)
+ * returns 0 ok, <0 for the kinds on which the reference throws. */
+static int derivatives_grid_rule(const ceg_rule_t* rule, double r2, double out[4])
+{
+    double value, d1, d2, d3;
+    switch (rule->kind) {
+    case CEG_LENNARDJONES: {                       /* :434-441 */
+        double eps = rule->p[0], sigma = rule->p[1];
+        double s = (sigma * sigma) / r2;
+        double x6 = s * s * s;                      /* (σ^2/r2)^3 = Base.literal_pow: x*x*x */
+        double r4 = r2 * r2;
+        value = 4 * eps * x6 * (x6 - 1);
+        d1 = 24 * eps * (x6 * (1 - 2 * x6)) / r2;
+        d2 = 96 * eps * (x6 * (7 * x6 - 2)) / r4;
+        d3 = 384 * eps * (x6 * (5 - 28 * x6)) / (r4 * r4);
+        break;
+    }
+    case CEG_COULOMB:                               /* :442-443 error(...) */
+        return CEG_ERR_RULE;
+    case CEG_HARDSPHERE: {                          /* :444-446 */
+        double rr = rule->p[0] + rule->p[1];
+        value = (r2 < rr * rr) ? INFINITY : 0.0;
+        d1 = d2 = d3 = 0.0;
+        break;
+    }
+    case CEG_BUCKINGHAM: {                          /* :447-457 */
+        double A = rule->p[0], B = rule->p[1], C = rule->p[2];
+        double r4 = r2 * r2;
+        double r = sqrt(r2);
+        double r6 = r4 * r2;
+        double x6 = C / r6;
+        double xe = A * exp(-B * r);
+        value = xe - x6;
+        d1 = -B * xe / r + 6 * x6 / r2;
+        d2 = -48 * x6 / r4 + B * xe * (1 + B * r) / (r2 * r);
+        d3 = -(3 * B * r + B * B * r2 + 3) * B * xe * r / r6 + 480 * C / (r6 * r6);
+        break;
+    }
+    case CEG_NOINTERACTION:
+    case CEG_COULOMB_EWALD_DIRECT:                  /* :458-461 early return, shift not applied */
+        out[0] = out[1] = out[2] = out[3] = 0.0;
+        return 0;
+    case CEG_MONOMIAL:                              /* :462-465 error(...) */
+    case CEG_EXPONENTIAL:
+    case CEG_UNDEFINED_INTERACTION:                 /* :466-467 throw */
+    default:
+        return CEG_ERR_RULE;
+    }
+    out[0] = value - rule->shift;                   /* :471 */
+    out[1] = d1;
+    out[2] = d2;
+    out[3] = d3;
+    return 0;
+}
+
+/* ---- src/interactions.jl:599-610 derivativesGrid(f::InteractionRuleSum, d2)
+ *      src/forcefields.jl:302-304 derivatives_nocutoff
+ * A single InteractionRule is a run of length 1 (0 + x == x exactly for the
+ * finite, inf and nan values that occur, except -0.0 which cannot be observed
+ * after accumulation). */
+static int derivatives_nocutoff(const ceg_rule_t* rules, int nrules, double r2, double out[4])
+{
+    if (nrules == 1) return derivatives_grid_rule(rules, r2, out);
+    double value = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+    for (int x = 0; x < nrules; ++x) {
+        double t[4];
+        int rc = derivatives_grid_rule(rules + x, r2, t);
+        if (rc) return rc;
+        value += t[0];
+        d1 += t[1];
+        d2 += t[2];
+        d3 += t[3];
+    }
+    out[0] = value; out[1] = d1; out[2] = d2; out[3] = d3;
+    return 0;
+}
+
+ORACLE_API int oracle_derivatives_grid(const ceg_rule_t* rules, int nrules, double r2, double out[4])
+{
+    return derivatives_nocutoff(rules, nrules, r2, out);
+}
+
+/* ---- src/ewald.jl:299-312 derivatives_ewald(ewald, charge, r2) */
+static void derivatives_ewald(double alpha, double charge, double r2, double out[4])
+{
+    const double sqrtpi = 1.7724538509055160273; /* sqrt(π) */
+    double r = sqrt(r2);
+    double r3 = r2 * r;
+    double r5 = r3 * r2;
+    double a = alpha;
+    double r2a2 = r2 * (a * a);
+    double er2a2 = 2 * a * r * exp(-r2a2) / sqrtpi;
+    double erfar = erfc(a * r);
+    out[0] = charge * erfar / r;
+    out[1] = -charge * (er2a2 + erfar) / r3;
+    out[2] = charge * (er2a2 * (3 + 2 * r2a2) + 3 * erfar) / r5;
+    out[3] = charge * (-er2a2 * (15 + 10 * r2a2 + 4 * (r2a2 * r2a2)) - 15 * erfar) / (r5 * r2);
+}
+
+ORACLE_API void oracle_derivatives_ewald(double alpha, double charge, double r2, double out[4])
+{
+    derivatives_ewald(alpha, charge, r2, out);
+}
+
+/* ---- src/probes.jl:71-92 compute_derivatives_vdw(s, pos)
+ * out8 = value, d1[3], d2[3], d3 */
+ORACLE_API int oracle_compute_derivatives_vdw(
+    const double* positions, const int64_t* atomkinds, int64_t natoms,
+    const double mat[9], const double invmat[9], int ortho, double safemin2, double cutoff2,
+    const ceg_rule_t* rules, const int32_t* rule_offset,
+    const double pos[3], double out8[8])
+{
+    double buffer[3], buffer2[3];
+    double value = 0.0, d1[3] = {0, 0, 0}, d2[3] = {0, 0, 0}, d3 = 0.0;
+    for (int64_t i = 0; i < natoms; ++i) {                       /* :80 */
+        buffer[0] = pos[0] - positions[3 * i + 0];               /* :81 */
+        buffer[1] = pos[1] - positions[3 * i + 1];
+        buffer[2] = pos[2] - positions[3 * i + 2];
+        double dd2 = periodic_distance2_fromcartesian(buffer, mat, invmat, ortho, safemin2, buffer2);
+        if (dd2 >= cutoff2) continue;                            /* :83 */
+        int64_t k = atomkinds[i] - 1;
+        double t[4];
+        int rc = derivatives_nocutoff(rules + rule_offset[k], rule_offset[k + 1] - rule_offset[k], dd2, t);
+        if (rc) return rc;
+        value += t[0];                                           /* :85 */
+        d1[0] += t[1] * buffer[0];                               /* :86 */
+        d1[1] += t[1] * buffer[1];
+        d1[2] += t[1] * buffer[2];
+        double d13 = buffer[0] * buffer[2];                      /* :87 */
+        d2[0] += t[2] * (buffer[0] * buffer[1]);                 /* :88 */
+        d2[1] += t[2] * d13;
+        d2[2] += t[2] * (buffer[1] * buffer[2]);
+        d3 += t[3] * d13 * buffer[1];                            /* :89 */
+    }
+    out8[0] = value;
+    out8[1] = d1[0]; out8[2] = d1[1]; out8[3] = d1[2];
+    out8[4] = d2[0]; out8[5] = d2[1]; out8[6] = d2[2];
+    out8[7] = d3;
+    return 0;
+}
+
+/* ---- src/probes.jl:94-117 compute_derivatives_ewald(s, ewald, pos) */
+ORACLE_API int oracle_compute_derivatives_ewald(
+    const double* positions, const double* charges, int64_t natoms,
+    const double mat[9], const double invmat[9], int ortho, double safemin2, double cutoff2,
+    double alpha, const double pos[3], double out8[8])
+{
+    double buffer[3], buffer2[3];
+    double value = 0.0, d1[3] = {0, 0, 0}, d2[3] = {0, 0, 0}, d3 = 0.0;
+    double smallest_d2 = INFINITY;                               /* :104 */
+    for (int64_t i = 0; i < natoms; ++i) {
+        buffer[0] = pos[0] - positions[3 * i + 0];
+        buffer[1] = pos[1] - positions[3 * i + 1];
+        buffer[2] = pos[2] - positions[3 * i + 2];
+        double dd2 = periodic_distance2_fromcartesian(buffer, mat, invmat, ortho, safemin2, buffer2);
+        if (dd2 >= cutoff2) continue;
+        smallest_d2 = (dd2 < smallest_d2) ? dd2 : smallest_d2;   /* :108 min */
+        double t[4];
+        derivatives_ewald(alpha, charges[i], dd2, t);
+        value += t[0];
+        d1[0] += t[1] * buffer[0];
+        d1[1] += t[1] * buffer[1];
+        d1[2] += t[1] * buffer[2];
+        double d13 = buffer[0] * buffer[2];
+        d2[0] += t[2] * (buffer[0] * buffer[1]);
+        d2[1] += t[2] * d13;
+        d2[2] += t[2] * (buffer[1] * buffer[2]);
+        d3 += t[3] * d13 * buffer[1];
+    }
+    out8[0] = (smallest_d2 < 1.0) ? INFINITY : value;            /* :116 */
+    out8[1] = d1[0]; out8[2] = d1[1]; out8[3] = d1[2];
+    out8[4] = d2[0]; out8[5] = d2[1]; out8[6] = d2[2];
+    out8[7] = d3;
+    return 0;
+}
+
+/* ---- src/grids.jl:118-135 _set_gridpoint!(grid,i,j,k,Δ,λ,λ⁻¹e7,derivatives)
+ * npts = (dims[2]+1)*(dims[1]+1)*(dims[0]+1): channel stride of the column-major
+ * [z,y,x,c] array; idx = k + nz*(j + ny*i). */
+static inline double clamp_julia(double x, double lo, double hi)
+{
+    /* Base.clamp: ifelse(x > hi, hi, ifelse(x < lo, lo, x)) -- NaN passes through */
+    return (x > hi) ? hi : ((x < lo) ? lo : x);
+}
+
+ORACLE_API void oracle_set_gridpoint(float* grid, int64_t idx, int64_t npts, const double delta[3],
+                                     double lambda, double thr, const double d[8])
+{
+    double value = d[0];
+    double d1[3] = {d[1], d[2], d[3]};
+    double d2[3] = {d[4], d[5], d[6]};
+    double d3 = d[7];
+    if (value > thr) {                                   /* :120-125 */
+        value = 2 * thr;
+        d1[0] = clamp_julia(d1[0], -thr, thr);
+        d1[1] = clamp_julia(d1[1], -thr, thr);
+        d1[2] = clamp_julia(d1[2], -thr, thr);
+        d2[0] = d2[1] = d2[2] = 0.0;
+        d3 = 0.0;
+    }
+    grid[idx + 0 * npts] = (float)(value * lambda);                              /* :126 */
+    grid[idx + 1 * npts] = (float)(d1[0] * delta[0] * lambda);                   /* :127 */
+    grid[idx + 2 * npts] = (float)(d1[1] * delta[1] * lambda);
+    grid[idx + 3 * npts] = (float)(d1[2] * delta[2] * lambda);
+    grid[idx + 4 * npts] = (float)(d2[0] * (delta[0] * delta[1]) * lambda);      /* :130 */
+    grid[idx + 5 * npts] = (float)(d2[1] * (delta[0] * delta[2]) * lambda);
+    grid[idx + 6 * npts] = (float)(d2[2] * (delta[1] * delta[2]) * lambda);
+    grid[idx + 7 * npts] = (float)(d3 * (delta[0] * delta[1] * delta[2]) * lambda); /* :133 */
+}
+
+/* ---- src/coordinates.jl:72-76 abc_to_xyz: (i*size)/dims + shift */
+static inline void abc_to_xyz(const int32_t dims[3], const double size[3], const double shift[3],
+                              int i, int j, int k, double pos[3])
+{
+    pos[0] = (double)i * size[0] / (double)dims[0] + shift[0];
+    pos[1] = (double)j * size[1] / (double)dims[1] + shift[1];
+    pos[2] = (double)k * size[2] / (double)dims[2] + shift[2];
+}
+
+ORACLE_API void oracle_abc_to_xyz(const int32_t dims[3], const double size[3], const double shift[3],
+                                  int32_t i, int32_t j, int32_t k, double pos[3])
+{
+    abc_to_xyz(dims, size, shift, i, j, k, pos);
+}
+
+/* ---- src/grids.jl:144-150 loop nest of create_grid_vdw, restricted to x-planes
+ * [i_begin, i_end) so a bounded sample can be timed; threaded over i like
+ * Threads.@threads (grids.jl:144).  raw8 (optional, may be NULL) receives the
+ * FP64 derivatives of every point before _set_gridpoint!, [8*idx + c]. */
+ORACLE_API int oracle_grid_vdw(
+    const double* positions, const int64_t* atomkinds, int64_t natoms,
+    const double mat[9], const double invmat[9], int ortho, double safemin2, double cutoff2,
+    const ceg_rule_t* rules, const int32_t* rule_offset, int32_t nkinds,
+    const int32_t dims[3], const double size[3], const double shift[3], const double delta[3],
+    double lambda, double thr, int32_t i_begin, int32_t i_end,
+    float* grid, double* raw8, int32_t nthreads)
+{
+    (void)nkinds;
+    const int64_t nz = dims[2] + 1, ny = dims[1] + 1, nx = dims[0] + 1;
+    const int64_t npts = nz * ny * nx;
+    int err = 0;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int i = i_begin; i < i_end; ++i) {
+        for (int j = 0; j <= dims[1]; ++j)
+            for (int k = 0; k <= dims[2]; ++k) {
+                double pos[3], d[8];
+                abc_to_xyz(dims, size, shift, i, j, k, pos);
+                int rc = oracle_compute_derivatives_vdw(positions, atomkinds, natoms, mat, invmat,
+                                                        ortho, safemin2, cutoff2, rules, rule_offset,
+                                                        pos, d);
+                if (rc) { err = rc; continue; }
+                int64_t idx = k + nz * (j + ny * (int64_t)i);
+                if (raw8) memcpy(raw8 + 8 * idx, d, sizeof d);
+                if (grid) oracle_set_gridpoint(grid, idx, npts, delta, lambda, thr, d);
+            }
+    }
+    return err;
+}
+
+/* ---- src/grids.jl:171-177 loop nest of create_grid_coulomb */
+ORACLE_API int oracle_grid_coulomb(
+    const double* positions, const double* charges, int64_t natoms,
+    const double mat[9], const double invmat[9], int ortho, double safemin2, double cutoff2,
+    double alpha,
+    const int32_t dims[3], const double size[3], const double shift[3], const double delta[3],
+    double lambda, double thr, int32_t i_begin, int32_t i_end,
+    float* grid, double* raw8, int32_t nthreads)
+{
+    const int64_t nz = dims[2] + 1, ny = dims[1] + 1, nx = dims[0] + 1;
+    const int64_t npts = nz * ny * nx;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int i = i_begin; i < i_end; ++i) {
+        for (int j = 0; j <= dims[1]; ++j)
+            for (int k = 0; k <= dims[2]; ++k) {
+                double pos[3], d[8];
+                abc_to_xyz(dims, size, shift, i, j, k, pos);
+                oracle_compute_derivatives_ewald(positions, charges, natoms, mat, invmat, ortho,
+                                                 safemin2, cutoff2, alpha, pos, d);
+                int64_t idx = k + nz * (j + ny * (int64_t)i);
+                if (raw8) memcpy(raw8 + 8 * idx, d, sizeof d);
+                if (grid) oracle_set_gridpoint(grid, idx, npts, delta, lambda, thr, d);
+            }
+    }
+    return 0;
+}
+
+/* compute_derivatives_* at a list of arbitrary points (for sampled fixtures) */
+ORACLE_API int oracle_points_vdw(
+    const double* positions, const int64_t* atomkinds, int64_t natoms,
+    const double mat[9], const double invmat[9], int ortho, double safemin2, double cutoff2,
+    const ceg_rule_t* rules, const int32_t* rule_offset,
+    const double* points, int64_t npoints, double* out8, int32_t nthreads)
+{
+    int err = 0;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < npoints; ++p) {
+        int rc = oracle_compute_derivatives_vdw(positions, atomkinds, natoms, mat, invmat, ortho,
+                                                safemin2, cutoff2, rules, rule_offset,
+                                                points + 3 * p, out8 + 8 * p);
+        if (rc) err = rc;
+    }
+    return err;
+}
+
+ORACLE_API int oracle_points_coulomb(
+    const double* positions, const double* charges, int64_t natoms,
+    const double mat[9], const double invmat[9], int ortho, double safemin2, double cutoff2,
+    double alpha, const double* points, int64_t npoints, double* out8, int32_t nthreads)
+{
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < npoints; ++p)
+        oracle_compute_derivatives_ewald(positions, charges, natoms, mat, invmat, ortho, safemin2,
+                                         cutoff2, alpha, points + 3 * p, out8 + 8 * p);
+    return 0;
+}
+
+ORACLE_API int oracle_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,198 @@
+"""ctypes front-end of the CPU oracle ``libceg_oracle.so`` (see ``ceg_oracle.c``).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of bench.py -- never by the product package.  Parity status:
+pinned to the reference at rtol 1e-3 through the literals of test/runtests.jl
+(tests/test_reference_pins.py); at 1e-6 it is the HIP kernels that are compared
+with this restatement.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+LIB = HERE / "libceg_oracle.so"
+
+_dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+
+
+def build(force: bool = False) -> Path:
+    """Compile the oracle with gcc (recipe: oracle/Makefile)."""
+    src = HERE / "ceg_oracle.c"
+    if force or not LIB.exists() or LIB.stat().st_mtime < src.stat().st_mtime:
+        subprocess.check_call(["make", "-C", str(HERE), "-B", "libceg_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return LIB
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not LIB.exists():
+            build()
+        l = C.CDLL(str(LIB))
+        l.oracle_periodic_distance2_fromcartesian.restype = C.c_double
+        l.oracle_periodic_distance2_fromcartesian.argtypes = [_dp, _dp, _dp, C.c_int, C.c_double]
+        l.oracle_derivatives_grid.restype = C.c_int
+        l.oracle_derivatives_grid.argtypes = [C.c_void_p, C.c_int, C.c_double, _dp]
+        l.oracle_derivatives_ewald.restype = None
+        l.oracle_derivatives_ewald.argtypes = [C.c_double, C.c_double, C.c_double, _dp]
+        l.oracle_set_gridpoint.restype = None
+        l.oracle_set_gridpoint.argtypes = [_fp, C.c_int64, C.c_int64, _dp, C.c_double, C.c_double, _dp]
+        l.oracle_abc_to_xyz.restype = None
+        l.oracle_abc_to_xyz.argtypes = [_i32p, _dp, _dp, C.c_int32, C.c_int32, C.c_int32, _dp]
+        l.oracle_grid_vdw.restype = C.c_int
+        l.oracle_grid_vdw.argtypes = [_dp, _i64p, C.c_int64, _dp, _dp, C.c_int, C.c_double, C.c_double,
+                                      C.c_void_p, _i32p, C.c_int32, _i32p, _dp, _dp, _dp,
+                                      C.c_double, C.c_double, C.c_int32, C.c_int32, _fp, _dp, C.c_int32]
+        l.oracle_grid_coulomb.restype = C.c_int
+        l.oracle_grid_coulomb.argtypes = [_dp, _dp, C.c_int64, _dp, _dp, C.c_int, C.c_double, C.c_double,
+                                          C.c_double, _i32p, _dp, _dp, _dp,
+                                          C.c_double, C.c_double, C.c_int32, C.c_int32, _fp, _dp, C.c_int32]
+        l.oracle_points_vdw.restype = C.c_int
+        l.oracle_points_vdw.argtypes = [_dp, _i64p, C.c_int64, _dp, _dp, C.c_int, C.c_double, C.c_double,
+                                        C.c_void_p, _i32p, _dp, C.c_int64, _dp, C.c_int32]
+        l.oracle_points_coulomb.restype = C.c_int
+        l.oracle_points_coulomb.argtypes = [_dp, _dp, C.c_int64, _dp, _dp, C.c_int, C.c_double, C.c_double,
+                                            C.c_double, _dp, C.c_int64, _dp, C.c_int32]
+        l.oracle_max_threads.restype = C.c_int
+        l.oracle_max_threads.argtypes = []
+        _lib = l
+    return _lib
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _cm(m) -> np.ndarray:
+    """3x3 -> column-major 9 vector"""
+    return np.ascontiguousarray(np.asarray(m, dtype=np.float64).T.reshape(9))
+
+
+class _Probe:
+    """flat view of a ceg_hip ProbeSystem for the C calls"""
+
+    def __init__(self, probe):
+        self.pos = np.ascontiguousarray(probe.positions, dtype=np.float64)
+        self.kinds = np.ascontiguousarray(probe.atomkinds, dtype=np.int64)
+        self.q = np.ascontiguousarray(probe.charges, dtype=np.float64)
+        self.n = len(self.pos)
+        self.mat = _cm(probe.mat)
+        self.invmat = _cm(probe.invmat)
+        self.ortho, self.safemin2 = probe.periodic_setup()
+        self.cutoff2 = probe.cutoff2
+        if probe.probe:
+            self.rules, self.offsets = probe.forcefield.rule_table(probe.probe)
+            self.nkinds = probe.forcefield.nkinds
+
+
+def _geom(cset):
+    return (np.ascontiguousarray(cset.dims, dtype=np.int32), np.ascontiguousarray(cset.size, dtype=np.float64),
+            np.ascontiguousarray(cset.shift, dtype=np.float64), np.ascontiguousarray(cset.delta, dtype=np.float64))
+
+
+def grid_vdw(probe, cset, lam, thr, i_begin=0, i_end=None, want_raw=False, nthreads=0):
+    """Loop nest of create_grid_vdw (grids.jl:144-150) for x-planes [i_begin, i_end).
+    Returns (grid float32[8,nx,ny,nz], raw float64[nx,ny,nz,8] or None); planes outside the
+    range are left NaN."""
+    p = _Probe(probe)
+    dims, size, shift, delta = _geom(cset)
+    nx, ny, nz = (int(d) + 1 for d in dims)
+    i_end = nx if i_end is None else i_end
+    grid = np.full((8, nx, ny, nz), np.nan, dtype=np.float32)
+    raw = np.full((nx, ny, nz, 8), np.nan, dtype=np.float64) if want_raw else None
+    rc = lib().oracle_grid_vdw(_d(p.pos), p.kinds.ctypes.data_as(_i64p), p.n, _d(p.mat), _d(p.invmat),
+                               int(p.ortho), p.safemin2, p.cutoff2, p.rules.ctypes.data,
+                               p.offsets.ctypes.data_as(_i32p), p.nkinds,
+                               dims.ctypes.data_as(_i32p), _d(size), _d(shift), _d(delta),
+                               lam, thr, i_begin, i_end, grid.ctypes.data_as(_fp),
+                               _d(raw) if want_raw else None, nthreads)
+    if rc:
+        raise RuntimeError(f"oracle_grid_vdw: rule kind rejected by derivativesGrid (code {rc})")
+    return grid, raw
+
+
+def grid_coulomb(probe, alpha, cset, lam, thr, i_begin=0, i_end=None, want_raw=False, nthreads=0):
+    """Loop nest of create_grid_coulomb (grids.jl:171-177)."""
+    p = _Probe(probe)
+    dims, size, shift, delta = _geom(cset)
+    nx, ny, nz = (int(d) + 1 for d in dims)
+    i_end = nx if i_end is None else i_end
+    grid = np.full((8, nx, ny, nz), np.nan, dtype=np.float32)
+    raw = np.full((nx, ny, nz, 8), np.nan, dtype=np.float64) if want_raw else None
+    lib().oracle_grid_coulomb(_d(p.pos), _d(p.q), p.n, _d(p.mat), _d(p.invmat), int(p.ortho), p.safemin2,
+                              p.cutoff2, alpha, dims.ctypes.data_as(_i32p), _d(size), _d(shift), _d(delta),
+                              lam, thr, i_begin, i_end, grid.ctypes.data_as(_fp),
+                              _d(raw) if want_raw else None, nthreads)
+    return grid, raw
+
+
+def points_vdw(probe, points, nthreads=0) -> np.ndarray:
+    """compute_derivatives_vdw (probes.jl:71-92) at arbitrary points -> float64[n,8]"""
+    p = _Probe(probe)
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    out = np.empty((len(pts), 8), dtype=np.float64)
+    rc = lib().oracle_points_vdw(_d(p.pos), p.kinds.ctypes.data_as(_i64p), p.n, _d(p.mat), _d(p.invmat),
+                                 int(p.ortho), p.safemin2, p.cutoff2, p.rules.ctypes.data,
+                                 p.offsets.ctypes.data_as(_i32p), _d(pts), len(pts), _d(out), nthreads)
+    if rc:
+        raise RuntimeError(f"oracle_points_vdw: rule kind rejected (code {rc})")
+    return out
+
+
+def points_coulomb(probe, alpha, points, nthreads=0) -> np.ndarray:
+    """compute_derivatives_ewald (probes.jl:94-117) at arbitrary points -> float64[n,8]"""
+    p = _Probe(probe)
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    out = np.empty((len(pts), 8), dtype=np.float64)
+    lib().oracle_points_coulomb(_d(p.pos), _d(p.q), p.n, _d(p.mat), _d(p.invmat), int(p.ortho), p.safemin2,
+                                p.cutoff2, alpha, _d(pts), len(pts), _d(out), nthreads)
+    return out
+
+
+def set_gridpoints(raw8: np.ndarray, delta, lam, thr) -> np.ndarray:
+    """_set_gridpoint! (grids.jl:118-135) applied to float64[n,8] -> float32[n,8]"""
+    raw8 = np.ascontiguousarray(raw8, dtype=np.float64).reshape(-1, 8)
+    n = len(raw8)
+    out = np.empty((8, n), dtype=np.float32)
+    dl = np.ascontiguousarray(delta, dtype=np.float64)
+    l = lib()
+    for t in range(n):
+        l.oracle_set_gridpoint(out.ctypes.data_as(_fp), t, n, _d(dl), lam, thr, _d(raw8[t]))
+    return out.T.copy()
+
+
+def periodic_distance2(d, mat, invmat, ortho, safemin2):
+    """periodic_distance2_fromcartesian! (utils.jl:210-246) -> (d2, image vector)"""
+    buf = np.array(d, dtype=np.float64)
+    d2 = lib().oracle_periodic_distance2_fromcartesian(_d(buf), _d(_cm(mat)), _d(_cm(invmat)), int(ortho), safemin2)
+    return d2, buf
+
+
+def derivatives_grid(rules: np.ndarray, r2: float) -> np.ndarray:
+    out = np.empty(4)
+    rc = lib().oracle_derivatives_grid(rules.ctypes.data, len(rules), r2, _d(out))
+    if rc:
+        raise RuntimeError("rule kind rejected by derivativesGrid")
+    return out
+
+
+def derivatives_ewald(alpha: float, charge: float, r2: float) -> np.ndarray:
+    out = np.empty(4)
+    lib().oracle_derivatives_ewald(alpha, charge, r2, _d(out))
+    return out
+
+
+def max_threads() -> int:
+    return lib().oracle_max_threads()
