@@ -1,0 +1,636 @@
+// ceg_api.hip -- C ABI of libceg_hip.so (include/ceg_hip.h): plan management, host-side
+// preparation of the lattice-image list and bins, slab scheduling over devices.
+//
+// Replaces the loop nests of create_grid_vdw / create_grid_coulomb
+// (src/grids.jl:144-150, 171-177 of CrystalEnergyGrids.jl).  No CPU compute path exists
+// here: without a HIP device every build entry point fails with CEG_ERR_NO_DEVICE.
+#include "ceg_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace ceg;
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_err = "";
+
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(CEG_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                               \
+    } while (0)
+
+extern "C" int ceg_abi_version(void) { return CEG_ABI_VERSION; }
+
+extern "C" const char* ceg_last_error(void) { return g_err.c_str(); }
+
+extern "C" int ceg_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+// ------------------------------------------------------------------ plan
+struct ceg_plan {
+    int device = 0;
+    Geom g{};
+    int64_t natoms = 0;
+    bool has_rules = false, has_charge = false;
+    bool can_cull = false;
+    // host copies (needed to (re)build the image list)
+    std::vector<double> h_pos, h_charge;
+    std::vector<int32_t> h_kind;           // 0-based, -1 if none
+    std::vector<DevRule> h_rules;
+    std::vector<int32_t> h_offset;
+    int32_t nkinds = 0;
+    // device
+    double4* d_atoms = nullptr;
+    int32_t* d_kind = nullptr;
+    DevRule* d_rules = nullptr;
+    int32_t* d_offset = nullptr;
+    double4* d_images = nullptr;
+    int32_t* d_imgkind = nullptr;
+    int32_t* d_binstart = nullptr;
+    ImageBins ib{};
+    bool images_built = false;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+inline void matvec(const double* m, const double v[3], double o[3])
+{
+    for (int i = 0; i < 3; ++i) o[i] = m[i] * v[0] + m[i + 3] * v[1] + m[i + 6] * v[2];
+}
+
+// perpendicular widths of the cell (src/utils.jl:10-29)
+void perpendicular_widths(const double* m, double w[3])
+{
+    const double* a = m;
+    const double* b = m + 3;
+    const double* c = m + 6;
+    auto cross = [](const double* u, const double* v, double* o) {
+        o[0] = u[1] * v[2] - u[2] * v[1];
+        o[1] = u[2] * v[0] - u[0] * v[2];
+        o[2] = u[0] * v[1] - u[1] * v[0];
+    };
+    auto norm = [](const double* u) { return std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]); };
+    double axb[3], bxc[3], cxa[3];
+    cross(a, b, axb);
+    cross(b, c, bxc);
+    cross(c, a, cxa);
+    const double vol = std::fabs(a[0] * bxc[0] + a[1] * bxc[1] + a[2] * bxc[2]);
+    w[0] = vol / norm(bxc);
+    w[1] = vol / norm(cxa);
+    w[2] = vol / norm(axb);
+}
+
+// Translate the public rule table into device rules.  Only kinds that occur in the atom list
+// are validated, mirroring the reference where derivativesGrid raises lazily
+// (src/interactions.jl:442-443,462-467).
+int convert_rules(ceg_plan* p, const ceg_rule_t* rules, const int32_t* rule_offset, int32_t nkinds)
+{
+    std::vector<char> present(nkinds, 0);
+    for (int64_t a = 0; a < p->natoms; ++a) present[p->h_kind[a]] = 1;
+    p->h_offset.assign(nkinds + 1, 0);
+    p->h_rules.clear();
+    for (int32_t k = 0; k < nkinds; ++k) {
+        p->h_offset[k] = (int32_t)p->h_rules.size();
+        for (int32_t t = rule_offset[k]; t < rule_offset[k + 1]; ++t) {
+            const ceg_rule_t& r = rules[t];
+            DevRule d{};
+            d.kind = r.kind;
+            d.shift = r.shift;
+            switch (r.kind) {
+            case CEG_NOINTERACTION:
+            case CEG_COULOMB_EWALD_DIRECT:
+                continue;  // exact zeros in a VdW grid
+            case CEG_LENNARDJONES:
+                d.p0 = r.p[0];
+                d.p1 = r.p[1] * r.p[1];
+                break;
+            case CEG_BUCKINGHAM:
+                d.p0 = r.p[0];
+                d.p1 = r.p[1];
+                d.p2 = r.p[2];
+                break;
+            case CEG_HARDSPHERE: {
+                const double rr = r.p[0] + r.p[1];
+                d.p0 = rr * rr;
+                break;
+            }
+            default:
+                if (present[k])
+                    return fail(CEG_ERR_RULE,
+                                "interaction kind %d (force-field index %d) is not valid in a VdW grid "
+                                "(src/interactions.jl:442-467)", r.kind, k + 1);
+                continue;
+            }
+            p->h_rules.push_back(d);
+        }
+    }
+    p->h_offset[nkinds] = (int32_t)p->h_rules.size();
+    p->nkinds = nkinds;
+    return CEG_OK;
+}
+
+template <class T>
+int upload(T** dst, const T* src, size_t n)
+{
+    *dst = nullptr;
+    if (n == 0) n = 1;  // keep pointers valid
+    HIP_TRY(hipMalloc((void**)dst, n * sizeof(T)));
+    if (src) HIP_TRY(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return CEG_OK;
+}
+
+// Expand the atoms into every lattice image that can be within the cutoff of a grid point
+// (grid bounding box grown by the cutoff), bin them on a cartesian lattice and upload.
+int build_images(ceg_plan* p)
+{
+    const Geom& g = p->g;
+    const double cutoff = std::sqrt(g.cutoff2);
+    const double margin = cutoff * (1.0 + 1e-6) + 1e-6;
+    double lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = g.shift[a] - margin;
+        hi[a] = g.shift[a] + g.size[a] + margin;
+    }
+    // bins: ~4.5 A edge
+    const double target = 4.5;
+    int nb[3];
+    double bin[3];
+    for (int a = 0; a < 3; ++a) {
+        nb[a] = std::max(1, (int)std::floor((hi[a] - lo[a]) / target));
+        bin[a] = (hi[a] - lo[a]) / nb[a];
+    }
+    struct Img { double x, y, z, q; int32_t kind; int32_t bin; };
+    std::vector<Img> imgs;
+    imgs.reserve((size_t)p->natoms * 8);
+    const double* M = g.mat;
+    const double* I = g.invmat;
+    for (int64_t a = 0; a < p->natoms; ++a) {
+        const double pa[3] = {p->h_pos[3 * a], p->h_pos[3 * a + 1], p->h_pos[3 * a + 2]};
+        double fmin[3] = {1e300, 1e300, 1e300}, fmax[3] = {-1e300, -1e300, -1e300};
+        for (int c = 0; c < 8; ++c) {
+            const double d[3] = {((c & 1) ? hi[0] : lo[0]) - pa[0], ((c & 2) ? hi[1] : lo[1]) - pa[1],
+                                 ((c & 4) ? hi[2] : lo[2]) - pa[2]};
+            double f[3];
+            matvec(I, d, f);
+            for (int q = 0; q < 3; ++q) {
+                fmin[q] = std::min(fmin[q], f[q]);
+                fmax[q] = std::max(fmax[q], f[q]);
+            }
+        }
+        int n0[3], n1[3];
+        for (int q = 0; q < 3; ++q) {
+            n0[q] = (int)std::floor(fmin[q]) - 1;
+            n1[q] = (int)std::ceil(fmax[q]) + 1;
+        }
+        for (int nx = n0[0]; nx <= n1[0]; ++nx)
+            for (int ny = n0[1]; ny <= n1[1]; ++ny)
+                for (int nz = n0[2]; nz <= n1[2]; ++nz) {
+                    const double P[3] = {pa[0] + (nx * M[0] + ny * M[3] + nz * M[6]),
+                                         pa[1] + (nx * M[1] + ny * M[4] + nz * M[7]),
+                                         pa[2] + (nx * M[2] + ny * M[5] + nz * M[8])};
+                    if (P[0] < lo[0] || P[0] > hi[0] || P[1] < lo[1] || P[1] > hi[1] || P[2] < lo[2] ||
+                        P[2] > hi[2])
+                        continue;
+                    int b[3];
+                    for (int q = 0; q < 3; ++q) {
+                        b[q] = (int)std::floor((P[q] - lo[q]) / bin[q]);
+                        b[q] = std::min(std::max(b[q], 0), nb[q] - 1);
+                    }
+                    Img im;
+                    im.x = P[0]; im.y = P[1]; im.z = P[2];
+                    im.q = p->has_charge ? p->h_charge[a] : 0.0;
+                    im.kind = p->has_rules ? p->h_kind[a] : -1;
+                    im.bin = (b[0] * nb[1] + b[1]) * nb[2] + b[2];
+                    imgs.push_back(im);
+                }
+    }
+    if (imgs.size() > 0x7ffffff0ull) return fail(CEG_ERR_UNSUPPORTED, "too many lattice images");
+    const size_t nbins = (size_t)nb[0] * nb[1] * nb[2];
+    std::vector<int32_t> start(nbins + 1, 0);
+    for (const Img& im : imgs) start[im.bin + 1]++;
+    for (size_t b = 0; b < nbins; ++b) start[b + 1] += start[b];
+    std::vector<int32_t> cursor(start.begin(), start.end() - 1);
+    std::vector<double4> xyzq(imgs.size());
+    std::vector<int32_t> kind(imgs.size());
+    for (const Img& im : imgs) {       // stable: atom order, then lattice order, inside each bin
+        const int32_t s = cursor[im.bin]++;
+        xyzq[s] = make_double4(im.x, im.y, im.z, im.q);
+        kind[s] = im.kind;
+    }
+    if (int rc = upload(&p->d_images, xyzq.data(), xyzq.size())) return rc;
+    if (int rc = upload(&p->d_imgkind, kind.data(), kind.size())) return rc;
+    if (int rc = upload(&p->d_binstart, start.data(), start.size())) return rc;
+    ImageBins& ib = p->ib;
+    ib.xyzq = p->d_images;
+    ib.kind = p->has_rules ? p->d_imgkind : nullptr;
+    ib.bin_start = p->d_binstart;
+    for (int a = 0; a < 3; ++a) {
+        ib.lo[a] = lo[a];
+        ib.bin[a] = bin[a];
+        ib.inv_bin[a] = 1.0 / bin[a];
+        ib.nb[a] = nb[a];
+    }
+    ib.nimages = (int32_t)imgs.size();
+    p->images_built = true;
+    return CEG_OK;
+}
+
+int check_common(const double* pos, int64_t natoms, const double* mat, const double* invmat,
+                 const int32_t* dims, const double* size, const double* shift, const double* delta)
+{
+    if (!pos && natoms > 0) return fail(CEG_ERR_INVALID, "pos is NULL");
+    if (natoms < 0) return fail(CEG_ERR_INVALID, "natoms < 0");
+    if (!mat || !invmat || !dims || !size || !shift || !delta)
+        return fail(CEG_ERR_INVALID, "NULL geometry argument");
+    for (int a = 0; a < 3; ++a)
+        if (dims[a] < 1) return fail(CEG_ERR_INVALID, "dims[%d] = %d < 1", a, dims[a]);
+    return CEG_OK;
+}
+
+}  // namespace
+
+extern "C" int ceg_plan_create(ceg_plan_t** plan, int32_t device,
+                               const double* pos, const int64_t* atomkind, const double* charge,
+                               int64_t natoms,
+                               const double mat[9], const double invmat[9],
+                               int32_t ortho, double safemin2, double cutoff2,
+                               const ceg_rule_t* rules, const int32_t* rule_offset, int32_t nkinds,
+                               double alpha,
+                               const int32_t dims[3], const double size[3], const double shift[3],
+                               const double delta[3])
+{
+    if (!plan) return fail(CEG_ERR_INVALID, "plan is NULL");
+    *plan = nullptr;
+    if (int rc = check_common(pos, natoms, mat, invmat, dims, size, shift, delta)) return rc;
+    const int ndev = ceg_device_count();
+    if (ndev <= 0) return fail(CEG_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(CEG_ERR_NO_DEVICE, "device %d not present (%d devices)", device, ndev);
+    const bool has_rules = rules && rule_offset && atomkind && nkinds > 0;
+    if (!has_rules && !charge) return fail(CEG_ERR_INVALID, "plan needs rules+atomkind and/or charges");
+
+    ceg_plan* p = new ceg_plan();
+    p->device = device;
+    p->natoms = natoms;
+    p->has_rules = has_rules;
+    p->has_charge = charge != nullptr;
+    Geom& g = p->g;
+    memcpy(g.mat, mat, sizeof g.mat);
+    memcpy(g.invmat, invmat, sizeof g.invmat);
+    for (int a = 0; a < 3; ++a) {
+        g.size[a] = size[a];
+        g.shift[a] = shift[a];
+        g.delta[a] = delta[a];
+        g.dims[a] = dims[a];
+    }
+    g.ortho = ortho ? 1 : 0;
+    g.safemin2 = safemin2;
+    g.cutoff2 = cutoff2;
+    g.alpha = alpha;
+    g.diag = (mat[1] == 0 && mat[2] == 0 && mat[3] == 0 && mat[5] == 0 && mat[6] == 0 && mat[7] == 0) ? 1 : 0;
+
+    p->h_pos.assign(pos, pos + 3 * natoms);
+    if (charge) p->h_charge.assign(charge, charge + natoms);
+    p->h_kind.assign(natoms, -1);
+    if (has_rules) {
+        for (int64_t a = 0; a < natoms; ++a) {
+            const int64_t k = atomkind[a];
+            if (k < 1 || k > nkinds) {
+                delete p;
+                return fail(CEG_ERR_INVALID, "atomkind[%lld] = %lld outside 1..%d", (long long)a, (long long)k, nkinds);
+            }
+            p->h_kind[a] = (int32_t)(k - 1);
+        }
+        if (int rc = convert_rules(p, rules, rule_offset, nkinds)) {
+            delete p;
+            return rc;
+        }
+    }
+    // culling needs: finite cutoff, every perpendicular width >= 2*cutoff (two images of one atom
+    // are then never both inside the cutoff), which ProbeSystem guarantees (src/probes.jl:24)
+    double w[3];
+    perpendicular_widths(g.mat, w);
+    const double cutoff = std::sqrt(cutoff2);
+    p->can_cull = std::isfinite(cutoff2) && cutoff2 > 0 &&
+                  std::min(w[0], std::min(w[1], w[2])) >= 2.0 * cutoff * (1.0 - 1e-12);
+
+    DeviceGuard guard(device);
+    if (!guard.ok) {
+        delete p;
+        return fail(CEG_ERR_HIP, "hipSetDevice(%d) failed", device);
+    }
+    std::vector<double4> xyzq((size_t)natoms);
+    for (int64_t a = 0; a < natoms; ++a)
+        xyzq[a] = make_double4(pos[3 * a], pos[3 * a + 1], pos[3 * a + 2], charge ? charge[a] : 0.0);
+    int rc = upload(&p->d_atoms, xyzq.data(), xyzq.size());
+    if (!rc) rc = upload(&p->d_kind, p->h_kind.data(), p->h_kind.size());
+    if (!rc) rc = upload(&p->d_rules, p->h_rules.data(), p->h_rules.size());
+    if (!rc) {
+        if (p->h_offset.empty()) p->h_offset.assign(1, 0);
+        rc = upload(&p->d_offset, p->h_offset.data(), p->h_offset.size());
+    }
+    if (!rc && p->can_cull) rc = build_images(p);
+    if (rc) {
+        ceg_plan_destroy(p);
+        return rc;
+    }
+    *plan = p;
+    return CEG_OK;
+}
+
+extern "C" int ceg_plan_destroy(ceg_plan_t* p)
+{
+    if (!p) return CEG_OK;
+    DeviceGuard guard(p->device);
+    (void)hipFree(p->d_atoms);
+    (void)hipFree(p->d_kind);
+    (void)hipFree(p->d_rules);
+    (void)hipFree(p->d_offset);
+    (void)hipFree(p->d_images);
+    (void)hipFree(p->d_imgkind);
+    (void)hipFree(p->d_binstart);
+    delete p;
+    return CEG_OK;
+}
+
+extern "C" int ceg_plan_can_cull(const ceg_plan_t* p) { return (p && p->can_cull) ? 1 : 0; }
+
+extern "C" int64_t ceg_plan_num_images(const ceg_plan_t* p) { return (p && p->images_built) ? p->ib.nimages : 0; }
+
+namespace {
+
+int resolve_algo(const ceg_plan* p, int32_t algo, bool* culled)
+{
+    switch (algo) {
+    case CEG_ALGO_AUTO: *culled = p->can_cull; return CEG_OK;
+    case CEG_ALGO_BRUTEFORCE: *culled = false; return CEG_OK;
+    case CEG_ALGO_CULLED:
+        if (!p->can_cull)
+            return fail(CEG_ERR_UNSUPPORTED,
+                        "culled algorithm needs every perpendicular cell width >= 2*cutoff");
+        *culled = true;
+        return CEG_OK;
+    default: return fail(CEG_ERR_INVALID, "unknown algo %d", algo);
+    }
+}
+
+int run(ceg_plan* p, int mode, const Output& out, const Points& pts, bool culled, hipStream_t stream)
+{
+    if (mode != MODE_COULOMB && !p->has_rules) return fail(CEG_ERR_INVALID, "plan was created without rules");
+    if (mode != MODE_VDW && !p->has_charge) return fail(CEG_ERR_INVALID, "plan was created without charges");
+    RuleTable rt{p->d_rules, p->d_offset, p->nkinds};
+    hipError_t e;
+    if (culled) {
+        e = launch_culled(mode, p->g, p->ib, rt, out, pts, stream);
+    } else {
+        AtomTable at{p->d_atoms, p->has_rules ? p->d_kind : nullptr, p->natoms};
+        e = launch_bruteforce(mode, p->g, at, rt, out, pts, stream);
+    }
+    if (e != hipSuccess) return fail(CEG_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    return CEG_OK;
+}
+
+int build_common(ceg_plan* p, int mode, double lv, double tv, double lc, double tc, int32_t i_begin,
+                 int32_t i_end, float* d_v, float* d_c, int64_t channel_stride, int32_t i_origin,
+                 int32_t algo, void* stream)
+{
+    if (!p) return fail(CEG_ERR_INVALID, "plan is NULL");
+    if (i_begin < 0 || i_end > p->g.dims[0] + 1 || i_begin > i_end)
+        return fail(CEG_ERR_INVALID, "bad x-plane range [%d,%d) for dims[0]+1 = %d", i_begin, i_end, p->g.dims[0] + 1);
+    if (i_origin > i_begin) return fail(CEG_ERR_INVALID, "i_origin %d > i_begin %d", i_origin, i_begin);
+    if ((mode != MODE_COULOMB && !d_v) || (mode != MODE_VDW && !d_c)) return fail(CEG_ERR_INVALID, "output pointer is NULL");
+    const int64_t plane = (int64_t)(p->g.dims[1] + 1) * (p->g.dims[2] + 1);
+    if (channel_stride < (int64_t)(i_end - i_origin) * plane)
+        return fail(CEG_ERR_INVALID, "channel_stride %lld too small", (long long)channel_stride);
+    bool culled;
+    if (int rc = resolve_algo(p, algo, &culled)) return rc;
+    Output out{};
+    out.vdw = d_v;
+    out.coulomb = d_c;
+    out.channel_stride = channel_stride;
+    out.i_origin = i_origin;
+    out.i_begin = i_begin;
+    out.i_end = i_end;
+    out.lambda_vdw = lv;
+    out.thr_vdw = tv;
+    out.lambda_coulomb = lc;
+    out.thr_coulomb = tc;
+    DeviceGuard guard(p->device);
+    if (!guard.ok) return fail(CEG_ERR_HIP, "hipSetDevice(%d) failed", p->device);
+    return run(p, mode, out, Points{nullptr, 0}, culled, (hipStream_t)stream);
+}
+
+}  // namespace
+
+extern "C" int ceg_plan_build_vdw(ceg_plan_t* plan, double lambda, double threshold, int32_t i_begin,
+                                  int32_t i_end, float* d_out, int64_t channel_stride, int32_t i_origin,
+                                  int32_t algo, void* stream)
+{
+    return build_common(plan, MODE_VDW, lambda, threshold, 0, 0, i_begin, i_end, d_out, nullptr, channel_stride,
+                        i_origin, algo, stream);
+}
+
+extern "C" int ceg_plan_build_coulomb(ceg_plan_t* plan, double lambda, double threshold, int32_t i_begin,
+                                      int32_t i_end, float* d_out, int64_t channel_stride, int32_t i_origin,
+                                      int32_t algo, void* stream)
+{
+    return build_common(plan, MODE_COULOMB, 0, 0, lambda, threshold, i_begin, i_end, nullptr, d_out,
+                        channel_stride, i_origin, algo, stream);
+}
+
+extern "C" int ceg_plan_build_fused(ceg_plan_t* plan, double lambda_vdw, double threshold_vdw,
+                                    double lambda_coulomb, double threshold_coulomb, int32_t i_begin,
+                                    int32_t i_end, float* d_out_vdw, float* d_out_coulomb,
+                                    int64_t channel_stride, int32_t i_origin, int32_t algo, void* stream)
+{
+    return build_common(plan, MODE_FUSED, lambda_vdw, threshold_vdw, lambda_coulomb, threshold_coulomb, i_begin,
+                        i_end, d_out_vdw, d_out_coulomb, channel_stride, i_origin, algo, stream);
+}
+
+extern "C" int ceg_plan_eval_points(ceg_plan_t* p, int32_t which, int32_t algo, const double* points,
+                                    int64_t npoints, double* out)
+{
+    if (!p) return fail(CEG_ERR_INVALID, "plan is NULL");
+    if (npoints < 0 || (npoints > 0 && (!points || !out))) return fail(CEG_ERR_INVALID, "bad points/out");
+    if (which != 0 && which != 1) return fail(CEG_ERR_INVALID, "which must be 0 (vdw) or 1 (coulomb)");
+    if (npoints == 0) return CEG_OK;
+    bool culled;
+    if (int rc = resolve_algo(p, algo, &culled)) return rc;
+    if (culled) {
+        // the image list only covers the grid's bounding box grown by the cutoff
+        bool inside = true;
+        for (int64_t q = 0; q < npoints && inside; ++q)
+            for (int a = 0; a < 3; ++a) {
+                const double x = points[3 * q + a];
+                if (!(x >= p->g.shift[a] - 1e-9 && x <= p->g.shift[a] + p->g.size[a] + 1e-9)) inside = false;
+            }
+        if (!inside) {
+            if (algo == CEG_ALGO_CULLED)
+                return fail(CEG_ERR_UNSUPPORTED, "culled evaluation needs points inside the grid bounding box");
+            culled = false;
+        }
+    }
+    DeviceGuard guard(p->device);
+    if (!guard.ok) return fail(CEG_ERR_HIP, "hipSetDevice(%d) failed", p->device);
+    double* d_pts = nullptr;
+    double* d_out = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_pts, sizeof(double) * 3 * npoints));
+    if (hipMalloc((void**)&d_out, sizeof(double) * 8 * npoints) != hipSuccess) {
+        (void)hipFree(d_pts);
+        return fail(CEG_ERR_HIP, "hipMalloc failed");
+    }
+    int rc = CEG_OK;
+    if (hipMemcpy(d_pts, points, sizeof(double) * 3 * npoints, hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(CEG_ERR_HIP, "hipMemcpy H2D failed");
+    if (!rc) {
+        Output o{};
+        if (which == 0) o.raw_vdw = d_out; else o.raw_coulomb = d_out;
+        rc = run(p, which == 0 ? MODE_VDW : MODE_COULOMB, o, Points{d_pts, npoints}, culled, nullptr);
+    }
+    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(CEG_ERR_HIP, "kernel execution failed: %s", hipGetErrorString(hipGetLastError()));
+    if (!rc && hipMemcpy(out, d_out, sizeof(double) * 8 * npoints, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(CEG_ERR_HIP, "hipMemcpy D2H failed");
+    (void)hipFree(d_pts);
+    (void)hipFree(d_out);
+    return rc;
+}
+
+// ------------------------------------------------------------------ one-shot host API
+namespace {
+
+// x-planes [begin,end) of device `d` out of `n`
+inline void slab(int nx, int n, int d, int* begin, int* end)
+{
+    const int base = nx / n, rem = nx % n;
+    *begin = d * base + std::min(d, rem);
+    *end = *begin + base + (d < rem ? 1 : 0);
+}
+
+int oneshot(int mode, const double* pos, const int64_t* atomkind, const double* charge, int64_t natoms,
+            const double* mat, const double* invmat, int32_t ortho, double safemin2, double cutoff2,
+            const ceg_rule_t* rules, const int32_t* rule_offset, int32_t nkinds, double alpha,
+            const int32_t* dims, const double* size, const double* shift, const double* delta,
+            double lambda, double threshold, float* grid, int32_t ngpus)
+{
+    if (!grid) return fail(CEG_ERR_INVALID, "grid is NULL");
+    if (int rc = check_common(pos, natoms, mat, invmat, dims, size, shift, delta)) return rc;
+    const int ndev = ceg_device_count();
+    if (ndev <= 0) return fail(CEG_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (ngpus < 1 || ngpus > ndev) return fail(CEG_ERR_NO_DEVICE, "ngpus = %d but %d HIP devices are present", ngpus, ndev);
+    const int nx = dims[0] + 1;
+    const int64_t plane = (int64_t)(dims[1] + 1) * (dims[2] + 1);
+    const int64_t npts = plane * nx;
+    ngpus = std::min(ngpus, nx);
+
+    std::vector<ceg_plan*> plans(ngpus, nullptr);
+    std::vector<float*> d_out(ngpus, nullptr);
+    std::vector<hipStream_t> streams(ngpus, nullptr);
+    int rc = CEG_OK;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    for (int d = 0; d < ngpus && !rc; ++d) {
+        rc = ceg_plan_create(&plans[d], d, pos, atomkind, charge, natoms, mat, invmat, ortho, safemin2, cutoff2,
+                             rules, rule_offset, nkinds, alpha, dims, size, shift, delta);
+        if (rc) break;
+        int b, e;
+        slab(nx, ngpus, d, &b, &e);
+        if (hipSetDevice(d) != hipSuccess) { rc = fail(CEG_ERR_HIP, "hipSetDevice(%d) failed", d); break; }
+        if (hipStreamCreateWithFlags(&streams[d], hipStreamNonBlocking) != hipSuccess) { rc = fail(CEG_ERR_HIP, "hipStreamCreate failed"); break; }
+        const int64_t slab_pts = (int64_t)(e - b) * plane;
+        if (hipMalloc((void**)&d_out[d], sizeof(float) * 8 * std::max<int64_t>(slab_pts, 1)) != hipSuccess) {
+            rc = fail(CEG_ERR_HIP, "hipMalloc of %lld bytes failed on device %d", (long long)(sizeof(float) * 8 * slab_pts), d);
+            break;
+        }
+        if (mode == MODE_VDW)
+            rc = ceg_plan_build_vdw(plans[d], lambda, threshold, b, e, d_out[d], slab_pts, b, CEG_ALGO_AUTO, streams[d]);
+        else
+            rc = ceg_plan_build_coulomb(plans[d], lambda, threshold, b, e, d_out[d], slab_pts, b, CEG_ALGO_AUTO, streams[d]);
+    }
+    // gather: each device's slab goes straight into its place in the host array (one copy per channel)
+    for (int d = 0; d < ngpus && !rc; ++d) {
+        int b, e;
+        slab(nx, ngpus, d, &b, &e);
+        const int64_t slab_pts = (int64_t)(e - b) * plane;
+        if (hipSetDevice(d) != hipSuccess) { rc = fail(CEG_ERR_HIP, "hipSetDevice(%d) failed", d); break; }
+        if (hipStreamSynchronize(streams[d]) != hipSuccess) { rc = fail(CEG_ERR_HIP, "kernel execution failed on device %d: %s", d, hipGetErrorString(hipGetLastError())); break; }
+        for (int c = 0; c < 8 && !rc; ++c)
+            if (slab_pts > 0 && hipMemcpy(grid + c * npts + (int64_t)b * plane, d_out[d] + c * slab_pts, sizeof(float) * slab_pts,
+                                          hipMemcpyDeviceToHost) != hipSuccess)
+                rc = fail(CEG_ERR_HIP, "hipMemcpy D2H failed on device %d", d);
+    }
+    for (int d = 0; d < ngpus; ++d) {
+        if (hipSetDevice(d) == hipSuccess) {
+            if (d_out[d]) (void)hipFree(d_out[d]);
+            if (streams[d]) (void)hipStreamDestroy(streams[d]);
+        }
+        if (plans[d]) ceg_plan_destroy(plans[d]);
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return rc;
+}
+
+}  // namespace
+
+extern "C" int ceg_grid_vdw(const double* pos, const int64_t* atomkind, int64_t natoms,
+                            const double mat[9], const double invmat[9],
+                            int32_t ortho, double safemin2, double cutoff2,
+                            const ceg_rule_t* rules, const int32_t* rule_offset, int32_t nkinds,
+                            const int32_t dims[3], const double size[3], const double shift[3],
+                            const double delta[3], double lambda, double threshold,
+                            float* grid, int32_t ngpus)
+{
+    if (!rules || !rule_offset || !atomkind || nkinds <= 0) return fail(CEG_ERR_INVALID, "rule table / atomkind missing");
+    return oneshot(MODE_VDW, pos, atomkind, nullptr, natoms, mat, invmat, ortho, safemin2, cutoff2, rules,
+                   rule_offset, nkinds, 0.0, dims, size, shift, delta, lambda, threshold, grid, ngpus);
+}
+
+extern "C" int ceg_grid_coulomb(const double* pos, const double* charge, int64_t natoms,
+                                const double mat[9], const double invmat[9],
+                                int32_t ortho, double safemin2, double cutoff2, double alpha,
+                                const int32_t dims[3], const double size[3], const double shift[3],
+                                const double delta[3], double lambda, double threshold,
+                                float* grid, int32_t ngpus)
+{
+    if (!charge) return fail(CEG_ERR_INVALID, "charge is NULL");
+    return oneshot(MODE_COULOMB, pos, nullptr, charge, natoms, mat, invmat, ortho, safemin2, cutoff2, nullptr,
+                   nullptr, 0, alpha, dims, size, shift, delta, lambda, threshold, grid, ngpus);
+}

@@ -1,0 +1,97 @@
+// ceg_internal.h -- types shared by the HIP kernels (ceg_kernels.hip) and the C-ABI
+// layer (ceg_api.hip).  Not installed; the public interface is include/ceg_hip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ceg_hip.h"
+
+namespace ceg {
+
+// What one launch computes.
+enum Mode : int { MODE_VDW = 0, MODE_COULOMB = 1, MODE_FUSED = 2 };
+
+// One pair rule as the kernels want it (derived from ceg_rule_t at plan creation;
+// NoInteraction / CoulombEwaldDirect rules are dropped because derivativesGrid returns
+// exact zeros for them, src/interactions.jl:458-461).
+//   LJ          : p0 = eps, p1 = sigma^2
+//   Buckingham  : p0 = A,   p1 = B,  p2 = C
+//   HardSphere  : p0 = (R1+R2)^2
+struct DevRule {
+    int32_t kind;
+    int32_t _pad;
+    double  p0, p1, p2;
+    double  shift;
+};
+
+// Geometry + periodic-distance set-up, passed to kernels by value (kernarg -> SGPRs).
+struct Geom {
+    double mat[9];      // column-major supercell matrix   (src/probes.jl:27)
+    double invmat[9];   // its inverse                      (src/probes.jl:28)
+    double size[3];     // GridCoordinatesSetup.size        (src/coordinates.jl:34)
+    double shift[3];    //                      .shift      (:35)
+    double delta[3];    //                      .delta      (:39)
+    int32_t dims[3];    //                      .dims       (:36-37)
+    int32_t ortho;      // src/utils.jl:148
+    double safemin2;    // src/utils.jl:150-152, squared
+    double cutoff2;     // src/probes.jl:75
+    double alpha;       // ewald.alpha, 1/A                 (src/ewald.jl:203)
+    int32_t diag;       // 1 if mat is exactly diagonal (wrapped image == nearest image)
+    int32_t _pad;
+};
+
+// Where results go.  Grid mode: 8 float channels per grid, written with
+// _set_gridpoint! semantics (src/grids.jl:118-135).  Raw mode (eval_points): the 8 FP64
+// numbers of compute_derivatives_* per point, before clamping/scaling.
+struct Output {
+    float*  vdw;            // device, may be null
+    float*  coulomb;        // device, may be null
+    double* raw_vdw;        // device [8*npoints], may be null
+    double* raw_coulomb;
+    int64_t channel_stride; // floats between channels
+    int32_t i_origin;       // x-plane stored at offset 0
+    int32_t i_begin, i_end; // x-planes computed by this launch
+    double  lambda_vdw, thr_vdw;
+    double  lambda_coulomb, thr_coulomb;
+};
+
+// Arbitrary point list (eval_points) or null for grid mode.
+struct Points {
+    const double* xyz;      // device [3*n]
+    int64_t n;
+};
+
+// Atom table for the brute-force kernels (one record per ProbeSystem atom).
+struct AtomTable {
+    const double4* xyzq;    // x, y, z, charge (0 if no charges given)
+    const int32_t* kind;    // 0-based force-field index, -1 if no kinds given
+    int64_t n;
+};
+
+// Rule table on the device.
+struct RuleTable {
+    const DevRule* rules;
+    const int32_t* offset;  // [nkinds+1]
+    int32_t nkinds;
+};
+
+// Lattice-image list + bins for the culled kernels.
+struct ImageBins {
+    const double4* xyzq;    // image position (atom + lattice vector), charge
+    const int32_t* kind;    // 0-based kind, -1 when the plan has no rules
+    const int32_t* bin_start; // [nbx*nby*nbz + 1], bins ordered (bx, by, bz) with bz fastest
+    double lo[3];           // lower corner of the binned region
+    double inv_bin[3];      // 1 / bin edge
+    double bin[3];          // bin edge
+    int32_t nb[3];
+    int32_t nimages;
+};
+
+// launchers (ceg_kernels.hip)
+hipError_t launch_bruteforce(int mode, const Geom& g, const AtomTable& atoms, const RuleTable& rt,
+                             const Output& out, const Points& pts, hipStream_t stream);
+hipError_t launch_culled(int mode, const Geom& g, const ImageBins& ib, const RuleTable& rt,
+                         const Output& out, const Points& pts, hipStream_t stream);
+
+}  // namespace ceg

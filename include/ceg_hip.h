@@ -33,6 +33,12 @@ extern "C" {
 
 #define CEG_ABI_VERSION 1
 
+#if defined(__GNUC__)
+#define CEG_API __attribute__((visibility("default")))
+#else
+#define CEG_API
+#endif
+
 /* error codes */
 #define CEG_OK                 0
 #define CEG_ERR_INVALID       -1   /* bad argument (null pointer, negative size, ...)        */
@@ -75,9 +81,9 @@ enum ceg_algo {
 };
 
 /* ---- library / device info ------------------------------------------------ */
-int         ceg_abi_version(void);
-int         ceg_device_count(void);         /* number of HIP devices, 0 if none   */
-const char* ceg_last_error(void);           /* thread-local, never NULL           */
+CEG_API int         ceg_abi_version(void);
+CEG_API int         ceg_device_count(void);         /* number of HIP devices, 0 if none   */
+CEG_API const char* ceg_last_error(void);           /* thread-local, never NULL           */
 
 /* ---- one-shot host API ---------------------------------------------------- */
 /*
@@ -101,7 +107,7 @@ const char* ceg_last_error(void);           /* thread-local, never NULL         
  *            column-major [z,y,x,channel] (src/grids.jl:126-133)
  *  ngpus     1..ceg_device_count(): x-slabs are spread over that many devices
  */
-int ceg_grid_vdw(const double* pos, const int64_t* atomkind, int64_t natoms,
+CEG_API int ceg_grid_vdw(const double* pos, const int64_t* atomkind, int64_t natoms,
                  const double mat[9], const double invmat[9],
                  int32_t ortho, double safemin2, double cutoff2,
                  const ceg_rule_t* rules, const int32_t* rule_offset, int32_t nkinds,
@@ -118,7 +124,7 @@ int ceg_grid_vdw(const double* pos, const int64_t* atomkind, int64_t natoms,
  *  lambda = COULOMBIC_CONVERSION_FACTOR/GRID_TO_KELVIN, threshold = 1e7/lambda
  *  (src/grids.jl:169-170).
  */
-int ceg_grid_coulomb(const double* pos, const double* charge, int64_t natoms,
+CEG_API int ceg_grid_coulomb(const double* pos, const double* charge, int64_t natoms,
                      const double mat[9], const double invmat[9],
                      int32_t ortho, double safemin2, double cutoff2, double alpha,
                      const int32_t dims[3], const double size[3], const double shift[3],
@@ -139,7 +145,7 @@ int ceg_grid_coulomb(const double* pos, const double* charge, int64_t natoms,
  */
 typedef struct ceg_plan ceg_plan_t;
 
-int ceg_plan_create(ceg_plan_t** plan, int32_t device,
+CEG_API int ceg_plan_create(ceg_plan_t** plan, int32_t device,
                     const double* pos, const int64_t* atomkind, const double* charge,
                     int64_t natoms,
                     const double mat[9], const double invmat[9],
@@ -148,14 +154,14 @@ int ceg_plan_create(ceg_plan_t** plan, int32_t device,
                     double alpha,
                     const int32_t dims[3], const double size[3], const double shift[3],
                     const double delta[3]);
-int ceg_plan_destroy(ceg_plan_t* plan);
+CEG_API int ceg_plan_destroy(ceg_plan_t* plan);
 
 /* 1 if the culled algorithm is valid for this plan (every perpendicular width of
  * `mat` is >= 2*cutoff, which ProbeSystem guarantees, src/probes.jl:24), else 0. */
-int ceg_plan_can_cull(const ceg_plan_t* plan);
+CEG_API int ceg_plan_can_cull(const ceg_plan_t* plan);
 
 /* number of lattice images kept by the culled algorithm (0 before first use) */
-int64_t ceg_plan_num_images(const ceg_plan_t* plan);
+CEG_API int64_t ceg_plan_num_images(const ceg_plan_t* plan);
 
 /*
  * Build x-planes i in [i_begin, i_end) (0 <= i_begin <= i_end <= dims[0]+1).
@@ -166,17 +172,17 @@ int64_t ceg_plan_num_images(const ceg_plan_t* plan);
  * slab points).  d_out is DEVICE memory on the plan's device; `stream` is a
  * hipStream_t (NULL = default stream).  The call is asynchronous.
  */
-int ceg_plan_build_vdw(ceg_plan_t* plan, double lambda, double threshold,
+CEG_API int ceg_plan_build_vdw(ceg_plan_t* plan, double lambda, double threshold,
                        int32_t i_begin, int32_t i_end,
                        float* d_out, int64_t channel_stride, int32_t i_origin,
                        int32_t algo, void* stream);
-int ceg_plan_build_coulomb(ceg_plan_t* plan, double lambda, double threshold,
+CEG_API int ceg_plan_build_coulomb(ceg_plan_t* plan, double lambda, double threshold,
                            int32_t i_begin, int32_t i_end,
                            float* d_out, int64_t channel_stride, int32_t i_origin,
                            int32_t algo, void* stream);
 /* VdW and Coulomb grids of the same slab in one pass over the atoms (shared
  * geometry work).  Same semantics as the two calls above. */
-int ceg_plan_build_fused(ceg_plan_t* plan,
+CEG_API int ceg_plan_build_fused(ceg_plan_t* plan,
                          double lambda_vdw, double threshold_vdw,
                          double lambda_coulomb, double threshold_coulomb,
                          int32_t i_begin, int32_t i_end,
@@ -190,7 +196,7 @@ int ceg_plan_build_fused(ceg_plan_t* plan,
  * _set_gridpoint!: out[8*p + 0..7] = value, d1x, d1y, d1z, d2xy, d2xz, d2yz, d3.
  * points/out are HOST memory; synchronous.  which: 0 = vdw, 1 = coulomb.
  */
-int ceg_plan_eval_points(ceg_plan_t* plan, int32_t which, int32_t algo,
+CEG_API int ceg_plan_eval_points(ceg_plan_t* plan, int32_t which, int32_t algo,
                          const double* points, int64_t npoints, double* out);
 
 #ifdef __cplusplus
