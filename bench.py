@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py -- grid-points/s of the grid-build hot path on MI355X.
+
+One "step" = one full build of the BASELINE.json roofline workload (SURVEY §8d run "R"):
+the CHA_1.4_3b4eeb96 fixture tiled 2x2x3 (11 664 framework atoms) probed on a 256^3 grid,
+Lennard-Jones (Ar probe) VdW grid + real-space-Ewald Coulomb grid, each 8 Float32 channels per
+point, computed in FP64 by the hand-written HIP kernels behind the C ABI
+(crystalenergygrids.jl_amd/csrc).  Inputs (atom table, lattice images, bins) are resident in
+HBM before the timed region; the timed region is kernel launch(es) + (N > 1) the RCCL
+all-gather that assembles the grid on every rank.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  `value` = grid points of the full grid / step time (whole job).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+for p in (str(ROOT / "crystalenergygrids.jl_amd"), str(ROOT)):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz (no MFMA on this path)
+# nominal flop convention of SURVEY §8d: distance test 47, LJ 50, Ewald 140 per in-cutoff pair
+N_CUT = 310.0                  # mean neighbours within 12 A at CHA density
+F_DIST, F_LJ, F_EWALD = 47.0, 50.0, 140.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mode", choices=("fused", "vdw", "coulomb"), default="fused")
+    ap.add_argument("--algo", choices=("auto", "bruteforce", "culled"), default="auto")
+    ap.add_argument("--n", type=int, default=255, help="dims per axis (odd); grid has (n+1)^3 points")
+    ap.add_argument("--cpu-rows", type=int, default=-1, help="y-rows per x-plane the CPU baseline times, one plane per thread (-1 = auto ~12 s, 0 = skip)")
+    ap.add_argument("--no-check", action="store_true", help="skip the built-in oracle spot check")
+    return ap.parse_args()
+
+
+def cpu_baseline(w, mode: str, rows: int):
+    """Oracle (C restatement of the reference algorithm: brute force over all atoms, literal
+    min-image routine, threaded over the x index like Threads.@threads in grids.jl:144) on a
+    bounded sample of the same workload: one x-plane per thread, `rows` y-rows of each."""
+    from oracle import oracle as O
+    from ceg_hip import grids as G
+    threads = O.max_threads()
+    nx, ny, nz = w.cset.npoints
+    planes = min(threads, nx)
+    i0 = max(0, nx // 2 - planes // 2)
+    i1 = i0 + planes
+
+    def run(j0, j1):
+        t = time.perf_counter()
+        if mode in ("fused", "vdw"):
+            lam, thr = G.vdw_scaling()
+            O.grid_vdw(w.probe_vdw, w.cset, lam, thr, i0, i1, j_begin=j0, j_end=j1)
+        if mode in ("fused", "coulomb"):
+            lam, thr = G.coulomb_scaling()
+            O.grid_coulomb(w.probe_coulomb, w.alpha, w.cset, lam, thr, i0, i1, j_begin=j0, j_end=j1)
+        return time.perf_counter() - t
+
+    mid = ny // 2
+    if rows < 0:
+        t = run(mid, mid + 1)
+        rows = int(max(1, min(ny, round(12.0 / max(t, 1e-9)))))
+    j0 = max(0, mid - rows // 2)
+    j1 = min(ny, j0 + rows)
+    t = run(j0, j1)
+    pts = planes * (j1 - j0) * nz
+    return {"value": pts / t, "unit": "grid-points/s", "cores": threads, "kind": "port",
+            "sample": f"{planes} x-planes x {j1 - j0} y-rows x {nz} ({pts} of {nx * ny * nz} points) x {w.natoms} atoms, "
+                      f"{mode}, {t:.1f} s; CPU restatement of the reference algorithm (brute force over all atoms), "
+                      "not the Julia package"}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the grid build has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+
+    from ceg_hip import _abi, workloads as W
+    from ceg_hip.distributed import allgather_grid, slab_range
+    from ceg_hip.plan import GridPlan
+
+    w = W.roofline_workload("Ar", args.n)
+    nx, ny, nz = w.cset.npoints
+    npts = nx * ny * nz
+    algo = {"auto": _abi.ALGO_AUTO, "bruteforce": _abi.ALGO_BRUTEFORCE, "culled": _abi.ALGO_CULLED}[args.algo]
+    plan = GridPlan(w.cset, w.probe_vdw, w.probe_coulomb, w.alpha, device=local_rank)
+    b, e = slab_range(nx, world, rank)
+    n_local = e - b
+    need_v = args.mode in ("fused", "vdw")
+    need_c = args.mode in ("fused", "coulomb")
+    # full grids live on every rank (that is what the gather produces); rank-local slab buffers
+    full_v = torch.empty((8, nx, ny, nz), dtype=torch.float32, device=dev) if need_v else None
+    full_c = torch.empty((8, nx, ny, nz), dtype=torch.float32, device=dev) if need_c else None
+    if world == 1:
+        loc_v, loc_c = full_v, full_c
+    else:
+        loc_v = torch.empty((8, n_local, ny, nz), dtype=torch.float32, device=dev) if need_v else None
+        loc_c = torch.empty((8, n_local, ny, nz), dtype=torch.float32, device=dev) if need_c else None
+    cs = n_local * ny * nz if world > 1 else npts
+    origin = b if world > 1 else 0
+
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def launch():
+        s = torch.cuda.current_stream().cuda_stream
+        if args.mode == "fused":
+            plan.build_fused(loc_v.data_ptr(), loc_c.data_ptr(), cs, b, e, origin, algo, s)
+        elif args.mode == "vdw":
+            plan.build_vdw(loc_v.data_ptr(), cs, b, e, origin, algo, s)
+        else:
+            plan.build_coulomb(loc_c.data_ptr(), cs, b, e, origin, algo, s)
+
+    def step(k=None):
+        if k is not None:
+            ev0[k].record()
+        launch()
+        if k is not None:
+            ev1[k].record()
+        if world > 1:
+            if need_v:
+                allgather_grid(full_v, loc_v)
+            if need_c:
+                allgather_grid(full_c, loc_c)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(bb) for a, bb in zip(ev0, ev1)])) if args.steps else float("nan")
+    if world > 1:
+        t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kern_ms = float(t[0]), float(t[1])
+
+    # built-in spot check against the oracle (a block of this rank's result), after timing
+    check = None
+    if not args.no_check and rank == 0:
+        from oracle import oracle as O
+        from oracle.compare import compare_grids
+        from ceg_hip import grids as G
+        T = min(O.max_threads(), 16, nx)
+        i0, j0 = nx // 2 - T // 2, ny // 2
+        i1, j1 = i0 + T, min(ny, j0 + 2)
+        worst = 0.0
+        if need_v:
+            lam, thr = G.vdw_scaling()
+            ref, _ = O.grid_vdw(w.probe_vdw, w.cset, lam, thr, i0, i1, j_begin=j0, j_end=j1)
+            worst = max(worst, compare_grids(full_v[:, i0:i1, j0:j1].cpu().numpy(), ref[:, i0:i1, j0:j1], "bench/vdw"))
+        if need_c:
+            lam, thr = G.coulomb_scaling()
+            ref, _ = O.grid_coulomb(w.probe_coulomb, w.alpha, w.cset, lam, thr, i0, i1, j_begin=j0, j_end=j1)
+            worst = max(worst, compare_grids(full_c[:, i0:i1, j0:j1].cpu().numpy(), ref[:, i0:i1, j0:j1], "bench/coulomb"))
+        check = {"points": (i1 - i0) * (j1 - j0) * nz, "max_rel_err": worst, "tol": 1e-6}
+
+    if rank == 0:
+        ms = elapsed / max(args.steps, 1) * 1e3
+        value = npts / (ms * 1e-3)
+        ngrids = int(need_v) + int(need_c)
+        # algorithmic (compulsory) HBM bytes per launch: 32 B per point per grid written + the
+        # image/atom table read once (32 B position+charge, 4 B kind)  -- SURVEY §8d
+        slab_pts = n_local * ny * nz
+        alg_bytes = 32.0 * slab_pts * ngrids + 36.0 * max(plan.num_images, w.natoms)
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        min_flops = slab_pts * N_CUT * ((F_DIST + F_LJ if need_v else 0.0) + (F_DIST + F_EWALD if need_c else 0.0)
+                                        - (F_DIST if (need_v and need_c) else 0.0))
+        tflops = min_flops / (kern_ms * 1e-3) / 1e12
+        traffic = None
+        prof = ROOT / "profiles" / "hbm_traffic.json"
+        if prof.exists():
+            try:
+                traffic = json.loads(prof.read_text()).get(f"{args.mode}/{args.n}/{world}")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "grid-points/sec", "value": value, "unit": "grid-points/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": w.name, "grid_points": npts, "framework_atoms": w.natoms,
+                       "lattice_images": plan.num_images, "grids_per_step": ngrids, "mode": args.mode,
+                       "algo": "culled" if (algo != _abi.ALGO_BRUTEFORCE and plan.can_cull) else "bruteforce",
+                       "parallelism": f"x-slab sharding over {world} GPU(s)" + (", RCCL all-gather of slabs" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": f"k_culled<{args.mode}>" if plan.can_cull and algo != _abi.ALGO_BRUTEFORCE else f"k_bruteforce<{args.mode}>",
+                         "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes,
+                         "note": "HBM is not the binding roofline of this path (>=1e3 flop/B); see roofline_fp64"},
+            "roofline_fp64": {"bound": "fp64-valu", "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": tflops / FP64_VALU_PEAK_TFLOPS,
+                              "flops": "minimum-work count of SURVEY 8d: points x 310 neighbours x (47 + 50 LJ / + 140 Ewald)"},
+            "selfcheck": check,
+        }
+        if world == 1 and args.cpu_rows != 0:
+            out["cpu_baseline"] = cpu_baseline(w, args.mode, args.cpu_rows)
+        print(json.dumps(out), flush=True)
+    plan.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -319,15 +319,16 @@ ORACLE_API void oracle_abc_to_xyz(const int32_t dims[3], const double size[3], c
 }
 
 /* ---- src/grids.jl:144-150 loop nest of create_grid_vdw, restricted to x-planes
- * [i_begin, i_end) so a bounded sample can be timed; threaded over i like
- * Threads.@threads (grids.jl:144).  raw8 (optional, may be NULL) receives the
+ * [i_begin, i_end) and y-rows [j_begin, j_end) so a bounded sample can be timed (the full
+ * grid is i in [0, dims[0]+1), j in [0, dims[1]+1)); threaded over i like Threads.@threads
+ * (grids.jl:144).  raw8 (optional, may be NULL) receives the
  * FP64 derivatives of every point before _set_gridpoint!, [8*idx + c]. */
 ORACLE_API int oracle_grid_vdw(
     const double* positions, const int64_t* atomkinds, int64_t natoms,
     const double mat[9], const double invmat[9], int ortho, double safemin2, double cutoff2,
     const ceg_rule_t* rules, const int32_t* rule_offset, int32_t nkinds,
     const int32_t dims[3], const double size[3], const double shift[3], const double delta[3],
-    double lambda, double thr, int32_t i_begin, int32_t i_end,
+    double lambda, double thr, int32_t i_begin, int32_t i_end, int32_t j_begin, int32_t j_end,
     float* grid, double* raw8, int32_t nthreads)
 {
     (void)nkinds;
@@ -341,7 +342,7 @@ ORACLE_API int oracle_grid_vdw(
 #endif
 #pragma omp parallel for schedule(dynamic, 1)
     for (int i = i_begin; i < i_end; ++i) {
-        for (int j = 0; j <= dims[1]; ++j)
+        for (int j = j_begin; j < j_end; ++j)
             for (int k = 0; k <= dims[2]; ++k) {
                 double pos[3], d[8];
                 abc_to_xyz(dims, size, shift, i, j, k, pos);
@@ -363,7 +364,7 @@ ORACLE_API int oracle_grid_coulomb(
     const double mat[9], const double invmat[9], int ortho, double safemin2, double cutoff2,
     double alpha,
     const int32_t dims[3], const double size[3], const double shift[3], const double delta[3],
-    double lambda, double thr, int32_t i_begin, int32_t i_end,
+    double lambda, double thr, int32_t i_begin, int32_t i_end, int32_t j_begin, int32_t j_end,
     float* grid, double* raw8, int32_t nthreads)
 {
     const int64_t nz = dims[2] + 1, ny = dims[1] + 1, nx = dims[0] + 1;
@@ -375,7 +376,7 @@ ORACLE_API int oracle_grid_coulomb(
 #endif
 #pragma omp parallel for schedule(dynamic, 1)
     for (int i = i_begin; i < i_end; ++i) {
-        for (int j = 0; j <= dims[1]; ++j)
+        for (int j = j_begin; j < j_end; ++j)
             for (int k = 0; k <= dims[2]; ++k) {
                 double pos[3], d[8];
                 abc_to_xyz(dims, size, shift, i, j, k, pos);

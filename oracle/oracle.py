@@ -54,11 +54,11 @@ def lib() -> C.CDLL:
         l.oracle_grid_vdw.restype = C.c_int
         l.oracle_grid_vdw.argtypes = [_dp, _i64p, C.c_int64, _dp, _dp, C.c_int, C.c_double, C.c_double,
                                       C.c_void_p, _i32p, C.c_int32, _i32p, _dp, _dp, _dp,
-                                      C.c_double, C.c_double, C.c_int32, C.c_int32, _fp, _dp, C.c_int32]
+                                      C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp, _dp, C.c_int32]
         l.oracle_grid_coulomb.restype = C.c_int
         l.oracle_grid_coulomb.argtypes = [_dp, _dp, C.c_int64, _dp, _dp, C.c_int, C.c_double, C.c_double,
                                           C.c_double, _i32p, _dp, _dp, _dp,
-                                          C.c_double, C.c_double, C.c_int32, C.c_int32, _fp, _dp, C.c_int32]
+                                          C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp, _dp, C.c_int32]
         l.oracle_points_vdw.restype = C.c_int
         l.oracle_points_vdw.argtypes = [_dp, _i64p, C.c_int64, _dp, _dp, C.c_int, C.c_double, C.c_double,
                                         C.c_void_p, _i32p, _dp, C.c_int64, _dp, C.c_int32]
@@ -102,7 +102,7 @@ def _geom(cset):
             np.ascontiguousarray(cset.shift, dtype=np.float64), np.ascontiguousarray(cset.delta, dtype=np.float64))
 
 
-def grid_vdw(probe, cset, lam, thr, i_begin=0, i_end=None, want_raw=False, nthreads=0):
+def grid_vdw(probe, cset, lam, thr, i_begin=0, i_end=None, want_raw=False, nthreads=0, j_begin=0, j_end=None):
     """Loop nest of create_grid_vdw (grids.jl:144-150) for x-planes [i_begin, i_end).
     Returns (grid float32[8,nx,ny,nz], raw float64[nx,ny,nz,8] or None); planes outside the
     range are left NaN."""
@@ -110,30 +110,32 @@ def grid_vdw(probe, cset, lam, thr, i_begin=0, i_end=None, want_raw=False, nthre
     dims, size, shift, delta = _geom(cset)
     nx, ny, nz = (int(d) + 1 for d in dims)
     i_end = nx if i_end is None else i_end
+    j_end = ny if j_end is None else j_end
     grid = np.full((8, nx, ny, nz), np.nan, dtype=np.float32)
     raw = np.full((nx, ny, nz, 8), np.nan, dtype=np.float64) if want_raw else None
     rc = lib().oracle_grid_vdw(_d(p.pos), p.kinds.ctypes.data_as(_i64p), p.n, _d(p.mat), _d(p.invmat),
                                int(p.ortho), p.safemin2, p.cutoff2, p.rules.ctypes.data,
                                p.offsets.ctypes.data_as(_i32p), p.nkinds,
                                dims.ctypes.data_as(_i32p), _d(size), _d(shift), _d(delta),
-                               lam, thr, i_begin, i_end, grid.ctypes.data_as(_fp),
+                               lam, thr, i_begin, i_end, j_begin, j_end, grid.ctypes.data_as(_fp),
                                _d(raw) if want_raw else None, nthreads)
     if rc:
         raise RuntimeError(f"oracle_grid_vdw: rule kind rejected by derivativesGrid (code {rc})")
     return grid, raw
 
 
-def grid_coulomb(probe, alpha, cset, lam, thr, i_begin=0, i_end=None, want_raw=False, nthreads=0):
+def grid_coulomb(probe, alpha, cset, lam, thr, i_begin=0, i_end=None, want_raw=False, nthreads=0, j_begin=0, j_end=None):
     """Loop nest of create_grid_coulomb (grids.jl:171-177)."""
     p = _Probe(probe)
     dims, size, shift, delta = _geom(cset)
     nx, ny, nz = (int(d) + 1 for d in dims)
     i_end = nx if i_end is None else i_end
+    j_end = ny if j_end is None else j_end
     grid = np.full((8, nx, ny, nz), np.nan, dtype=np.float32)
     raw = np.full((nx, ny, nz, 8), np.nan, dtype=np.float64) if want_raw else None
     lib().oracle_grid_coulomb(_d(p.pos), _d(p.q), p.n, _d(p.mat), _d(p.invmat), int(p.ortho), p.safemin2,
                               p.cutoff2, alpha, dims.ctypes.data_as(_i32p), _d(size), _d(shift), _d(delta),
-                              lam, thr, i_begin, i_end, grid.ctypes.data_as(_fp),
+                              lam, thr, i_begin, i_end, j_begin, j_end, grid.ctypes.data_as(_fp),
                               _d(raw) if want_raw else None, nthreads)
     return grid, raw
 

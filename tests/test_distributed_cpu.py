@@ -1,0 +1,60 @@
+"""N > 1 path on CPU: world_size 2 and 3 over gloo.  Each rank fills its x-slab (the oracle
+stands in for the kernel launch here -- this test is about the sharding + gather, the data
+path of ceg_hip.distributed), then the single all-gather assembles the grid on every rank."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, spacing, outdir):
+    for p in (str(ROOT / "crystalenergygrids.jl_amd"), str(ROOT)):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ceg_hip import grids as G, workloads as W
+        from ceg_hip.distributed import allgather_grid, slab_range
+        from oracle import oracle as O
+        w = W.fixture_workload("CIT-7", "Ar", spacing)
+        nx, ny, nz = w.cset.npoints
+        b, e = slab_range(nx, world, rank)
+        lam, thr = G.vdw_scaling()
+        g, _ = O.grid_vdw(w.probe_vdw, w.cset, lam, thr, b, e, nthreads=2)
+        local = torch.from_numpy(np.ascontiguousarray(g[:, b:e]))
+        full = torch.full((8, nx, ny, nz), float("nan"), dtype=torch.float32)
+        allgather_grid(full, local)
+        np.save(os.path.join(outdir, f"rank{rank}.npy"), full.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,spacing", [(2, 1.5), (3, 1.5), (2, 2.5)])
+def test_slab_gather_gloo(tmp_path, world, spacing, oracle):
+    from ceg_hip import grids as G, workloads as W
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, spacing, str(tmp_path)), nprocs=world, join=True)
+    w = W.fixture_workload("CIT-7", "Ar", spacing)
+    lam, thr = G.vdw_scaling()
+    ref, _ = oracle.grid_vdw(w.probe_vdw, w.cset, lam, thr)
+    assert not np.isnan(ref).any()
+    for r in range(world):
+        got = np.load(tmp_path / f"rank{r}.npy")
+        np.testing.assert_array_equal(got, ref)

@@ -1,0 +1,339 @@
+"""GPU parity tests proper: the HIP kernels, called through the C ABI (libceg_hip.so), against
+the CPU oracle / the committed golden samples.  Tolerance: 1e-6 relative on every stored
+Float32 value (north_star), identical NaN / Inf / 2e7-sentinel patterns, bit-exact grid
+geometry (indices and offsets are integers computed by the same formulas; positions are
+checked bitwise through the raw FP64 path).  Run with `pytest -m gpu` on an MI355X."""
+import math
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import ceg_hip as ceg
+from ceg_hip import _abi, grids as G, workloads as W
+from ceg_hip.plan import GridPlan
+from ceg_hip.utils import mat_from_parameters, perpendicular_lengths, prepare_periodic_distance_computations
+from oracle.compare import compare_grids
+
+from util import compare_raw, grid_points, random_atoms, synthetic_probes
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = Path(__file__).parent / "golden"
+CASES = {"cha_0.5": ("CHA_1.4_3b4eeb96", 0.5), "cha_0.1": ("CHA_1.4_3b4eeb96", 0.1), "cit7_0.15": ("CIT-7", 0.15)}
+BRUTE, CULLED, AUTO = _abi.ALGO_BRUTEFORCE, _abi.ALGO_CULLED, _abi.ALGO_AUTO
+
+
+# ------------------------------------------------------------------ golden samples
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_golden_samples(hip_lib, case):
+    """BASELINE configs 1 / 2 and the triclinic supercell case at the committed sample points:
+    raw FP64 sums (both algorithms) and the Float32 values of full one-shot grid builds."""
+    fwname, spacing = CASES[case]
+    z = np.load(GOLDEN / f"samples_{case}.npz")
+    i, j, k = z["idx"].T
+    for atom in ("Ar", "Na"):
+        w = W.fixture_workload(fwname, atom, spacing)
+        np.testing.assert_array_equal(w.cset.dims, z["dims"])            # bit-exact geometry
+        plan = GridPlan(w.cset, w.probe_vdw, w.probe_coulomb, w.alpha)
+        assert plan.can_cull
+        for algo in (BRUTE, CULLED):
+            compare_raw(plan.eval_points("vdw", z["points"], algo), z[f"raw_vdw_{atom}"], f"{case}/vdw/{atom}/algo{algo}")
+            if atom == "Ar":
+                compare_raw(plan.eval_points("coulomb", z["points"], algo), z["raw_coulomb"], f"{case}/coulomb/algo{algo}")
+        plan.close()
+        grid = G.build_vdw_array(w.probe_vdw, w.cset)
+        compare_grids(grid[:, i, j, k], z[f"f32_vdw_{atom}"].T, f"{case}/grid/vdw/{atom}")
+    grid = G.build_coulomb_array(w.probe_coulomb, w.alpha, w.cset)
+    compare_grids(grid[:, i, j, k], z["f32_coulomb"].T, f"{case}/grid/coulomb")
+
+
+# ------------------------------------------------------------------ full grids vs oracle
+@pytest.mark.parametrize("fwname,spacing", [("CHA_1.4_3b4eeb96", 0.5), ("CIT-7", 0.3), ("CHA_1.4_3b4eeb96_Na_11812", 0.7)])
+def test_full_grids_vs_oracle(hip_lib, oracle, fwname, spacing):
+    for atom in ("Ar", "Na"):
+        w = W.fixture_workload(fwname, atom, spacing)
+        lam, thr = G.vdw_scaling()
+        ref, _ = oracle.grid_vdw(w.probe_vdw, w.cset, lam, thr)
+        got = G.build_vdw_array(w.probe_vdw, w.cset)
+        assert got.shape == ref.shape and got.dtype == np.float32
+        compare_grids(got, ref, f"{fwname}/{atom}")
+    lam, thr = G.coulomb_scaling()
+    ref, _ = oracle.grid_coulomb(w.probe_coulomb, w.alpha, w.cset, lam, thr)
+    compare_grids(G.build_coulomb_array(w.probe_coulomb, w.alpha, w.cset), ref, f"{fwname}/coulomb")
+
+
+def test_create_grid_files_roundtrip(hip_lib, oracle, tmp_path, forcefield):
+    """create_grid_vdw / create_grid_coulomb -> file -> parse_grid -> interpolate_grid, vs the same
+    through the oracle (the drop-in boundary as a caller sees it)."""
+    fw = ceg.load_framework_RASPA("CIT-7", "BoulfelfelSholl2021")
+    g = ceg.create_grid_vdw(tmp_path / "v.grid", fw, forcefield, 0.4, "Na")
+    eg = ceg.parse_grid(tmp_path / "v.grid", False)
+    assert eg.num_unitcell == (2, 3, 3)
+    np.testing.assert_array_equal(eg.grid, (g.astype(np.float64) * ceg.GRID_TO_KELVIN).astype(np.float32))
+    w = W.fixture_workload("CIT-7", "Na", 0.4)
+    lam, thr = G.vdw_scaling()
+    ref, _ = oracle.grid_vdw(w.probe_vdw, w.cset, lam, thr)
+    compare_grids(g, ref, "create_grid_vdw")
+    ew = ceg.initialize_ewald(fw)
+    gc = ceg.create_grid_coulomb(tmp_path / "c.grid", fw, forcefield, 0.4, ew)
+    ec = ceg.parse_grid(tmp_path / "c.grid", True)
+    assert ec.ewald_precision == 1e-6
+    lam, thr = G.coulomb_scaling()
+    refc, _ = oracle.grid_coulomb(w.probe_coulomb, ew.alpha, w.cset, lam, thr)
+    compare_grids(gc, refc, "create_grid_coulomb")
+    ref_eg = G.EnergyGrid(eg.csetup, eg.num_unitcell, math.inf, True, (ref.astype(np.float64) * ceg.GRID_TO_KELVIN).astype(np.float32))
+    for p in ([3.1, 4.2, 5.3], [-2.0, 7.5, 1.0], [9.99, 0.01, 8.0]):
+        a, b = ceg.interpolate_grid(eg, p), ceg.interpolate_grid(ref_eg, p)
+        assert a == b or a == pytest.approx(b, rel=1e-5)
+
+
+# ------------------------------------------------------------------ synthetic edge cases
+def _check_all(plan, pv, pc, alpha, cset, oracle, what, algos=(BRUTE, CULLED)):
+    pts = grid_points(cset)
+    ref_v = oracle.points_vdw(pv, pts)
+    ref_c = oracle.points_coulomb(pc, alpha, pts)
+    for algo in algos:
+        compare_raw(plan.eval_points("vdw", pts, algo), ref_v, f"{what}/vdw/algo{algo}")
+        compare_raw(plan.eval_points("coulomb", pts, algo), ref_c, f"{what}/coulomb/algo{algo}")
+    return ref_v, ref_c
+
+
+@pytest.mark.parametrize("name,lengths,angles", [
+    ("orthorhombic", (25.0, 27.0, 30.0), (90.0, 90.0, 90.0)),        # diagonal matrix: wrapped == nearest
+    ("near-ortho", (26.0, 26.0, 26.0), (91.5, 88.6, 90.9)),          # ortho flag true, images dropped like the reference
+    ("triclinic", (27.0, 29.0, 33.0), (94.07, 100.0, 85.0)),
+    ("skewed-60", (36.0, 36.0, 36.0), (60.0, 60.0, 60.0)),            # safemin2 < cutoff2: stale-vector branch is live
+    ("skewed-mixed", (34.0, 40.0, 38.0), (62.0, 115.0, 70.0)),
+])
+def test_cells_and_min_image_branches(hip_lib, oracle, name, lengths, angles):
+    mat = mat_from_parameters(lengths, angles)
+    assert perpendicular_lengths(mat).min() >= 24.0, perpendicular_lengths(mat)
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    n = 120
+    pos = random_atoms(mat, n, rng)
+    kinds = rng.integers(1, 5, n)
+    q = rng.uniform(-1.2, 1.9, n)
+    pv, pc = synthetic_probes(mat, pos, kinds, q)
+    ortho, safemin2 = pv.periodic_setup()
+    if name.startswith("skewed"):
+        assert not ortho and safemin2 < 144.0
+    if name == "near-ortho":
+        assert ortho
+    cset = W.grid_setup_with_dims(mat, (9, 7, 11))                     # 10 x 8 x 12 points: partial 4x4x4 tiles
+    alpha = 0.26505830360350674
+    plan = GridPlan(cset, pv, pc, alpha)
+    assert plan.can_cull
+    _check_all(plan, pv, pc, alpha, cset, oracle, name)
+    plan.close()
+
+
+def test_points_on_atoms_nan_inf_patterns(hip_lib, oracle):
+    """Grid points that coincide with atoms: LJ value +Inf and -Inf*0 = NaN derivatives, hard-sphere
+    Inf, Coulomb Inf within 1 A -- must come out identically (then clamp to the 2e7 sentinel)."""
+    L = 30.0
+    mat = np.diag([L, L, L])
+    cset = W.grid_setup_with_dims(mat, (15, 15, 15))                   # spacing 2.0 exactly, shift 0
+    pos = np.array([[4.0, 6.0, 8.0], [10.0, 10.0, 10.0], [20.0, 2.0, 28.0], [11.3, 17.7, 5.1], [0.0, 0.0, 0.0]])
+    kinds = np.array([1, 2, 4, 2, 1])
+    q = np.array([1.0, -1.0, 0.5, 0.0, -0.7])
+    pv, pc = synthetic_probes(mat, pos, kinds, q)
+    alpha = 0.265
+    plan = GridPlan(cset, pv, pc, alpha)
+    ref_v, ref_c = _check_all(plan, pv, pc, alpha, cset, oracle, "on-atoms")
+    assert np.isnan(ref_v).any() and np.isinf(ref_v).any() and np.isinf(ref_c).any() and np.isnan(ref_c).any()
+    plan.close()
+    for build, probe, sc, args in ((G.build_vdw_array, pv, G.vdw_scaling, ()), (G.build_coulomb_array, pc, G.coulomb_scaling, (alpha,))):
+        got = build(probe, *args, cset)
+        lam, thr = sc()
+        ref = (oracle.grid_vdw(pv, cset, lam, thr) if not args else oracle.grid_coulomb(pc, alpha, cset, lam, thr))[0]
+        compare_grids(got, ref, "on-atoms/grid")
+        assert (ref[0] == np.float32(2e7)).any() and np.isnan(ref[1:4]).any()
+
+
+def test_small_cell_forces_bruteforce(hip_lib, oracle):
+    """A ProbeSystem that violates the 2*cutoff width rule (never produced by ProbeSystem itself,
+    probes.jl:24, but legal at the C boundary): AUTO must fall back to the literal kernel, CULLED
+    must refuse."""
+    mat = mat_from_parameters((15.0, 16.0, 17.0), (80.0, 95.0, 100.0))
+    rng = np.random.default_rng(3)
+    pos = random_atoms(mat, 40, rng)
+    pv, pc = synthetic_probes(mat, pos, rng.integers(1, 5, 40), rng.uniform(-1, 1, 40))
+    cset = W.grid_setup_with_dims(mat, (7, 7, 7))
+    plan = GridPlan(cset, pv, pc, 0.265)
+    assert not plan.can_cull
+    _check_all(plan, pv, pc, 0.265, cset, oracle, "small-cell", algos=(BRUTE, AUTO))
+    with pytest.raises(_abi.CegError) as ei:
+        plan.eval_points("vdw", grid_points(cset), CULLED)
+    assert ei.value.code == -5
+    plan.close()
+    lam, thr = G.vdw_scaling()
+    compare_grids(G.build_vdw_array(pv, cset), oracle.grid_vdw(pv, cset, lam, thr)[0], "small-cell/grid")
+
+
+def test_empty_and_single_atom_frameworks(hip_lib, oracle):
+    mat = np.diag([24.0, 25.0, 26.0])
+    cset = W.grid_setup_with_dims(mat, (5, 5, 5))
+    pv, pc = synthetic_probes(mat, [[1.0, 2.0, 3.0]], [1], [0.8])
+    plan = GridPlan(cset, pv, pc, 0.265)
+    _check_all(plan, pv, pc, 0.265, cset, oracle, "single")
+    plan.close()
+    pv0, pc0 = synthetic_probes(mat, np.empty((0, 3)), np.empty(0, dtype=np.int64), np.empty(0))
+    got = G.build_vdw_array(pv0, cset)
+    assert got.shape == (8, 6, 6, 6) and np.all(got == 0)
+    assert np.all(G.build_coulomb_array(pc0, 0.265, cset) == 0)
+
+
+def test_eval_points_outside_grid_box(hip_lib, oracle):
+    w = W.fixture_workload("CIT-7", "Na", 1.0)
+    plan = GridPlan(w.cset, w.probe_vdw, w.probe_coulomb, w.alpha)
+    rng = np.random.default_rng(9)
+    pts = rng.uniform(-60, 90, (300, 3))                                # far outside the unit-cell bounding box
+    compare_raw(plan.eval_points("vdw", pts, AUTO), oracle.points_vdw(w.probe_vdw, pts), "outside/vdw")
+    compare_raw(plan.eval_points("coulomb", pts, AUTO), oracle.points_coulomb(w.probe_coulomb, w.alpha, pts), "outside/coulomb")
+    with pytest.raises(_abi.CegError):
+        plan.eval_points("vdw", pts, CULLED)
+    inside = w.cset.shift + rng.uniform(0, 1, (500, 3)) * w.cset.size   # unordered points: arbitrary 64-point "tiles"
+    compare_raw(plan.eval_points("vdw", inside, CULLED), oracle.points_vdw(w.probe_vdw, inside), "scattered/vdw")
+    compare_raw(plan.eval_points("coulomb", inside, CULLED), oracle.points_coulomb(w.probe_coulomb, w.alpha, inside), "scattered/coulomb")
+    plan.close()
+
+
+def test_library_rejects_invalid_rule_kinds(hip_lib):
+    """A Monomial rule on a kind that occurs in the framework -> CEG_ERR_RULE (interactions.jl:462-465)."""
+    w = W.fixture_workload("CIT-7", "Ar", 2.0)
+    rules, off = w.forcefield.rule_table(w.probe_vdw.probe)
+    k = w.forcefield.sdict["Oz"]
+    rules[off[k - 1]]["kind"] = 5
+    pos = np.ascontiguousarray(w.probe_vdw.positions)
+    kinds = np.ascontiguousarray(w.probe_vdw.atomkinds)
+    dims, size, shift, delta = G._grid_args(w.cset)
+    grid = np.empty((8,) + w.cset.npoints, dtype=np.float32)
+    lam, thr = G.vdw_scaling()
+    mat, inv = G._matT(w.probe_vdw.mat), G._matT(w.probe_vdw.invmat)
+    rc = hip_lib.ceg_grid_vdw(_abi.dptr(pos), _abi.i64ptr(kinds), len(kinds), _abi.dptr(mat), _abi.dptr(inv), 0, 144.2, 144.0,
+                              rules.ctypes.data, _abi.i32ptr(off), w.forcefield.nkinds, _abi.i32ptr(dims), _abi.dptr(size),
+                              _abi.dptr(shift), _abi.dptr(delta), lam, thr, _abi.fptr(grid), 1)
+    assert rc == -4 and b"not valid in a VdW grid" in hip_lib.ceg_last_error()
+    rc = hip_lib.ceg_grid_vdw(_abi.dptr(pos), _abi.i64ptr(kinds), len(kinds), _abi.dptr(mat), _abi.dptr(inv), 0, 144.2, 144.0,
+                              rules.ctypes.data, _abi.i32ptr(off), w.forcefield.nkinds, _abi.i32ptr(dims), _abi.dptr(size),
+                              _abi.dptr(shift), _abi.dptr(delta), lam, thr, _abi.fptr(grid), 99)
+    assert rc == -2
+
+
+# ------------------------------------------------------------------ plan API on device buffers
+def test_slabs_fused_and_layouts(hip_lib, oracle):
+    """x-slab builds into device memory (full buffer and compact slabs, odd split), fused ==
+    separate, culled == brute force, all == oracle."""
+    import torch
+    w = W.fixture_workload("CHA_1.4_3b4eeb96", "Na", 0.9)
+    nx, ny, nz = w.cset.npoints
+    plane = ny * nz
+    plan = GridPlan(w.cset, w.probe_vdw, w.probe_coulomb, w.alpha)
+    dev = torch.device("cuda", 0)
+    lam, thr = G.vdw_scaling()
+    ref_v, _ = oracle.grid_vdw(w.probe_vdw, w.cset, lam, thr)
+    lam, thr = G.coulomb_scaling()
+    ref_c, _ = oracle.grid_coulomb(w.probe_coulomb, w.alpha, w.cset, lam, thr)
+    full_v = torch.full((8, nx, ny, nz), float("nan"), dtype=torch.float32, device=dev)
+    full_c = torch.full_like(full_v, float("nan"))
+    s = torch.cuda.current_stream().cuda_stream
+    cuts = [0, 5, 6, 19, nx]                                           # uneven slabs, one of a single plane
+    for b, e in zip(cuts[:-1], cuts[1:]):
+        plan.build_fused(full_v.data_ptr(), full_c.data_ptr(), nx * plane, b, e, 0, CULLED, s)
+    torch.cuda.synchronize()
+    compare_grids(full_v.cpu().numpy(), ref_v, "slabs/fused/vdw")
+    compare_grids(full_c.cpu().numpy(), ref_c, "slabs/fused/coulomb")
+    # compact slab buffers, separate kernels, brute force
+    b, e = 7, 21
+    loc_v = torch.empty((8, e - b, ny, nz), dtype=torch.float32, device=dev)
+    loc_c = torch.empty_like(loc_v)
+    plan.build_vdw(loc_v.data_ptr(), (e - b) * plane, b, e, b, BRUTE, s)
+    plan.build_coulomb(loc_c.data_ptr(), (e - b) * plane, b, e, b, BRUTE, s)
+    torch.cuda.synchronize()
+    compare_grids(loc_v.cpu().numpy(), ref_v[:, b:e], "slab/brute/vdw")
+    compare_grids(loc_c.cpu().numpy(), ref_c[:, b:e], "slab/brute/coulomb")
+    # culled and brute force agree with each other far inside the tolerance
+    compare_grids(loc_v.cpu().numpy(), full_v[:, b:e].cpu().numpy(), "slab/brute-vs-culled", rtol=2e-7)
+    # argument validation
+    for bad in ((-1, 3, 0), (3, 2, 0), (0, nx + 1, 0), (4, 6, 5)):
+        with pytest.raises(_abi.CegError):
+            plan.build_vdw(loc_v.data_ptr(), nx * plane, bad[0], bad[1], bad[2], AUTO, s)
+    with pytest.raises(_abi.CegError):
+        plan.build_vdw(loc_v.data_ptr(), 3, 0, 4, 0, AUTO, s)
+    plan.close()
+
+
+# ------------------------------------------------------------------ BASELINE size, size-independent properties
+def test_roofline_workload_properties(hip_lib, oracle):
+    """256^3 x 11 664 atoms (BASELINE config 3).  The oracle would need ~15 CPU-hours for the full
+    grid, so: (a) culled == brute force on a slab, (b) slab builds are independent of the split,
+    (c) invariance under translating every atom by a lattice vector, (d) an oracle block."""
+    import torch
+    w = W.roofline_workload("Ar", 255)
+    nx, ny, nz = w.cset.npoints
+    plane = ny * nz
+    dev = torch.device("cuda", 0)
+    plan = GridPlan(w.cset, w.probe_vdw, w.probe_coulomb, w.alpha)
+    assert plan.can_cull and plan.num_images > w.natoms
+    s = torch.cuda.current_stream().cuda_stream
+    full_v = torch.empty((8, nx, ny, nz), dtype=torch.float32, device=dev)
+    full_c = torch.empty_like(full_v)
+    plan.build_fused(full_v.data_ptr(), full_c.data_ptr(), nx * plane, 0, nx, 0, CULLED, s)
+    torch.cuda.synchronize()
+    assert torch.isfinite(full_v).all() and torch.isfinite(full_c).all()
+    assert (full_v[0] == 2e7).any() and (full_c[0] == 2e7).any()
+    # (a) brute force on 8 x-planes
+    b, e = 100, 108
+    loc_v = torch.empty((8, e - b, ny, nz), dtype=torch.float32, device=dev)
+    loc_c = torch.empty_like(loc_v)
+    plan.build_fused(loc_v.data_ptr(), loc_c.data_ptr(), (e - b) * plane, b, e, b, BRUTE, s)
+    torch.cuda.synchronize()
+    compare_grids(full_v[:, b:e].cpu().numpy(), loc_v.cpu().numpy(), "R/culled-vs-brute/vdw")
+    compare_grids(full_c[:, b:e].cpu().numpy(), loc_c.cpu().numpy(), "R/culled-vs-brute/coulomb")
+    # (b) split independence (bitwise: same tiles, same candidate order only if tile origin is the same;
+    #     slabs starting at multiples of 4 keep the tiling, so those are bit-identical)
+    again = torch.empty_like(full_v)
+    for sb, se in ((0, 64), (64, 200), (200, nx)):
+        plan.build_vdw(again.data_ptr(), nx * plane, sb, se, 0, CULLED, s)
+    torch.cuda.synchronize()
+    assert torch.equal(again, full_v)
+    odd = torch.empty((8, 7, ny, nz), dtype=torch.float32, device=dev)
+    plan.build_vdw(odd.data_ptr(), 7 * plane, 33, 40, 33, CULLED, s)          # tiles shifted by one plane
+    torch.cuda.synchronize()
+    compare_grids(odd.cpu().numpy(), full_v[:, 33:40].cpu().numpy(), "R/shifted-tiles", rtol=2e-7)
+    plan.close()
+    # (c) lattice-translation invariance
+    import copy
+    pv2, pc2 = copy.copy(w.probe_vdw), copy.copy(w.probe_coulomb)
+    t = w.probe_vdw.mat @ np.array([1.0, -1.0, 2.0])
+    pv2.positions = w.probe_vdw.positions + t
+    pc2.positions = pv2.positions
+    plan2 = GridPlan(w.cset, pv2, pc2, w.alpha)
+    v2 = torch.empty((8, 16, ny, nz), dtype=torch.float32, device=dev)
+    c2 = torch.empty_like(v2)
+    plan2.build_fused(v2.data_ptr(), c2.data_ptr(), 16 * plane, 120, 136, 120, CULLED, s)
+    torch.cuda.synchronize()
+    compare_grids(v2.cpu().numpy(), full_v[:, 120:136].cpu().numpy(), "R/translation/vdw")
+    compare_grids(c2.cpu().numpy(), full_c[:, 120:136].cpu().numpy(), "R/translation/coulomb")
+    plan2.close()
+    # (d) oracle block: 16 planes x 2 rows
+    i0, i1, j0, j1 = 120, 136, 128, 130
+    lam, thr = G.vdw_scaling()
+    ref, _ = oracle.grid_vdw(w.probe_vdw, w.cset, lam, thr, i0, i1, j_begin=j0, j_end=j1)
+    compare_grids(full_v[:, i0:i1, j0:j1].cpu().numpy(), ref[:, i0:i1, j0:j1], "R/oracle/vdw")
+    lam, thr = G.coulomb_scaling()
+    ref, _ = oracle.grid_coulomb(w.probe_coulomb, w.alpha, w.cset, lam, thr, i0, i1, j_begin=j0, j_end=j1)
+    compare_grids(full_c[:, i0:i1, j0:j1].cpu().numpy(), ref[:, i0:i1, j0:j1], "R/oracle/coulomb")
+
+
+def test_multi_device_oneshot_if_available(hip_lib, oracle):
+    """ngpus > 1 in the one-shot entry point (single process, slabs on several devices)."""
+    n = hip_lib.ceg_device_count()
+    if n < 2:
+        pytest.skip("one device visible")
+    w = W.fixture_workload("CHA_1.4_3b4eeb96", "Ar", 0.7)
+    lam, thr = G.vdw_scaling()
+    ref, _ = oracle.grid_vdw(w.probe_vdw, w.cset, lam, thr)
+    compare_grids(G.build_vdw_array(w.probe_vdw, w.cset, ngpus=min(n, 4)), ref, "multi-device")

@@ -1,0 +1,246 @@
+"""Host-side logic around the hot path (no GPU): ABI exports, geometry rules, force-field
+flattening, ``.grid`` file format, interpolation, error behaviour."""
+import ctypes
+import math
+import re
+import struct
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import ceg_hip as ceg
+from ceg_hip import _abi, grids as G, workloads as W
+from ceg_hip.constants import tricubic_coeff
+from ceg_hip.interactions import FF, InteractionRule, InteractionRuleSum, make_rule
+from ceg_hip.probes import ProbeSystem
+from ceg_hip.utils import find_supercell, get_atom_name, mat_from_parameters, prepare_periodic_distance_computations
+
+ROOT = Path(__file__).resolve().parent.parent
+FFNAME = "BoulfelfelSholl2021"
+
+
+# ------------------------------------------------------------------ C ABI
+def test_library_exports_every_declared_symbol():
+    """include/ceg_hip.h <-> libceg_hip.so <-> ctypes prototypes (no compute call)."""
+    header = (ROOT / "include" / "ceg_hip.h").read_text()
+    declared = set(re.findall(r"CEG_API\s+[\w\s\*]+?\b(ceg_\w+)\s*\(", header))
+    assert declared == set(_abi.PROTOTYPES), declared ^ set(_abi.PROTOTYPES)
+    lib = _abi.load_library()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.ceg_abi_version() == 1
+    assert lib.ceg_last_error() is not None
+
+
+def test_rule_struct_layout():
+    assert _abi.RULE_DTYPE.itemsize == 40
+    assert _abi.RULE_DTYPE.fields["p"][1] == 8 and _abi.RULE_DTYPE.fields["shift"][1] == 32
+
+
+def test_no_device_is_an_error_not_a_fallback():
+    """Without a GPU the build entry points must fail loudly (this container has none)."""
+    lib = _abi.load_library()
+    if lib.ceg_device_count() > 0:
+        pytest.skip("a HIP device is visible")
+    w = W.fixture_workload("CIT-7", "Ar", 2.0)
+    with pytest.raises(_abi.CegError) as ei:
+        G.build_vdw_array(w.probe_vdw, w.cset)
+    assert ei.value.code == -2 and "no HIP device" in str(ei.value)
+    with pytest.raises(_abi.CegError):
+        G.build_coulomb_array(w.probe_coulomb, w.alpha, w.cset)
+
+
+# ------------------------------------------------------------------ geometry
+def test_grid_coordinates_setup_cha():
+    """coordinates.jl:32-41 on the CHA fixture (numbers of SURVEY appendix A)."""
+    fw = ceg.load_framework_RASPA("CHA_1.4_3b4eeb96", FFNAME)
+    assert len(fw) == 972
+    for spacing, dims in ((0.5, (65, 61, 57)), (0.3, (109, 101, 95)), (0.15, (217, 203, 189)), (0.1, (325, 305, 283))):
+        cs = ceg.GridCoordinatesSetup.from_cell(fw.mat, spacing)
+        assert tuple(cs.dims) == dims and cs.dims.dtype == np.int32
+        assert np.all(cs.dims % 2 == 1)
+    np.testing.assert_allclose(cs.size, [32.40512513, 30.46790010, 28.22271121], rtol=1e-9)
+    np.testing.assert_allclose(cs.shift, [-4.02812513, -2.16246457, 0.0], rtol=1e-8, atol=1e-12)
+    np.testing.assert_array_equal(cs.delta, cs.size / cs.dims)
+    assert find_supercell(fw.mat, 12.0) == (1, 1, 1)
+    ortho, safemin = prepare_periodic_distance_computations(fw.mat)
+    assert not ortho and safemin == pytest.approx(14.0757679, rel=1e-8)
+
+
+def test_ortho_flag_uses_float16_tolerance():
+    """utils.jl:148 -- 2 % of 90 degrees evaluated on the Float16-rounded angle."""
+    def ortho(angle):
+        return prepare_periodic_distance_computations(mat_from_parameters((20.0, 21.0, 22.0), (90.0, 90.0, angle)))[0]
+    assert ortho(90.0) and ortho(91.5) and ortho(88.3)
+    assert not ortho(91.9) and not ortho(94.07) and not ortho(88.0)
+
+
+def test_supercell_tiling_order():
+    """probes.jl:37-53: index = ix*n*ny*nz + iy*n*nz + iz*n + i."""
+    ff = ceg.parse_forcefield_RASPA(FFNAME)
+    fw = ceg.load_framework_RASPA("CIT-7", FFNAME)
+    p = ProbeSystem.build(fw, ff, "Ar")
+    n, (nx, ny, nz) = len(fw), p.num_supercell
+    assert (nx, ny, nz) == (2, 3, 3)
+    a, b, c = fw.mat[:, 0], fw.mat[:, 1], fw.mat[:, 2]
+    for ix, iy, iz, i in ((0, 0, 0, 5), (1, 0, 0, 0), (0, 2, 1, 17), (1, 2, 2, 59)):
+        idx = ix * n * ny * nz + iy * n * nz + iz * n + i
+        np.testing.assert_allclose(p.positions[idx], fw.position[i] + ix * a + iy * b + iz * c, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(p.mat, np.column_stack((2 * a, 3 * b, 3 * c)))
+    np.testing.assert_allclose(p.mat @ p.invmat, np.eye(3), atol=1e-12)
+
+
+def test_get_atom_name():
+    assert get_atom_name("Oz_2") == "Oz" and get_atom_name("C_co2") == "C_co2"
+    assert get_atom_name("Na") == "Na" and get_atom_name("Si12") == "Si" and get_atom_name("O_co2_7") == "O_co2"
+
+
+# ------------------------------------------------------------------ force field
+def test_forcefield_fixture_rules():
+    """raspa.jl:611-702 on the fixture."""
+    ff = ceg.parse_forcefield_RASPA(FFNAME)
+    assert ff.sdict["UNIT"] == 1 and ff.sdict["Oz"] == 2 and ff.sdict["Siz"] == 5 and ff.sdict["Na"] == 8 and ff.sdict["Ar"] == 20
+    assert ff.cutoff == 12.0
+    r = ff["Ar", "Oz"]
+    assert isinstance(r, InteractionRule) and r.kind == FF.LennardJones and r.params == [107.69, 3.15]
+    assert r.shift == pytest.approx(4 * 107.69 * ((3.15 / 12) ** 12 - (3.15 / 12) ** 6), rel=1e-12) and not r.tailcorrection
+    assert ff["Ar", "Siz"].kind == FF.NoInteraction and ff["Ar", "Alz"].kind == FF.NoInteraction
+    assert ff["Ar", "Na"].params == [262.0, 2.396]
+    s = ff["Na", "Oa"]
+    assert isinstance(s, InteractionRuleSum)
+    assert [x.kind for x in s.rules] == [FF.HardSphere, FF.CoulombEwaldDirect, FF.Buckingham]
+    assert s.rules[0].params == [1.5, 0.0] and s.rules[2].params == [5.581e7, 3.985, 9.167e5]
+    assert s.rules[1].params[0] == pytest.approx(0.26505830360350674, rel=1e-15)
+    assert all(x.shift == 0.0 for x in s.rules)                       # general rule: truncated
+    assert ff["Na", "Siz"].kind == FF.CoulombEwaldDirect
+    assert ff.needsvdwgrid("Na") and ff.needsvdwgrid("Ar")
+    # Lorentz-Berthelot mixing of two LJ species (forcefields.jl:72-76)
+    m = ff["C_co2", "N_n2"]
+    lj = [x for x in ([m] if isinstance(m, InteractionRule) else m.rules) if x.kind == FF.LennardJones][0]
+    assert lj.params[0] == pytest.approx(math.sqrt(28.129 * 36.4)) and lj.params[1] == pytest.approx((2.757 + 3.32) / 2)
+
+
+def test_rule_table_flattening():
+    ff = ceg.parse_forcefield_RASPA(FFNAME)
+    rules, off = ff.rule_table(ff.sdict["Na"])
+    assert off.dtype == np.int32 and len(off) == ff.nkinds + 1 and off[0] == 0 and off[-1] == len(rules)
+    k = ff.sdict["Oz"]
+    run = rules[off[k - 1]:off[k]]
+    assert [int(x) for x in run["kind"]] == [0, 1, 4]
+    np.testing.assert_array_equal(run["p"][2], [5.581e7, 3.985, 9.167e5])
+    rules_ar, off_ar = ff.rule_table(ff.sdict["Ar"])
+    k = ff.sdict["Siz"]
+    assert [int(x) for x in rules_ar[off_ar[k - 1]:off_ar[k]]["kind"]] == [8]
+
+
+def test_vdw_grid_rule_errors_mirror_reference():
+    """interactions.jl:442-443,462-467: the shim raises before the device call."""
+    from ceg_hip.interactions import check_vdw_grid_rule, UndefinedInteractionError
+    with pytest.raises(UndefinedInteractionError):
+        check_vdw_grid_rule(make_rule(FF.UndefinedInteraction))
+    with pytest.raises(RuntimeError, match="Monomial"):
+        check_vdw_grid_rule(make_rule(FF.Monomial, 1.0, 2.0))
+    with pytest.raises(RuntimeError, match="Coulomb"):
+        check_vdw_grid_rule(make_rule(FF.Coulomb, 1.0, 1.0))
+    check_vdw_grid_rule(make_rule(FF.NoInteraction))
+
+
+# ------------------------------------------------------------------ .grid files
+def _fake_grid(cset, seed=0):
+    nx, ny, nz = cset.npoints
+    rng = np.random.default_rng(seed)
+    return rng.standard_normal((8, nx, ny, nz)).astype(np.float32)
+
+
+def test_grid_file_layout_roundtrip(tmp_path):
+    """grids.jl:108-116,151-155,178-183 -> parse_grid grids.jl:61-94."""
+    fw = ceg.load_framework_RASPA("CIT-7", FFNAME)
+    cset = ceg.GridCoordinatesSetup.from_cell(fw.mat, 1.0)
+    grid = _fake_grid(cset)
+    nbytes = grid.size * 4
+    f_v, f_c = tmp_path / "v.grid", tmp_path / "c.grid"
+    G.write_grid_file(f_v, cset, (2, 3, 3), grid)
+    G.write_grid_file(f_c, cset, (2, 3, 3), grid, 1e-6)
+    assert f_v.stat().st_size == 128 + nbytes + 72          # header 128 B, trailer 72 B
+    assert f_c.stat().st_size == 136 + nbytes + 72
+    raw = f_v.read_bytes()
+    assert struct.unpack("<d", raw[:8])[0] == 1.0
+    assert struct.unpack("<3i", raw[8:20]) == tuple(int(d) for d in cset.dims)
+    assert struct.unpack("<3d", raw[20:44]) == tuple(cset.size)
+    assert struct.unpack("<3i", raw[116:128]) == (2, 3, 3)
+    np.testing.assert_array_equal(np.frombuffer(raw[128:128 + nbytes], dtype="<f4"), grid.reshape(-1))
+    np.testing.assert_array_equal(np.frombuffer(raw[-72:], dtype="<f8").reshape(3, 3).T, fw.mat)
+    for path, isc in ((f_v, False), (f_c, True)):
+        g = ceg.parse_grid(path, isc)
+        assert g.num_unitcell == (2, 3, 3) and g.higherorder
+        assert g.ewald_precision == (1e-6 if isc else math.inf)
+        np.testing.assert_array_equal(g.csetup.dims, cset.dims)
+        np.testing.assert_array_equal(g.grid, (grid.astype(np.float64) * ceg.GRID_TO_KELVIN).astype(np.float32))
+        np.testing.assert_array_equal(g.csetup.cell.mat, fw.mat)
+
+
+def test_array_memory_order_matches_julia():
+    """numpy (8,nx,ny,nz) C-order == Julia Array{Cfloat,4}(nz,ny,nx,8) column-major."""
+    nx, ny, nz = 5, 4, 3
+    a = np.arange(8 * nx * ny * nz, dtype=np.float32).reshape(8, nx, ny, nz)
+    c, i, j, k = 3, 2, 1, 2
+    assert a[c, i, j, k] == k + nz * (j + ny * (i + nx * c))
+
+
+# ------------------------------------------------------------------ interpolation
+def test_tricubic_coeff_reproduces_cubic_polynomial():
+    """COEFF (constants.jl:24-89, derived in constants.tricubic_coeff) must make
+    interpolate_grid exact for any tricubic polynomial."""
+    C = tricubic_coeff()
+    assert C.shape == (64, 64) and np.all(C == np.round(C))
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal((4, 4, 4))                      # a[i,j,k] x^i y^j z^k
+    def deriv(x, y, z, ox, oy, oz):
+        tot = 0.0
+        for i in range(4):
+            for j in range(4):
+                for k in range(4):
+                    def d(e, o, t):
+                        if o > e:
+                            return 0.0
+                        return (e if o else 1) * t ** (e - o)
+                    tot += a[i, j, k] * d(i, ox, x) * d(j, oy, y) * d(k, oz, z)
+        return tot
+    chans = [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1), (1, 1, 1)]
+    X = np.array([deriv(c & 1, (c >> 1) & 1, (c >> 2) & 1, *ch) for ch in chans for c in range(8)])
+    for r in ((0.3, 0.7, 0.2), (0.0, 0.0, 0.0), (0.99, 0.5, 0.01)):
+        assert G.interpolate_from_corners(X, r, False) == pytest.approx(deriv(*r, 0, 0, 0), rel=1e-12, abs=1e-12)
+
+
+def test_interpolate_vdw_blocked_corner():
+    X = np.zeros(64)
+    X[3] = 6e6
+    assert G.interpolate_from_corners(X, (0.5, 0.5, 0.5), True) == 1e100          # grids.jl:245-248
+    assert G.interpolate_from_corners(X, (0.5, 0.5, 0.5), False) != 1e100
+
+
+def test_zero_and_invalid_grids():
+    assert G.interpolate_grid(G.EnergyGrid.trivial(True), [0, 0, 0]) == 0.0
+    with pytest.raises(ValueError):
+        G.interpolate_grid(G.EnergyGrid.trivial(False), [0, 0, 0])
+
+
+# ------------------------------------------------------------------ sharding
+def test_slab_range_partition():
+    from ceg_hip.distributed import slab_range
+    for nx in (1, 7, 218, 256):
+        for world in (1, 2, 3, 4, 8):
+            spans = [slab_range(nx, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == nx
+            assert all(spans[r][1] == spans[r + 1][0] for r in range(world - 1))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_roofline_workload_shape():
+    w = W.roofline_workload("Ar", 255)
+    assert w.natoms == 11664 and w.cset.npoints == (256, 256, 256) and w.npoints == 16777216
+    assert w.probe_vdw.num_supercell == (1, 1, 1)
+    np.testing.assert_array_equal(w.probe_vdw.positions, w.probe_coulomb.positions)
+    assert abs(w.probe_coulomb.charges.sum() - 12 * (-122.769)) < 1e-6

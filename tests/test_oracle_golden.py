@@ -1,0 +1,53 @@
+"""The oracle reproduces the committed golden samples bit for bit (guards the checker itself
+against accidental edits; the samples were produced by tests/golden/make_golden.py)."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from ceg_hip import grids as G, workloads as W
+
+GOLDEN = Path(__file__).parent / "golden"
+CASES = {"cha_0.5": ("CHA_1.4_3b4eeb96", 0.5), "cha_0.1": ("CHA_1.4_3b4eeb96", 0.1), "cit7_0.15": ("CIT-7", 0.15)}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_oracle_matches_golden_samples(oracle, case):
+    fwname, spacing = CASES[case]
+    z = np.load(GOLDEN / f"samples_{case}.npz")
+    for atom in ("Ar", "Na"):
+        w = W.fixture_workload(fwname, atom, spacing)
+        np.testing.assert_array_equal(w.cset.dims, z["dims"])
+        i, j, k = z["idx"].T
+        pts = np.stack([i * w.cset.size[0] / w.cset.dims[0] + w.cset.shift[0],
+                        j * w.cset.size[1] / w.cset.dims[1] + w.cset.shift[1],
+                        k * w.cset.size[2] / w.cset.dims[2] + w.cset.shift[2]], axis=1)
+        np.testing.assert_array_equal(pts, z["points"])
+        raw = oracle.points_vdw(w.probe_vdw, pts)
+        np.testing.assert_array_equal(raw, z[f"raw_vdw_{atom}"])
+        lam, thr = G.vdw_scaling()
+        np.testing.assert_array_equal(oracle.set_gridpoints(raw, w.cset.delta, lam, thr), z[f"f32_vdw_{atom}"])
+    raw = oracle.points_coulomb(w.probe_coulomb, w.alpha, pts)
+    np.testing.assert_array_equal(raw, z["raw_coulomb"])
+    lam, thr = G.coulomb_scaling()
+    np.testing.assert_array_equal(oracle.set_gridpoints(raw, w.cset.delta, lam, thr), z["f32_coulomb"])
+    # the samples do exercise the special values
+    assert (z["f32_vdw_Na"][:, 0] == np.float32(2e7)).any() and (z["f32_coulomb"][:, 0] == np.float32(2e7)).any()
+
+
+def test_oracle_grid_driver_equals_pointwise(oracle):
+    """oracle_grid_vdw/coulomb (loop nest + _set_gridpoint!) == pointwise evaluation, and the
+    [z,y,x,c] placement is right."""
+    w = W.fixture_workload("CIT-7", "Na", 1.5)
+    nx, ny, nz = w.cset.npoints
+    lam, thr = G.vdw_scaling()
+    grid, raw = oracle.grid_vdw(w.probe_vdw, w.cset, lam, thr, want_raw=True)
+    assert grid.shape == (8, nx, ny, nz) and not np.isnan(raw).all()
+    from ceg_hip import abc_to_xyz
+    for (i, j, k) in ((0, 0, 0), (nx - 1, ny - 1, nz - 1), (3, 2, 1)):
+        one = oracle.points_vdw(w.probe_vdw, abc_to_xyz(w.cset, i, j, k)[None, :])
+        np.testing.assert_array_equal(raw[i, j, k], one[0])
+        np.testing.assert_array_equal(grid[:, i, j, k], oracle.set_gridpoints(one, w.cset.delta, lam, thr)[0])
+    lamc, thrc = G.coulomb_scaling()
+    gc, rawc = oracle.grid_coulomb(w.probe_coulomb, w.alpha, w.cset, lamc, thrc, i_begin=1, i_end=3, want_raw=True)
+    assert np.isnan(gc[:, 0]).all() and np.isnan(gc[:, 3:]).all() and not np.isnan(gc[0, 1:3]).any()
