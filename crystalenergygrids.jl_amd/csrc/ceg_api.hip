@@ -72,6 +72,7 @@ struct ceg_plan {
     int32_t* d_offset = nullptr;
     double4* d_images = nullptr;
     int32_t* d_imgkind = nullptr;
+    int32_t* d_imgatom = nullptr;
     int32_t* d_binstart = nullptr;
     ImageBins ib{};
     bool images_built = false;
@@ -199,7 +200,7 @@ int build_images(ceg_plan* p)
         nb[a] = std::max(1, (int)std::floor((hi[a] - lo[a]) / target));
         bin[a] = (hi[a] - lo[a]) / nb[a];
     }
-    struct Img { double x, y, z, q; int32_t kind; int32_t bin; };
+    struct Img { double x, y, z, q; int32_t kind; int32_t bin; int32_t atom; };
     std::vector<Img> imgs;
     imgs.reserve((size_t)p->natoms * 8);
     const double* M = g.mat;
@@ -241,6 +242,7 @@ int build_images(ceg_plan* p)
                     im.q = p->has_charge ? p->h_charge[a] : 0.0;
                     im.kind = p->has_rules ? p->h_kind[a] : -1;
                     im.bin = (b[0] * nb[1] + b[1]) * nb[2] + b[2];
+                    im.atom = (int32_t)a;
                     imgs.push_back(im);
                 }
     }
@@ -252,17 +254,22 @@ int build_images(ceg_plan* p)
     std::vector<int32_t> cursor(start.begin(), start.end() - 1);
     std::vector<double4> xyzq(imgs.size());
     std::vector<int32_t> kind(imgs.size());
+    std::vector<int32_t> atom(imgs.size());
     for (const Img& im : imgs) {       // stable: atom order, then lattice order, inside each bin
         const int32_t s = cursor[im.bin]++;
         xyzq[s] = make_double4(im.x, im.y, im.z, im.q);
         kind[s] = im.kind;
+        atom[s] = im.atom;
     }
     if (int rc = upload(&p->d_images, xyzq.data(), xyzq.size())) return rc;
     if (int rc = upload(&p->d_imgkind, kind.data(), kind.size())) return rc;
+    if (int rc = upload(&p->d_imgatom, atom.data(), atom.size())) return rc;
     if (int rc = upload(&p->d_binstart, start.data(), start.size())) return rc;
     ImageBins& ib = p->ib;
     ib.xyzq = p->d_images;
     ib.kind = p->has_rules ? p->d_imgkind : nullptr;
+    ib.atom = p->d_imgatom;
+    ib.atoms = p->d_atoms;
     ib.bin_start = p->d_binstart;
     for (int a = 0; a < 3; ++a) {
         ib.lo[a] = lo[a];
@@ -387,6 +394,7 @@ extern "C" int ceg_plan_destroy(ceg_plan_t* p)
     (void)hipFree(p->d_offset);
     (void)hipFree(p->d_images);
     (void)hipFree(p->d_imgkind);
+    (void)hipFree(p->d_imgatom);
     (void)hipFree(p->d_binstart);
     delete p;
     return CEG_OK;

@@ -80,6 +80,8 @@ struct RuleTable {
 struct ImageBins {
     const double4* xyzq;    // image position (atom + lattice vector), charge
     const int32_t* kind;    // 0-based kind, -1 when the plan has no rules
+    const int32_t* atom;    // index of the ProbeSystem atom this image belongs to
+    const double4* atoms;   // the ProbeSystem atoms themselves (exact path for very close pairs)
     const int32_t* bin_start; // [nbx*nby*nbz + 1], bins ordered (bx, by, bz) with bz fastest
     double lo[3];           // lower corner of the binned region
     double inv_bin[3];      // 1 / bin edge

@@ -181,6 +181,9 @@ __device__ __forceinline__ void write_results(const Geom& g, const Output& out, 
 // the image vector the reference leaves in `buffer` (stale on the fall-through path).
 __device__ __forceinline__ double periodic_distance2_literal(const Geom& g, double& dx, double& dy, double& dz)
 {
+    // same operation sequence as the Julia source (StaticArrays mat-vec = plain mul/add, no FMA):
+    // components the reference's wrap arithmetic makes exactly zero stay exactly zero
+#pragma clang fp contract(off)
     const double* M = g.mat;
     const double* I = g.invmat;
     double f0 = I[0] * dx + I[3] * dy + I[6] * dz;
@@ -336,6 +339,8 @@ __device__ __forceinline__ double wave_max(double x)
     return x;
 }
 
+// pairs closer than this (A^2) take the literal min-image arithmetic in the culled kernel
+constexpr double R_EXACT2 = 4.0;
 constexpr int META_SIMPLE = 1 << 24;
 constexpr int META_KINDMASK = (1 << 24) - 1;
 
@@ -345,6 +350,7 @@ __global__ __launch_bounds__(64) void k_culled(Geom g, ImageBins ib, RuleTable r
 {
     __shared__ double4 s_cand[64];
     __shared__ int32_t s_meta[64];
+    __shared__ int32_t s_atom[64];
     __shared__ int32_t s_rowstart[64];
     __shared__ int32_t s_rowprefix[65];
 
@@ -407,6 +413,9 @@ __global__ __launch_bounds__(64) void k_culled(Geom g, ImageBins ib, RuleTable r
     accum_zero(av);
     accum_zero(ac);
     double smallest_d2 = __builtin_huge_val();
+    // widths of the "decide with the reference's arithmetic" bands (negative = band unused)
+    const double band_cut = 1e-9 * g.cutoff2;
+    const double band_safe = (g.ortho || g.safemin2 > g.cutoff2 * (1.0 + 1e-8)) ? -1.0 : 1e-9 * g.safemin2;
 
     for (int rbase = 0; rbase < nrows; rbase += 64) {
         // -- one row per lane: image range [start, start+count)
@@ -446,7 +455,7 @@ __global__ __launch_bounds__(64) void k_culled(Geom g, ImageBins ib, RuleTable r
             const int t = cbase + lane;
             bool keep = false;
             double4 P = make_double4(0, 0, 0, 0);
-            int meta = 0;
+            int meta = 0, aidx = 0;
             if (t < total) {
                 int lo = 0, hi = 64;           // largest lo with prefix[lo] <= t
 #pragma unroll
@@ -456,6 +465,7 @@ __global__ __launch_bounds__(64) void k_culled(Geom g, ImageBins ib, RuleTable r
                 }
                 const int img = s_rowstart[lo] + (t - s_rowprefix[lo]);
                 P = ib.xyzq[img];
+                aidx = ib.atom[img];
                 const int kd = ib.kind ? ib.kind[img] : -1;
                 const double qx = fmax(0.0, fabs(cx - P.x) - hx);
                 const double qy = fmax(0.0, fabs(cy - P.y) - hy);
@@ -481,6 +491,7 @@ __global__ __launch_bounds__(64) void k_culled(Geom g, ImageBins ib, RuleTable r
                                                            __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
                 s_cand[slot] = P;
                 s_meta[slot] = meta;
+                s_atom[slot] = aidx;
             }
             __syncthreads();
 
@@ -489,9 +500,21 @@ __global__ __launch_bounds__(64) void k_culled(Geom g, ImageBins ib, RuleTable r
                 const double4 A = s_cand[q];
                 const int mt = __builtin_amdgcn_readfirstlane(s_meta[q]);
                 double dx = px - A.x, dy = py - A.y, dz = pz - A.z;
-                const double r2 = dx * dx + dy * dy + dz * dz;
+                double r2 = dx * dx + dy * dy + dz * dz;
                 bool in = r2 < g.cutoff2;
-                if (mt & META_SIMPLE) {
+                if (r2 < R_EXACT2 || fabs(r2 - g.cutoff2) <= band_cut || fabs(r2 - g.safemin2) <= band_safe) {
+                    // (1) Very close pair: the radial factors are astronomically large (LJ ~ r^-14), so
+                    // a one-ulp difference in a component of d that the reference's wrap arithmetic
+                    // makes exactly zero would be amplified into the result.  (2) Pair within 1e-9 of
+                    // a decision threshold (cutoff, safemin): the decision must be taken on the
+                    // reference's own rounding of d2 (truncated potentials jump at the cutoff).
+                    // Redo such pairs exactly like the reference: original atom position, invmat*d,
+                    // wrap, mat*f (src/utils.jl:210-246).  ~0.5 % of the in-cutoff pairs.
+                    const double4 O = ib.atoms[s_atom[q]];
+                    dx = px - O.x; dy = py - O.y; dz = pz - O.z;
+                    r2 = periodic_distance2_literal(g, dx, dy, dz);
+                    in = r2 < g.cutoff2;
+                } else if (mt & META_SIMPLE) {
                     // wrapped image for the whole tile: returned as is, except for the
                     // stale-vector fall-through when safemin2 < r2 (src/utils.jl:233-245)
                     if (!g.ortho && r2 > g.safemin2) { dx -= g.mat[6]; dy -= g.mat[7]; dz -= g.mat[8]; }

@@ -103,8 +103,8 @@ def _check_all(plan, pv, pc, alpha, cset, oracle, what, algos=(BRUTE, CULLED)):
     ("orthorhombic", (25.0, 27.0, 30.0), (90.0, 90.0, 90.0)),        # diagonal matrix: wrapped == nearest
     ("near-ortho", (26.0, 26.0, 26.0), (91.5, 88.6, 90.9)),          # ortho flag true, images dropped like the reference
     ("triclinic", (27.0, 29.0, 33.0), (94.07, 100.0, 85.0)),
-    ("skewed-60", (36.0, 36.0, 36.0), (60.0, 60.0, 60.0)),            # safemin2 < cutoff2: stale-vector branch is live
-    ("skewed-mixed", (34.0, 40.0, 38.0), (62.0, 115.0, 70.0)),
+    ("skewed-60", (31.0, 31.0, 31.0), (60.0, 60.0, 60.0)),            # safemin2 < cutoff2: stale-vector branch is live
+    ("skewed-mixed", (30.0, 33.0, 36.0), (65.0, 110.0, 75.0)),
 ])
 def test_cells_and_min_image_branches(hip_lib, oracle, name, lengths, angles):
     mat = mat_from_parameters(lengths, angles)
