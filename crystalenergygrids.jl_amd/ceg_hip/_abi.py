@@ -83,7 +83,7 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = Path(path) if path is not None else LIB_PATH
+    p = Path(path) if path is not None else Path(os.environ.get("CEG_HIP_LIB", LIB_PATH))
     if not p.exists():
         raise ImportError(
             f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -76,6 +76,9 @@ struct ceg_plan {
     int32_t* d_binstart = nullptr;
     ImageBins ib{};
     bool images_built = false;
+    PlanConst* d_pc = nullptr;   // device copy of {g, ib, rt}
+    bool lj_only = false;        // every kind present has <= 1 rule and it is Lennard-Jones
+    bool fast_ewald = false;     // alpha*cutoff within the erfcx polynomial's domain
 };
 
 namespace {
@@ -167,6 +170,12 @@ int convert_rules(ceg_plan* p, const ceg_rule_t* rules, const int32_t* rule_offs
     }
     p->h_offset[nkinds] = (int32_t)p->h_rules.size();
     p->nkinds = nkinds;
+    p->lj_only = true;
+    for (int32_t k = 0; k < nkinds; ++k) {
+        if (!present[k]) continue;
+        const int32_t n = p->h_offset[k + 1] - p->h_offset[k];
+        if (n > 1 || (n == 1 && p->h_rules[p->h_offset[k]].kind != CEG_LENNARDJONES)) p->lj_only = false;
+    }
     return CEG_OK;
 }
 
@@ -376,6 +385,14 @@ extern "C" int ceg_plan_create(ceg_plan_t** plan, int32_t device,
         rc = upload(&p->d_offset, p->h_offset.data(), p->h_offset.size());
     }
     if (!rc && p->can_cull) rc = build_images(p);
+    if (!rc && p->can_cull) {
+        PlanConst hc{};
+        hc.g = p->g;
+        hc.ib = p->ib;
+        hc.rt = RuleTable{p->d_rules, p->d_offset, p->nkinds};
+        rc = upload(&p->d_pc, &hc, 1);
+        p->fast_ewald = std::isfinite(alpha) && alpha >= 0 && alpha * std::sqrt(cutoff2) <= CEG_ERFCX_XMAX * (1.0 - 1e-9);
+    }
     if (rc) {
         ceg_plan_destroy(p);
         return rc;
@@ -396,6 +413,7 @@ extern "C" int ceg_plan_destroy(ceg_plan_t* p)
     (void)hipFree(p->d_imgkind);
     (void)hipFree(p->d_imgatom);
     (void)hipFree(p->d_binstart);
+    (void)hipFree(p->d_pc);
     delete p;
     return CEG_OK;
 }
@@ -428,7 +446,7 @@ int run(ceg_plan* p, int mode, const Output& out, const Points& pts, bool culled
     RuleTable rt{p->d_rules, p->d_offset, p->nkinds};
     hipError_t e;
     if (culled) {
-        e = launch_culled(mode, p->g, p->ib, rt, out, pts, stream);
+        e = launch_culled(mode, p->d_pc, p->g, p->lj_only, p->fast_ewald, out, pts, stream);
     } else {
         AtomTable at{p->d_atoms, p->has_rules ? p->d_kind : nullptr, p->natoms};
         e = launch_bruteforce(mode, p->g, at, rt, out, pts, stream);

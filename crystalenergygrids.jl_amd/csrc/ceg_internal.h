@@ -90,10 +90,21 @@ struct ImageBins {
     int32_t nimages;
 };
 
+// Plan constants resident in device memory (uploaded once per plan): the culled kernel reads
+// them through a pointer so that only what the hot loop needs lives in scalar registers.
+struct PlanConst {
+    Geom g;
+    ImageBins ib;
+    RuleTable rt;
+};
+
+// largest alpha*r for which the fast erfcx polynomial (ceg_math.h) is valid
+constexpr double CEG_ERFCX_XMAX = 5.0;
+
 // launchers (ceg_kernels.hip)
 hipError_t launch_bruteforce(int mode, const Geom& g, const AtomTable& atoms, const RuleTable& rt,
                              const Output& out, const Points& pts, hipStream_t stream);
-hipError_t launch_culled(int mode, const Geom& g, const ImageBins& ib, const RuleTable& rt,
+hipError_t launch_culled(int mode, const PlanConst* d_pc, const Geom& g, bool ljonly, bool fastew,
                          const Output& out, const Points& pts, hipStream_t stream);
 
 }  // namespace ceg

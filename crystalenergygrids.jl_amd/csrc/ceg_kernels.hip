@@ -27,6 +27,7 @@
 //
 // No MFMA: this is a pairwise FP64 reduction, bound by the FP64 vector ALU.
 #include "ceg_internal.h"
+#include "ceg_math.h"
 
 namespace ceg {
 
@@ -110,6 +111,27 @@ __device__ __forceinline__ void ewald_terms(double alpha, double charge, double 
     const double r2a2 = r2 * (alpha * alpha);
     const double er2a2 = 2.0 * alpha * r * exp(-r2a2) * inv_sqrtpi;
     const double erfar = erfc(alpha * r);
+    v = charge * erfar / r;
+    p1 = -charge * (er2a2 + erfar) / r3;
+    p2 = charge * (er2a2 * (3.0 + 2.0 * r2a2) + 3.0 * erfar) / r5;
+    p3 = charge * (-er2a2 * (15.0 + 10.0 * r2a2 + 4.0 * (r2a2 * r2a2)) - 15.0 * erfar) / (r5 * r2);
+}
+
+// derivatives_ewald with the literal operation order of src/ewald.jl:299-312 (IEEE sqrt and
+// divisions, so r -> 0 behaves like the reference) but exp / erfc from ceg_math.h; valid for
+// alpha*r <= ERFCX_XMAX.  Used for the few pairs the culled kernel redoes with the reference's
+// arithmetic: keeps libm's register-hungry erfc out of that kernel.
+__device__ __forceinline__ void ewald_terms_poly(double alpha, double charge, double r2,
+                                                 double& v, double& p1, double& p2, double& p3)
+{
+    const double inv_sqrtpi = 0.56418958354775628695;
+    const double r = sqrt(r2);
+    const double r3 = r2 * r;
+    const double r5 = r3 * r2;
+    const double r2a2 = r2 * (alpha * alpha);
+    const double E = fast_exp_neg(-r2a2);
+    const double er2a2 = 2.0 * alpha * r * E * inv_sqrtpi;
+    const double erfar = E * erfcx_poly(alpha * r);
     v = charge * erfar / r;
     p1 = -charge * (er2a2 + erfar) / r3;
     p2 = charge * (er2a2 * (3.0 + 2.0 * r2a2) + 3.0 * erfar) / r5;
@@ -284,46 +306,53 @@ __global__ __launch_bounds__(256) void k_bruteforce(Geom g, AtomTable atoms, Rul
     if (valid) write_results<MODE>(g, out, POINTS, t, i, j, k, av, ac, smallest_d2);
 }
 
+#ifndef CEG_WAVES
+#define CEG_WAVES 4
+#endif
+// pairs closer than this (A^2) take the literal min-image arithmetic in the culled kernel
+constexpr double R_EXACT2 = 4.0;
+constexpr int META_SIMPLE = 1 << 24;      // image is the wrapped one for every point of the tile
+constexpr int META_HASVDW = 1 << 25;      // the atom's kind has at least one VdW rule
+constexpr int META_KINDMASK = (1 << 24) - 1;
+
 // ------------------------------------------------------------------ culled kernel
-// Is image P (d = pos - P, |d|^2 = r2 < cutoff2, hence the unique nearest image) the one
-// periodic_distance2! (src/utils.jl:226-246) returns for this pair?  On true, d is what the
-// reference leaves in `buffer`.
-__device__ __forceinline__ bool select_image(const Geom& g, double& dx, double& dy, double& dz, double r2)
+// Pairs the hot loop of k_culled sets aside (bit q of `slow` = candidate q of the current LDS
+// chunk): very close pairs, pairs within 1e-9 of a decision threshold, images that are not
+// provably the wrapped one.  Each is recomputed exactly like the reference does it -- original
+// atom position, invmat*d, wrap, mat*f, neighbour search (periodic_distance2_literal) -- and
+// evaluated with libm-grade radial functions.  Kept out of line so its registers do not weigh on
+// the hot loop.
+template <int MODE, bool FASTEW>
+__device__ __forceinline__ void slow_pairs(const PlanConst* __restrict__ pc, unsigned long long slow,
+                                        double px, double py, double pz,
+                                        const double4* s_cand, const int32_t* s_meta, const int32_t* s_atom,
+                                        Accum& av, Accum& ac, double& smallest_d2)
 {
-    const double* M = g.mat;
-    const double* I = g.invmat;
-    const double gx = I[0] * dx + I[3] * dy + I[6] * dz;
-    const double gy = I[1] * dx + I[4] * dy + I[7] * dz;
-    const double gz = I[2] * dx + I[5] * dy + I[8] * dz;
-    const double mx = floor(gx + 0.5), my = floor(gy + 0.5), mz = floor(gz + 0.5);
-    if (mx == 0.0 && my == 0.0 && mz == 0.0) {
-        // P is the wrapped image.  Returned directly if ortho or within safemin; otherwise the
-        // neighbour search finds nothing closer (all other images are >= cutoff away) and
-        // falls through with buffer = wrapped - c.
-        if (!g.ortho && r2 > g.safemin2) { dx -= M[6]; dy -= M[7]; dz -= M[8]; }
-        return true;
+    const Geom& g = pc->g;
+    while (slow != 0ull) {
+        const int q = __builtin_ctzll(slow);
+        slow &= slow - 1ull;
+        const int mt = s_meta[q];
+        const double4 O = pc->ib.atoms[s_atom[q]];
+        double dx = px - O.x, dy = py - O.y, dz = pz - O.z;
+        const double r2 = periodic_distance2_literal(g, dx, dy, dz);
+        if (r2 >= g.cutoff2) continue;
+        if (MODE != MODE_COULOMB && (mt & META_HASVDW)) {
+            const int kd = mt & META_KINDMASK;
+            double v, p1, p2, p3;
+            vdw_terms(pc->rt.rules, pc->rt.offset[kd], pc->rt.offset[kd + 1], r2, v, p1, p2, p3);
+            accum_add(av, v, p1, p2, p3, dx, dy, dz);
+        }
+        if (MODE != MODE_VDW) {
+            smallest_d2 = fmin(smallest_d2, r2);
+            double v, p1, p2, p3;
+            if (FASTEW)
+                ewald_terms_poly(g.alpha, O.w, r2, v, p1, p2, p3);
+            else
+                ewald_terms(g.alpha, O.w, r2, v, p1, p2, p3);
+            accum_add(ac, v, p1, p2, p3, dx, dy, dz);
+        }
     }
-    if (g.ortho) return false;           // the wrapped image (out of cutoff) is returned
-    const double vx = dx - (M[0] * mx + M[3] * my + M[6] * mz);
-    const double vy = dy - (M[1] * mx + M[4] * my + M[7] * mz);
-    const double vz = dz - (M[2] * mx + M[5] * my + M[8] * mz);
-    const double ref2 = vx * vx + vy * vy + vz * vz;
-    if (ref2 <= g.safemin2) return false;
-#pragma unroll
-    for (int ax = 0; ax < 3; ++ax) {
-        const double cx = M[3 * ax], cy = M[3 * ax + 1], cz = M[3 * ax + 2];
-        const double m_ax = (ax == 0) ? mx : ((ax == 1) ? my : mz);
-        const double m_o1 = (ax == 0) ? my : mx;
-        const double m_o2 = (ax == 2) ? my : mz;
-        const bool others_zero = (m_o1 == 0.0) && (m_o2 == 0.0);
-        double ex = vx + cx, ey = vy + cy, ez = vz + cz;
-        double n2 = ex * ex + ey * ey + ez * ez;
-        if (n2 < ref2) return others_zero && (m_ax == 1.0);
-        ex = vx - cx; ey = vy - cy; ez = vz - cz;
-        n2 = ex * ex + ey * ey + ez * ez;
-        if (n2 < ref2) return others_zero && (m_ax == -1.0);
-    }
-    return false;                        // fall-through returns |wrapped|^2 >= cutoff2
 }
 
 __device__ __forceinline__ double wave_min(double x)
@@ -339,22 +368,32 @@ __device__ __forceinline__ double wave_max(double x)
     return x;
 }
 
-// pairs closer than this (A^2) take the literal min-image arithmetic in the culled kernel
-constexpr double R_EXACT2 = 4.0;
-constexpr int META_SIMPLE = 1 << 24;
-constexpr int META_KINDMASK = (1 << 24) - 1;
-
-template <int MODE, bool POINTS>
-__global__ __launch_bounds__(64) void k_culled(Geom g, ImageBins ib, RuleTable rt, Output out, Points pts,
+// Template flags of k_culled
+//   MODE    what is accumulated (VdW / Coulomb / both in one pass)
+//   POINTS  arbitrary point list (eval_points) instead of 4x4x4 grid tiles
+//   LJONLY  every kind present has at most one rule and it is Lennard-Jones: eps, sigma^2, shift
+//           travel with the candidate through LDS and the pair term uses the shared 1/r
+//   FASTEW  alpha*cutoff <= ERFCX_XMAX: real-space Ewald term from ceg_math.h (one exp, erfcx
+//           polynomial, no division); otherwise libm-style erfc/exp
+template <int MODE, bool POINTS, bool LJONLY, bool FASTEW>
+__global__ __launch_bounds__(64, CEG_WAVES) void k_culled(const PlanConst* __restrict__ pc, Output out, Points pts,
                                                 int tiles_j, int tiles_k)
 {
     __shared__ double4 s_cand[64];
+    __shared__ double4 s_lj[64];
     __shared__ int32_t s_meta[64];
     __shared__ int32_t s_atom[64];
     __shared__ int32_t s_rowstart[64];
     __shared__ int32_t s_rowprefix[65];
 
+    const Geom& g = pc->g;
+    const ImageBins& ib = pc->ib;
+    const RuleTable& rt = pc->rt;
     const int lane = threadIdx.x;
+    const double cutoff2 = g.cutoff2;
+    const double alpha = g.alpha;
+    const int32_t ortho = g.ortho;
+    const double safemin2 = g.safemin2;
 
     // ---- this lane's point
     int i = 0, j = 0, k = 0;
@@ -390,13 +429,8 @@ __global__ __launch_bounds__(64) void k_culled(Geom g, ImageBins ib, RuleTable r
     const double cx = 0.5 * (blx + bhx), cy = 0.5 * (bly + bhy), cz = 0.5 * (blz + bhz);
     const double hx = 0.5 * (bhx - blx), hy = 0.5 * (bhy - bly), hz = 0.5 * (bhz - blz);
     // cutoff with a rounding margin: anything a lane can see with r2 < cutoff2 is kept
-    const double rc2 = g.cutoff2 * (1.0 + 1e-9) + 1e-9;
+    const double rc2 = cutoff2 * (1.0 + 1e-9) + 1e-9;
     const double rc = sqrt(rc2);
-    // fractional half-extent of the tile box (+ margin), for the "always the wrapped image" test
-    const double* I = g.invmat;
-    const double e0 = fabs(I[0]) * hx + fabs(I[3]) * hy + fabs(I[6]) * hz + 1e-9;
-    const double e1 = fabs(I[1]) * hx + fabs(I[4]) * hy + fabs(I[7]) * hz + 1e-9;
-    const double e2 = fabs(I[2]) * hx + fabs(I[5]) * hy + fabs(I[8]) * hz + 1e-9;
 
     // ---- bin rows (bx, by) intersecting the neighbourhood
     auto bin_of = [&](double x, int ax) -> int {
@@ -406,16 +440,18 @@ __global__ __launch_bounds__(64) void k_culled(Geom g, ImageBins ib, RuleTable r
     };
     const int bx0 = bin_of(blx - rc, 0), bx1 = bin_of(bhx + rc, 0);
     const int by0 = bin_of(bly - rc, 1), by1 = bin_of(bhy + rc, 1);
-    const int nrx = bx1 - bx0 + 1, nry = by1 - by0 + 1;
-    const int nrows = nrx * nry;
+    const int nry = by1 - by0 + 1;
+    const int nrows = (bx1 - bx0 + 1) * nry;
 
     Accum av, ac;
     accum_zero(av);
     accum_zero(ac);
     double smallest_d2 = __builtin_huge_val();
     // widths of the "decide with the reference's arithmetic" bands (negative = band unused)
-    const double band_cut = 1e-9 * g.cutoff2;
-    const double band_safe = (g.ortho || g.safemin2 > g.cutoff2 * (1.0 + 1e-8)) ? -1.0 : 1e-9 * g.safemin2;
+    const double band_cut = 1e-9 * cutoff2;
+    const double band_safe = (ortho || safemin2 > cutoff2 * (1.0 + 1e-8)) ? -1.0 : 1e-9 * safemin2;
+    const double alpha2 = alpha * alpha;
+    const bool stale_possible = !ortho && safemin2 < cutoff2;
 
     for (int rbase = 0; rbase < nrows; rbase += 64) {
         // -- one row per lane: image range [start, start+count)
@@ -455,6 +491,7 @@ __global__ __launch_bounds__(64) void k_culled(Geom g, ImageBins ib, RuleTable r
             const int t = cbase + lane;
             bool keep = false;
             double4 P = make_double4(0, 0, 0, 0);
+            double4 LJ = make_double4(0, 0, 0, 0);
             int meta = 0, aidx = 0;
             if (t < total) {
                 int lo = 0, hi = 64;           // largest lo with prefix[lo] <= t
@@ -471,17 +508,30 @@ __global__ __launch_bounds__(64) void k_culled(Geom g, ImageBins ib, RuleTable r
                 const double qy = fmax(0.0, fabs(cy - P.y) - hy);
                 const double qz = fmax(0.0, fabs(cz - P.z) - hz);
                 keep = (qx * qx + qy * qy + qz * qz) < rc2;
-                if (MODE == MODE_VDW)          // kinds without a rule contribute exact zeros
-                    keep = keep && (kd >= 0) && (rt.offset[kd + 1] > rt.offset[kd]);
+                bool hasvdw = false;
+                if (MODE != MODE_COULOMB && kd >= 0) {
+                    const int rb = rt.offset[kd];
+                    hasvdw = rt.offset[kd + 1] > rb;
+                    if (LJONLY && hasvdw && keep) {
+                        const DevRule R = rt.rules[rb];
+                        LJ = make_double4(R.p0, R.p1, R.shift, 0.0);
+                    }
+                }
+                if (MODE == MODE_VDW) keep = keep && hasvdw;   // kinds without a rule contribute exact zeros
                 bool simple = g.diag != 0;
-                if (!simple) {
+                if (!simple && keep) {
+                    const double* I = g.invmat;
                     const double ux = cx - P.x, uy = cy - P.y, uz = cz - P.z;
                     const double f0 = I[0] * ux + I[3] * uy + I[6] * uz;
                     const double f1 = I[1] * ux + I[4] * uy + I[7] * uz;
                     const double f2 = I[2] * ux + I[5] * uy + I[8] * uz;
+                    // fractional half-extent of the tile box (+ margin)
+                    const double e0 = fabs(I[0]) * hx + fabs(I[3]) * hy + fabs(I[6]) * hz + 1e-9;
+                    const double e1 = fabs(I[1]) * hx + fabs(I[4]) * hy + fabs(I[7]) * hz + 1e-9;
+                    const double e2 = fabs(I[2]) * hx + fabs(I[5]) * hy + fabs(I[8]) * hz + 1e-9;
                     simple = (fabs(f0) + e0 < 0.5) && (fabs(f1) + e1 < 0.5) && (fabs(f2) + e2 < 0.5);
                 }
-                meta = (kd & META_KINDMASK) | (simple ? META_SIMPLE : 0);
+                meta = (kd & META_KINDMASK) | (simple ? META_SIMPLE : 0) | (hasvdw ? META_HASVDW : 0);
             }
             const unsigned long long mask = __ballot(keep);
             const int nkeep = __popcll(mask);
@@ -490,56 +540,104 @@ __global__ __launch_bounds__(64) void k_culled(Geom g, ImageBins ib, RuleTable r
                 const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                                            __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
                 s_cand[slot] = P;
+                if (LJONLY && MODE != MODE_COULOMB) s_lj[slot] = LJ;
                 s_meta[slot] = meta;
                 s_atom[slot] = aidx;
             }
             __syncthreads();
 
-            // -- every lane against every kept image (LDS broadcast reads)
+            // -- every lane against every kept image (LDS broadcast reads).  The hot loop only
+            //    handles the regular case -- the image is the wrapped one for the whole tile, the
+            //    pair is between R_EXACT and the cutoff and away from every decision threshold.
+            //    Anything else is recorded in a per-lane bit mask and redone after the loop with
+            //    the reference's literal arithmetic (slow_pairs).
+            unsigned long long slow = 0ull;
             for (int q = 0; q < nkeep; ++q) {
                 const double4 A = s_cand[q];
                 const int mt = __builtin_amdgcn_readfirstlane(s_meta[q]);
                 double dx = px - A.x, dy = py - A.y, dz = pz - A.z;
-                double r2 = dx * dx + dy * dy + dz * dz;
-                bool in = r2 < g.cutoff2;
-                if (r2 < R_EXACT2 || fabs(r2 - g.cutoff2) <= band_cut || fabs(r2 - g.safemin2) <= band_safe) {
-                    // (1) Very close pair: the radial factors are astronomically large (LJ ~ r^-14), so
-                    // a one-ulp difference in a component of d that the reference's wrap arithmetic
-                    // makes exactly zero would be amplified into the result.  (2) Pair within 1e-9 of
-                    // a decision threshold (cutoff, safemin): the decision must be taken on the
-                    // reference's own rounding of d2 (truncated potentials jump at the cutoff).
-                    // Redo such pairs exactly like the reference: original atom position, invmat*d,
-                    // wrap, mat*f (src/utils.jl:210-246).  ~0.5 % of the in-cutoff pairs.
-                    const double4 O = ib.atoms[s_atom[q]];
-                    dx = px - O.x; dy = py - O.y; dz = pz - O.z;
-                    r2 = periodic_distance2_literal(g, dx, dy, dz);
-                    in = r2 < g.cutoff2;
-                } else if (mt & META_SIMPLE) {
-                    // wrapped image for the whole tile: returned as is, except for the
-                    // stale-vector fall-through when safemin2 < r2 (src/utils.jl:233-245)
-                    if (!g.ortho && r2 > g.safemin2) { dx -= g.mat[6]; dy -= g.mat[7]; dz -= g.mat[8]; }
-                } else if (in) {
-                    in = select_image(g, dx, dy, dz, r2);
+                const double r2 = dx * dx + dy * dy + dz * dz;
+                bool in = r2 < cutoff2;
+                const bool odd = (r2 < R_EXACT2) || (fabs(r2 - cutoff2) <= band_cut) ||
+                                 (in && (!(mt & META_SIMPLE) || fabs(r2 - safemin2) <= band_safe));
+                if (odd) {
+                    slow |= 1ull << q;
+                    in = false;
                 }
                 if (!in) continue;
-                if (MODE != MODE_COULOMB) {
-                    int kd = mt & META_KINDMASK;
-                    if (kd != META_KINDMASK) {
-                        const int rb = rt.offset[kd], re = rt.offset[kd + 1];
-                        if (re > rb) {
-                            double v, p1, p2, p3;
-                            vdw_terms(rt.rules, rb, re, r2, v, p1, p2, p3);
-                            accum_add(av, v, p1, p2, p3, dx, dy, dz);
-                        }
+                if (stale_possible && r2 > safemin2) {
+                    // wrapped image beyond safemin: the reference's neighbour search finds nothing
+                    // closer and leaves buffer = wrapped - c (src/utils.jl:233-245)
+                    dx -= g.mat[6]; dy -= g.mat[7]; dz -= g.mat[8];
+                }
+
+                // ---- regular pair: 2 A <= r < cutoff
+                const double dxy = dx * dy, dxz = dx * dz, dyz = dy * dz;
+                const double dxyz = dxz * dy;
+                double rr = 0.0, rinv = 0.0, inv = 0.0;
+                if (LJONLY || (FASTEW && MODE != MODE_VDW)) {
+                    fast_sqrt_rsqrt(r2, rr, rinv);
+                    inv = rinv * rinv;
+                }
+                if (MODE != MODE_COULOMB && (mt & META_HASVDW)) {
+                    double v, p1, p2, p3;
+                    if (LJONLY) {
+                        // derivativesGrid, LJ branch (src/interactions.jl:434-441), with 1/r2 shared
+                        const double4 L = s_lj[q];             // eps, sigma^2, shift
+                        const double sx = L.y * inv;
+                        const double x6 = sx * sx * sx;
+                        const double a = L.x * x6;
+                        const double inv2 = inv * inv;
+                        v = __builtin_fma(4.0 * a, x6 - 1.0, -L.z);
+                        p1 = 24.0 * a * __builtin_fma(-2.0, x6, 1.0) * inv;
+                        p2 = 96.0 * a * __builtin_fma(7.0, x6, -2.0) * inv2;
+                        p3 = 384.0 * a * __builtin_fma(-28.0, x6, 5.0) * (inv2 * inv2);
+                    } else {
+                        const int kd = mt & META_KINDMASK;
+                        vdw_terms(rt.rules, rt.offset[kd], rt.offset[kd + 1], r2, v, p1, p2, p3);
                     }
+                    av.v += v;
+                    av.d1x = __builtin_fma(p1, dx, av.d1x);
+                    av.d1y = __builtin_fma(p1, dy, av.d1y);
+                    av.d1z = __builtin_fma(p1, dz, av.d1z);
+                    av.d2xy = __builtin_fma(p2, dxy, av.d2xy);
+                    av.d2xz = __builtin_fma(p2, dxz, av.d2xz);
+                    av.d2yz = __builtin_fma(p2, dyz, av.d2yz);
+                    av.d3 = __builtin_fma(p3, dxyz, av.d3);
                 }
                 if (MODE != MODE_VDW) {
-                    smallest_d2 = fmin(smallest_d2, r2);
+                    smallest_d2 = min_nonan(smallest_d2, r2);
                     double v, p1, p2, p3;
-                    ewald_terms(g.alpha, A.w, r2, v, p1, p2, p3);
-                    accum_add(ac, v, p1, p2, p3, dx, dy, dz);
+                    if (FASTEW) {
+                        // derivatives_ewald (src/ewald.jl:299-312): erfc(x) = exp(-x^2) erfcx(x)
+                        const double two_over_sqrtpi = 1.1283791670955125739;
+                        const double x = alpha * rr;
+                        const double x2 = alpha2 * r2;
+                        const double E = fast_exp_neg(-x2);
+                        const double c = E * erfcx_poly(x);              // erfc(alpha r)
+                        const double e = two_over_sqrtpi * x * E;        // 2 alpha r exp(-alpha^2 r^2)/sqrt(pi)
+                        const double q1 = A.w * rinv;                    // q / r
+                        const double q3 = q1 * inv, q5 = q3 * inv, q7 = q5 * inv;
+                        v = q1 * c;
+                        p1 = -q3 * (e + c);
+                        p2 = q5 * __builtin_fma(e, __builtin_fma(2.0, x2, 3.0), 3.0 * c);
+                        p3 = -q7 * __builtin_fma(e, __builtin_fma(x2, __builtin_fma(4.0, x2, 10.0), 15.0), 15.0 * c);
+                    } else {
+                        ewald_terms(alpha, A.w, r2, v, p1, p2, p3);
+                    }
+                    ac.v += v;
+                    ac.d1x = __builtin_fma(p1, dx, ac.d1x);
+                    ac.d1y = __builtin_fma(p1, dy, ac.d1y);
+                    ac.d1z = __builtin_fma(p1, dz, ac.d1z);
+                    ac.d2xy = __builtin_fma(p2, dxy, ac.d2xy);
+                    ac.d2xz = __builtin_fma(p2, dxz, ac.d2xz);
+                    ac.d2yz = __builtin_fma(p2, dyz, ac.d2yz);
+                    ac.d3 = __builtin_fma(p3, dxyz, ac.d3);
                 }
             }
+            // -- the pairs set aside above, one per lane per round
+            if (__any(slow != 0ull))
+                slow_pairs<MODE, FASTEW>(pc, slow, px, py, pz, s_cand, s_meta, s_atom, av, ac, smallest_d2);
         }
     }
     if (valid) write_results<MODE>(g, out, POINTS, pidx, i, j, k, av, ac, smallest_d2);
@@ -576,35 +674,45 @@ hipError_t launch_bruteforce(int mode, const Geom& g, const AtomTable& atoms, co
     return launch_bf_t<false>(mode, g, atoms, rt, out, pts, total, stream);
 }
 
+template <int MODE, bool POINTS>
+static void launch_cull_flags(bool ljonly, bool fastew, dim3 grid, dim3 block, hipStream_t stream,
+                              const PlanConst* pc, const Output& out, const Points& pts, int tj, int tk)
+{
+    // flags that do not matter for a mode are normalised so fewer variants get instantiated
+    if (MODE == MODE_VDW) fastew = true;
+    if (MODE == MODE_COULOMB) ljonly = true;
+    if (ljonly && fastew)
+        hipLaunchKernelGGL((k_culled<MODE, POINTS, true, true>), grid, block, 0, stream, pc, out, pts, tj, tk);
+    else if (ljonly)
+        hipLaunchKernelGGL((k_culled<MODE, POINTS, true, false>), grid, block, 0, stream, pc, out, pts, tj, tk);
+    else if (fastew)
+        hipLaunchKernelGGL((k_culled<MODE, POINTS, false, true>), grid, block, 0, stream, pc, out, pts, tj, tk);
+    else
+        hipLaunchKernelGGL((k_culled<MODE, POINTS, false, false>), grid, block, 0, stream, pc, out, pts, tj, tk);
+}
+
 template <bool POINTS>
-static hipError_t launch_cull_t(int mode, const Geom& g, const ImageBins& ib, const RuleTable& rt,
-                                const Output& out, const Points& pts, int64_t nblocks, int tj, int tk,
-                                hipStream_t stream)
+static hipError_t launch_cull_t(int mode, const PlanConst* pc, bool ljonly, bool fastew, const Output& out,
+                                const Points& pts, int64_t nblocks, int tj, int tk, hipStream_t stream)
 {
     if (nblocks <= 0) return hipSuccess;
     if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
     dim3 grid((unsigned)nblocks), block(64);
     switch (mode) {
-    case MODE_VDW:
-        hipLaunchKernelGGL((k_culled<MODE_VDW, POINTS>), grid, block, 0, stream, g, ib, rt, out, pts, tj, tk);
-        break;
-    case MODE_COULOMB:
-        hipLaunchKernelGGL((k_culled<MODE_COULOMB, POINTS>), grid, block, 0, stream, g, ib, rt, out, pts, tj, tk);
-        break;
-    default:
-        hipLaunchKernelGGL((k_culled<MODE_FUSED, POINTS>), grid, block, 0, stream, g, ib, rt, out, pts, tj, tk);
-        break;
+    case MODE_VDW: launch_cull_flags<MODE_VDW, POINTS>(ljonly, fastew, grid, block, stream, pc, out, pts, tj, tk); break;
+    case MODE_COULOMB: launch_cull_flags<MODE_COULOMB, POINTS>(ljonly, fastew, grid, block, stream, pc, out, pts, tj, tk); break;
+    default: launch_cull_flags<MODE_FUSED, POINTS>(ljonly, fastew, grid, block, stream, pc, out, pts, tj, tk); break;
     }
     return hipGetLastError();
 }
 
-hipError_t launch_culled(int mode, const Geom& g, const ImageBins& ib, const RuleTable& rt,
+hipError_t launch_culled(int mode, const PlanConst* d_pc, const Geom& g, bool ljonly, bool fastew,
                          const Output& out, const Points& pts, hipStream_t stream)
 {
-    if (pts.xyz) return launch_cull_t<true>(mode, g, ib, rt, out, pts, (pts.n + 63) / 64, 1, 1, stream);
+    if (pts.xyz) return launch_cull_t<true>(mode, d_pc, ljonly, fastew, out, pts, (pts.n + 63) / 64, 1, 1, stream);
     const int ni = out.i_end - out.i_begin;
     const int ti = (ni + 3) / 4, tj = (g.dims[1] + 1 + 3) / 4, tk = (g.dims[2] + 1 + 3) / 4;
-    return launch_cull_t<false>(mode, g, ib, rt, out, pts, (int64_t)ti * tj * tk, tj, tk, stream);
+    return launch_cull_t<false>(mode, d_pc, ljonly, fastew, out, pts, (int64_t)ti * tj * tk, tj, tk, stream);
 }
 
 }  // namespace ceg
