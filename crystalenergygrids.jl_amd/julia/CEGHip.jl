@@ -1,0 +1,178 @@
+# CEGHip.jl -- reference-side binding of libceg_hip.so (include/ceg_hip.h).
+#
+# Drop-in for the two loop nests of CrystalEnergyGrids.jl that fill an energy grid:
+#
+#     create_grid_vdw      src/grids.jl:137-157   (loop nest :144-150)
+#     create_grid_coulomb  src/grids.jl:159-185   (loop nest :171-177)
+#
+# Everything else -- ProbeSystem, GridCoordinatesSetup, initialize_ewald, the unit constants,
+# `_create_grid_common` and the file layout -- is the reference's own code, called unchanged, so
+# `retrieve_or_create_grid` (src/raspa.jl:420-439), `setup_RASPA`, `setup_montecarlo`,
+# `CrystalEnergySetup` and `energy_point` keep working without modification.
+#
+# NOT EXECUTED IN THIS REPOSITORY'S CI: the build image has no Julia toolchain.  The Python
+# package `ceg_hip` is the tested twin of this file (same argument marshalling, same C calls).
+#
+# Usage (after `using CrystalEnergyGrids`):
+#     include("CEGHip.jl"); CEGHip.install!()        # overrides the two methods
+#     ENV["CEG_HIP_LIB"] = "/path/to/libceg_hip.so"   # optional, default next to this file
+#     ENV["CEG_HIP_NGPUS"] = "8"                      # optional, default 1
+module CEGHip
+
+import CrystalEnergyGrids as CEG
+using CrystalEnergyGrids: ProbeSystem, ForceField, InteractionRule, InteractionRuleSum, FF,
+                          EwaldFramework, GridCoordinatesSetup, GRID_TO_KELVIN,
+                          COULOMBIC_CONVERSION_FACTOR, TÅ
+using Unitful, UnitfulAtomic
+using AtomsBase: AbstractSystem
+using StaticArrays
+
+const LIB = Ref(get(ENV, "CEG_HIP_LIB", joinpath(@__DIR__, "..", "csrc", "libceg_hip.so")))
+ngpus() = parse(Int, get(ENV, "CEG_HIP_NGPUS", "1"))
+
+# struct ceg_rule { int32 kind; int32 _pad; double p[3]; double shift; }   (include/ceg_hip.h)
+struct CegRule
+    kind::Int32
+    _pad::Int32
+    p1::Float64
+    p2::Float64
+    p3::Float64
+    shift::Float64
+end
+
+_rules(r::InteractionRule) = (r,)
+_rules(r::InteractionRuleSum) = r.rules
+
+"Flatten `ff.interactions[:, probe]` (what `derivatives_nocutoff`, src/forcefields.jl:302-304, dispatches on)."
+function rule_table(ff::ForceField, probe::Int)
+    n = size(ff.interactions, 1)
+    flat = CegRule[]
+    offsets = Int32[0]
+    for k in 1:n
+        for r in _rules(ff.interactions[k, probe])
+            p = r.params
+            push!(flat, CegRule(Int32(Int(r.kind)), 0, get(p, 1, 0.0), get(p, 2, 0.0), get(p, 3, 0.0), r.shift))
+        end
+        push!(offsets, Int32(length(flat)))
+    end
+    flat, offsets
+end
+
+"Raise what `derivativesGrid` (src/interactions.jl:442-443,462-467) would raise for the kinds present."
+function check_rules(ff::ForceField, probe::Int, kinds)
+    for k in unique(kinds), r in _rules(ff.interactions[k, probe])
+        r.kind === FF.UndefinedInteraction && throw(CEG.UndefinedInteractionError())
+        r.kind === FF.Coulomb && error("Coulomb interactions should not be taken into account in VdW grids.")
+        r.kind === FF.Monomial && error("VdW grid not implemented for Monomial")
+        r.kind === FF.Exponential && error("VdW grid not implemented for Exponential")
+    end
+end
+
+function _check(rc::Cint)
+    rc == 0 && return
+    msg = unsafe_string(ccall((:ceg_last_error, LIB[]), Cstring, ()))
+    error("libceg_hip error $rc: $msg")
+end
+
+function _geometry(cset::GridCoordinatesSetup)
+    dims = Int32[cset.dims...]
+    size = Float64[NoUnits(x/u"Å") for x in cset.size]
+    shift = Float64[NoUnits(x/u"Å") for x in cset.shift]
+    Δ = Float64[NoUnits(x/u"Å") for x in cset.Δ]
+    dims, size, shift, Δ
+end
+
+function _flatpos(probe::ProbeSystem)
+    pos = Vector{Float64}(undef, 3*length(probe.positions))
+    for (i, p) in enumerate(probe.positions)
+        pos[3i-2] = p[1]; pos[3i-1] = p[2]; pos[3i] = p[3]
+    end
+    pos
+end
+
+"GPU replacement of the loop nest src/grids.jl:144-150; fills and returns `grid`."
+function fill_grid_vdw!(grid::Array{Cfloat,4}, probe::ProbeSystem, cset::GridCoordinatesSetup, λ, thr)
+    ff = probe.forcefield
+    check_rules(ff, probe.probe, probe.atomkinds)
+    rules, offsets = rule_table(ff, probe.probe)
+    _, ortho, safemin = CEG.prepare_periodic_distance_computations(probe.mat)   # src/utils.jl:146-155
+    cutoff2 = NoUnits(ff.cutoff^2/u"Å^2")                                          # src/probes.jl:75
+    dims, size, shift, Δ = _geometry(cset)
+    pos = _flatpos(probe)
+    kinds = Int64.(probe.atomkinds)
+    mat = Vector{Float64}(vec(probe.mat)); invmat = Vector{Float64}(vec(probe.invmat))   # column-major
+    GC.@preserve grid pos kinds mat invmat rules offsets dims size shift Δ begin
+        _check(ccall((:ceg_grid_vdw, LIB[]), Cint,
+            (Ptr{Float64}, Ptr{Int64}, Int64, Ptr{Float64}, Ptr{Float64}, Int32, Float64, Float64,
+             Ptr{CegRule}, Ptr{Int32}, Int32, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+             Float64, Float64, Ptr{Cfloat}, Int32),
+            pos, kinds, length(kinds), mat, invmat, ortho, safemin^2, cutoff2,
+            rules, offsets, length(offsets)-1, dims, size, shift, Δ, λ, thr, grid, ngpus()))
+    end
+    grid
+end
+
+"GPU replacement of the loop nest src/grids.jl:171-177."
+function fill_grid_coulomb!(grid::Array{Cfloat,4}, probe::ProbeSystem, ewald::EwaldFramework, cset::GridCoordinatesSetup, λ, thr)
+    _, ortho, safemin = CEG.prepare_periodic_distance_computations(probe.mat)
+    cutoff2 = NoUnits(probe.forcefield.cutoff^2/u"Å^2")                            # src/probes.jl:98
+    dims, size, shift, Δ = _geometry(cset)
+    pos = _flatpos(probe)
+    mat = Vector{Float64}(vec(probe.mat)); invmat = Vector{Float64}(vec(probe.invmat))
+    α = NoUnits(ewald.α*u"Å")
+    GC.@preserve grid pos mat invmat dims size shift Δ begin
+        _check(ccall((:ceg_grid_coulomb, LIB[]), Cint,
+            (Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Int32, Float64, Float64, Float64,
+             Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Float64, Float64, Ptr{Cfloat}, Int32),
+            pos, probe.charges, length(probe.charges), mat, invmat, ortho, safemin^2, cutoff2, α,
+            dims, size, shift, Δ, λ, thr, grid, ngpus()))
+    end
+    grid
+end
+
+# The two methods below are the reference's (src/grids.jl:137-185) with the `@threads` loop nest
+# replaced by one call; every other line is unchanged.
+function create_grid_vdw(file, framework::AbstractSystem{3}, forcefield::ForceField, spacing::TÅ, atom::Symbol)
+    cset, num_unitcell = CEG._setup_grid_common(framework, spacing, forcefield.cutoff)
+    grid = Array{Cfloat,4}(undef, cset.dims[3]+1, cset.dims[2]+1, cset.dims[1]+1, 8)
+    probe_vdw = ProbeSystem(framework, forcefield, atom)
+    λ⁻¹ = GRID_TO_KELVIN
+    λ = inv(λ⁻¹)
+    fill_grid_vdw!(grid, probe_vdw, cset, λ, λ⁻¹*1e7)
+    open(file, "w") do f
+        CEG._create_grid_common(f, cset, num_unitcell)
+        write(f, grid)
+        write(f, NoUnits.(cset.cell.mat./u"Å"))
+    end
+    grid
+end
+
+function create_grid_coulomb(file, framework::AbstractSystem{3}, forcefield::ForceField, spacing::TÅ, _ewald=nothing)
+    cset, num_unitcell = CEG._setup_grid_common(framework, spacing, 12.0u"Å")
+    ewald = _ewald isa EwaldFramework ? _ewald : CEG.initialize_ewald(framework, num_unitcell)
+    grid = Array{Cfloat,4}(undef, cset.dims[3]+1, cset.dims[2]+1, cset.dims[1]+1, 8)
+    probe_coulomb = ProbeSystem(framework, forcefield)
+    λ = ustrip(u"K*Å/e_au^2", COULOMBIC_CONVERSION_FACTOR)/GRID_TO_KELVIN
+    λ⁻¹e7 = inv(λ)*1e7
+    fill_grid_coulomb!(grid, probe_coulomb, ewald, cset, λ, λ⁻¹e7)
+    open(file, "w") do f
+        CEG._create_grid_common(f, cset, num_unitcell)
+        write(f, ewald.precision)
+        write(f, grid)
+        write(f, NoUnits.(cset.cell.mat./u"Å"))
+    end
+    grid
+end
+
+"Override the package's two grid builders with the GPU versions (method overwrite)."
+function install!()
+    @eval CEG begin
+        create_grid_vdw(file, framework::AbstractSystem{3}, forcefield::ForceField, spacing::TÅ, atom::Symbol) =
+            $(create_grid_vdw)(file, framework, forcefield, spacing, atom)
+        create_grid_coulomb(file, framework::AbstractSystem{3}, forcefield::ForceField, spacing::TÅ, _ewald=nothing) =
+            $(create_grid_coulomb)(file, framework, forcefield, spacing, _ewald)
+    end
+    nothing
+end
+
+end # module
