@@ -76,7 +76,9 @@ struct ceg_plan {
     int32_t* d_binstart = nullptr;
     ImageBins ib{};
     bool images_built = false;
-    PlanConst* d_pc = nullptr;   // device copy of {g, ib, rt}
+    PlanConst* d_pc = nullptr;   // device copy of {g, ib, rt, tables}
+    double* d_erfcx = nullptr;
+    double* d_exp2 = nullptr;
     bool lj_only = false;        // every kind present has <= 1 rule and it is Lennard-Jones
     bool fast_ewald = false;     // alpha*cutoff within the erfcx polynomial's domain
 };
@@ -291,6 +293,60 @@ int build_images(ceg_plan* p)
     return CEG_OK;
 }
 
+// Function tables of the fast real-space Ewald term (csrc/ceg_math.h): erfcx on
+// [alpha*R_EXACT, alpha*cutoff] as ERFCX_TAB_N degree-5 pieces (Chebyshev-node interpolation in
+// long double), and 2^(j/64).  Returns false (fast path disabled, libm-grade erfc used instead)
+// if the fit does not reach 1e-14.
+bool build_ewald_tables(double alpha, double cutoff2, std::vector<double>& tab, std::vector<double>& exp2_tab,
+                        double* inv_h_out, double* mx0_inv_h_out)
+{
+    const int N = CEG_ERFCX_TAB_N;
+    const long double x0 = (long double)alpha * std::sqrt((long double)CEG_R_EXACT2) * (1.0L - 1e-6L);
+    const long double x1 = (long double)alpha * std::sqrt((long double)cutoff2 * (1.0L + 2e-9L)) * (1.0L + 1e-6L);
+    if (!(x1 > x0) || x1 > 5.0L * (1.0L - 1e-9L)) return false;   // 5 = ERFCX_XMAX of the slow path's polynomial
+    const long double h = (x1 - x0) / N;
+    auto erfcx = [](long double x) { return expl(x * x) * erfcl(x); };
+    tab.assign((size_t)N * 6, 0.0);
+    const long double PI = 3.14159265358979323846264338327950288L;
+    long double node[6];
+    for (int k = 0; k < 6; ++k) node[k] = 0.5L * cosl(PI * (k + 0.5L) / 6.0L);   // s in [-0.5, 0.5]
+    double worst = 0.0;
+    for (int i = 0; i < N; ++i) {
+        const long double lo = x0 + i * h;
+        long double V[6][7];
+        for (int r = 0; r < 6; ++r) {
+            long double pw = 1.0L;
+            for (int c = 0; c < 6; ++c) { V[r][c] = pw; pw *= node[r]; }
+            V[r][6] = erfcx(lo + (node[r] + 0.5L) * h);
+        }
+        for (int c = 0; c < 6; ++c) {                       // Gauss-Jordan with partial pivoting
+            int piv = c;
+            for (int r = c + 1; r < 6; ++r) if (fabsl(V[r][c]) > fabsl(V[piv][c])) piv = r;
+            for (int q = 0; q < 7; ++q) std::swap(V[c][q], V[piv][q]);
+            const long double d = V[c][c];
+            for (int q = 0; q < 7; ++q) V[c][q] /= d;
+            for (int r = 0; r < 6; ++r) if (r != c) {
+                const long double f = V[r][c];
+                for (int q = 0; q < 7; ++q) V[r][q] -= f * V[c][q];
+            }
+        }
+        for (int c = 0; c < 6; ++c) tab[(size_t)i * 6 + c] = (double)V[c][6];
+        for (int t = 0; t <= 8; ++t) {                      // accuracy check with a double Horner
+            const double sl = -0.5 + t / 8.0;
+            double pv = tab[(size_t)i * 6 + 5];
+            for (int c = 4; c >= 0; --c) pv = pv * sl + tab[(size_t)i * 6 + c];
+            const long double ref = erfcx(lo + ((long double)sl + 0.5L) * h);
+            worst = std::max(worst, (double)fabsl(((long double)pv - ref) / ref));
+        }
+    }
+    if (!(worst < 1e-14)) return false;
+    exp2_tab.resize(64);
+    for (int j = 0; j < 64; ++j) exp2_tab[j] = (double)exp2l((long double)j / 64.0L);
+    *inv_h_out = (double)(1.0L / h);
+    *mx0_inv_h_out = (double)(-x0 / h);
+    return true;
+}
+
 int check_common(const double* pos, int64_t natoms, const double* mat, const double* invmat,
                  const int32_t* dims, const double* size, const double* shift, const double* delta)
 {
@@ -390,8 +446,21 @@ extern "C" int ceg_plan_create(ceg_plan_t** plan, int32_t device,
         hc.g = p->g;
         hc.ib = p->ib;
         hc.rt = RuleTable{p->d_rules, p->d_offset, p->nkinds};
-        rc = upload(&p->d_pc, &hc, 1);
-        p->fast_ewald = std::isfinite(alpha) && alpha >= 0 && alpha * std::sqrt(cutoff2) <= CEG_ERFCX_XMAX * (1.0 - 1e-9);
+        p->fast_ewald = false;
+        if (p->has_charge && std::isfinite(alpha) && alpha > 0) {
+            std::vector<double> tab, e2;
+            double inv_h = 0, mx0 = 0;
+            if (build_ewald_tables(alpha, cutoff2, tab, e2, &inv_h, &mx0)) {
+                rc = upload(&p->d_erfcx, tab.data(), tab.size());
+                if (!rc) rc = upload(&p->d_exp2, e2.data(), e2.size());
+                hc.erfcx_tab = p->d_erfcx;
+                hc.exp2_tab = p->d_exp2;
+                hc.erfcx_inv_h = inv_h;
+                hc.erfcx_mx0_inv_h = mx0;
+                p->fast_ewald = true;
+            }
+        }
+        if (!rc) rc = upload(&p->d_pc, &hc, 1);
     }
     if (rc) {
         ceg_plan_destroy(p);
@@ -414,6 +483,8 @@ extern "C" int ceg_plan_destroy(ceg_plan_t* p)
     (void)hipFree(p->d_imgatom);
     (void)hipFree(p->d_binstart);
     (void)hipFree(p->d_pc);
+    (void)hipFree(p->d_erfcx);
+    (void)hipFree(p->d_exp2);
     delete p;
     return CEG_OK;
 }

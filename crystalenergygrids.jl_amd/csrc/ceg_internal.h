@@ -96,10 +96,16 @@ struct PlanConst {
     Geom g;
     ImageBins ib;
     RuleTable rt;
+    // function tables of the fast real-space Ewald term (ceg_math.h), built per plan
+    const double* erfcx_tab;   // [ERFCX_TAB_N * 6]
+    const double* exp2_tab;    // [64]  2^(j/64)
+    double erfcx_inv_h;        // 1/h
+    double erfcx_mx0_inv_h;    // -x0/h
 };
 
-// largest alpha*r for which the fast erfcx polynomial (ceg_math.h) is valid
-constexpr double CEG_ERFCX_XMAX = 5.0;
+// shared between the host table builder and the kernels
+constexpr int CEG_ERFCX_TAB_N = 128;     // pieces of the erfcx table (= ERFCX_TAB_N of ceg_math.h)
+constexpr double CEG_R_EXACT2 = 4.0;     // pairs closer than this (A^2) take the exact path
 
 // launchers (ceg_kernels.hip)
 hipError_t launch_bruteforce(int mode, const Geom& g, const AtomTable& atoms, const RuleTable& rt,

@@ -307,10 +307,14 @@ __global__ __launch_bounds__(256) void k_bruteforce(Geom g, AtomTable atoms, Rul
 }
 
 #ifndef CEG_WAVES
-#define CEG_WAVES 4
+#define CEG_WAVES 4      // waves per SIMD the register allocator is asked to allow
+#endif
+#ifndef CEG_WG
+#define CEG_WG 256       // threads per workgroup of k_culled (one tile per wave)
 #endif
 // pairs closer than this (A^2) take the literal min-image arithmetic in the culled kernel
-constexpr double R_EXACT2 = 4.0;
+constexpr double R_EXACT2 = CEG_R_EXACT2;
+static_assert(ERFCX_TAB_N == CEG_ERFCX_TAB_N, "table size mismatch");
 constexpr int META_SIMPLE = 1 << 24;      // image is the wrapped one for every point of the tile
 constexpr int META_HASVDW = 1 << 25;      // the atom's kind has at least one VdW rule
 constexpr int META_KINDMASK = (1 << 24) - 1;
@@ -376,20 +380,42 @@ __device__ __forceinline__ double wave_max(double x)
 //   FASTEW  alpha*cutoff <= ERFCX_XMAX: real-space Ewald term from ceg_math.h (one exp, erfcx
 //           polynomial, no division); otherwise libm-style erfc/exp
 template <int MODE, bool POINTS, bool LJONLY, bool FASTEW>
-__global__ __launch_bounds__(64, CEG_WAVES) void k_culled(const PlanConst* __restrict__ pc, Output out, Points pts,
-                                                int tiles_j, int tiles_k)
+__global__ __launch_bounds__(CEG_WG, CEG_WAVES) void k_culled(const PlanConst* __restrict__ pc, Output out, Points pts,
+                                                              int tiles_j, int tiles_k, int64_t ntiles)
 {
-    __shared__ double4 s_cand[64];
-    __shared__ double4 s_lj[64];
-    __shared__ int32_t s_meta[64];
-    __shared__ int32_t s_atom[64];
-    __shared__ int32_t s_rowstart[64];
-    __shared__ int32_t s_rowprefix[65];
+    // One workgroup = CEG_WG/64 waves; each wave owns one tile and its own slice of the staging
+    // arrays (waves never touch each other's slice, so no workgroup barrier inside the loops --
+    // LDS operations of one wave complete in order).  The function tables are shared.
+    constexpr int NW = CEG_WG / 64;
+    __shared__ double4 s_cand_all[NW][64];
+    __shared__ double4 s_lj_all[NW][64];
+    __shared__ int32_t s_meta_all[NW][64];
+    __shared__ int32_t s_atom_all[NW][64];
+    __shared__ int32_t s_rowstart_all[NW][64];
+    __shared__ int32_t s_rowprefix_all[NW][66];
+    __shared__ __attribute__((aligned(16))) double s_erfcx[ERFCX_TAB_N * 6];
+    __shared__ double s_exp2[64];
+
+    const int wave = threadIdx.x >> 6;
+    double4* s_cand = s_cand_all[wave];
+    double4* s_lj = s_lj_all[wave];
+    int32_t* s_meta = s_meta_all[wave];
+    int32_t* s_atom = s_atom_all[wave];
+    int32_t* s_rowstart = s_rowstart_all[wave];
+    int32_t* s_rowprefix = s_rowprefix_all[wave];
+
+    if (FASTEW && MODE != MODE_VDW) {
+        for (int t = threadIdx.x; t < ERFCX_TAB_N * 6; t += CEG_WG) s_erfcx[t] = pc->erfcx_tab[t];
+        if (threadIdx.x < 64) s_exp2[threadIdx.x] = pc->exp2_tab[threadIdx.x];
+    }
+    __syncthreads();
+    const int64_t tile = (int64_t)blockIdx.x * NW + wave;
+    if (tile >= ntiles) return;
 
     const Geom& g = pc->g;
     const ImageBins& ib = pc->ib;
     const RuleTable& rt = pc->rt;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const double cutoff2 = g.cutoff2;
     const double alpha = g.alpha;
     const int32_t ortho = g.ortho;
@@ -401,14 +427,14 @@ __global__ __launch_bounds__(64, CEG_WAVES) void k_culled(const PlanConst* __res
     bool valid;
     double px, py, pz;
     if (POINTS) {
-        pidx = (int64_t)blockIdx.x * 64 + lane;
+        pidx = tile * 64 + lane;
         valid = pidx < pts.n;
         const int64_t tt = valid ? pidx : (pts.n - 1);
         px = pts.xyz[3 * tt]; py = pts.xyz[3 * tt + 1]; pz = pts.xyz[3 * tt + 2];
     } else {
-        const int tk = blockIdx.x % tiles_k;
-        const int tj = (blockIdx.x / tiles_k) % tiles_j;
-        const int ti = blockIdx.x / (tiles_k * tiles_j);
+        const int tk = (int)(tile % tiles_k);
+        const int tj = (int)((tile / tiles_k) % tiles_j);
+        const int ti = (int)(tile / ((int64_t)tiles_k * tiles_j));
         i = out.i_begin + 4 * ti + (lane >> 4);
         j = 4 * tj + ((lane >> 2) & 3);
         k = 4 * tk + (lane & 3);
@@ -452,6 +478,8 @@ __global__ __launch_bounds__(64, CEG_WAVES) void k_culled(const PlanConst* __res
     const double band_safe = (ortho || safemin2 > cutoff2 * (1.0 + 1e-8)) ? -1.0 : 1e-9 * safemin2;
     const double alpha2 = alpha * alpha;
     const bool stale_possible = !ortho && safemin2 < cutoff2;
+    const double cut_lo = cutoff2 - band_cut, cut_hi = cutoff2 + band_cut;
+    const double erf_inv_h = pc->erfcx_inv_h, erf_mx0 = pc->erfcx_mx0_inv_h;
 
     for (int rbase = 0; rbase < nrows; rbase += 64) {
         // -- one row per lane: image range [start, start+count)
@@ -479,11 +507,11 @@ __global__ __launch_bounds__(64, CEG_WAVES) void k_culled(const PlanConst* __res
             const int up = __shfl_up(incl, o);
             if (lane >= o) incl += up;
         }
-        __syncthreads();                       // previous batch's readers are done
+        __builtin_amdgcn_wave_barrier();                       // previous batch's readers are done
         s_rowstart[lane] = start;
         s_rowprefix[lane + 1] = incl;
         if (lane == 0) s_rowprefix[0] = 0;
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         const int total = s_rowprefix[64];
 
         for (int cbase = 0; cbase < total; cbase += 64) {
@@ -535,7 +563,7 @@ __global__ __launch_bounds__(64, CEG_WAVES) void k_culled(const PlanConst* __res
             }
             const unsigned long long mask = __ballot(keep);
             const int nkeep = __popcll(mask);
-            __syncthreads();                   // previous chunk's readers are done
+            __builtin_amdgcn_wave_barrier();                   // previous chunk's readers are done
             if (keep) {
                 const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                                            __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
@@ -544,7 +572,7 @@ __global__ __launch_bounds__(64, CEG_WAVES) void k_culled(const PlanConst* __res
                 s_meta[slot] = meta;
                 s_atom[slot] = aidx;
             }
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
 
             // -- every lane against every kept image (LDS broadcast reads).  The hot loop only
             //    handles the regular case -- the image is the wrapped one for the whole tile, the
@@ -557,13 +585,15 @@ __global__ __launch_bounds__(64, CEG_WAVES) void k_culled(const PlanConst* __res
                 const int mt = __builtin_amdgcn_readfirstlane(s_meta[q]);
                 double dx = px - A.x, dy = py - A.y, dz = pz - A.z;
                 const double r2 = dx * dx + dy * dy + dz * dz;
-                bool in = r2 < cutoff2;
-                const bool odd = (r2 < R_EXACT2) || (fabs(r2 - cutoff2) <= band_cut) ||
-                                 (in && (!(mt & META_SIMPLE) || fabs(r2 - safemin2) <= band_safe));
-                if (odd) {
-                    slow |= 1ull << q;
+                // regular: R_EXACT2 <= r2 < cutoff2 - band, image provably the wrapped one, not at
+                // the safemin threshold.  odd: anything else that could contribute.
+                bool in = (r2 >= R_EXACT2) && (r2 < cut_lo);
+                bool odd = !in && (r2 <= cut_hi);
+                if (!(mt & META_SIMPLE) || (band_safe >= 0.0 && fabs(r2 - safemin2) <= band_safe)) {
+                    odd = odd || in;
                     in = false;
                 }
+                if (odd) slow |= 1ull << q;
                 if (!in) continue;
                 if (stale_possible && r2 > safemin2) {
                     // wrapped image beyond safemin: the reference's neighbour search finds nothing
@@ -606,15 +636,15 @@ __global__ __launch_bounds__(64, CEG_WAVES) void k_culled(const PlanConst* __res
                     av.d3 = __builtin_fma(p3, dxyz, av.d3);
                 }
                 if (MODE != MODE_VDW) {
-                    smallest_d2 = min_nonan(smallest_d2, r2);
+                    // (regular pairs have r >= 2 A: they cannot trigger the smallest_d2 < 1 rule)
                     double v, p1, p2, p3;
                     if (FASTEW) {
                         // derivatives_ewald (src/ewald.jl:299-312): erfc(x) = exp(-x^2) erfcx(x)
                         const double two_over_sqrtpi = 1.1283791670955125739;
                         const double x = alpha * rr;
                         const double x2 = alpha2 * r2;
-                        const double E = fast_exp_neg(-x2);
-                        const double c = E * erfcx_poly(x);              // erfc(alpha r)
+                        const double E = exp_neg_tab(s_exp2, -x2);
+                        const double c = E * erfcx_tab(s_erfcx, x, erf_inv_h, erf_mx0);   // erfc(alpha r)
                         const double e = two_over_sqrtpi * x * E;        // 2 alpha r exp(-alpha^2 r^2)/sqrt(pi)
                         const double q1 = A.w * rinv;                    // q / r
                         const double q3 = q1 * inv, q5 = q3 * inv, q7 = q5 * inv;
@@ -623,6 +653,7 @@ __global__ __launch_bounds__(64, CEG_WAVES) void k_culled(const PlanConst* __res
                         p2 = q5 * __builtin_fma(e, __builtin_fma(2.0, x2, 3.0), 3.0 * c);
                         p3 = -q7 * __builtin_fma(e, __builtin_fma(x2, __builtin_fma(4.0, x2, 10.0), 15.0), 15.0 * c);
                     } else {
+                        smallest_d2 = min_nonan(smallest_d2, r2);
                         ewald_terms(alpha, A.w, r2, v, p1, p2, p3);
                     }
                     ac.v += v;
@@ -676,32 +707,35 @@ hipError_t launch_bruteforce(int mode, const Geom& g, const AtomTable& atoms, co
 
 template <int MODE, bool POINTS>
 static void launch_cull_flags(bool ljonly, bool fastew, dim3 grid, dim3 block, hipStream_t stream,
-                              const PlanConst* pc, const Output& out, const Points& pts, int tj, int tk)
+                              const PlanConst* pc, const Output& out, const Points& pts, int tj, int tk,
+                              int64_t ntiles)
 {
     // flags that do not matter for a mode are normalised so fewer variants get instantiated
     if (MODE == MODE_VDW) fastew = true;
     if (MODE == MODE_COULOMB) ljonly = true;
     if (ljonly && fastew)
-        hipLaunchKernelGGL((k_culled<MODE, POINTS, true, true>), grid, block, 0, stream, pc, out, pts, tj, tk);
+        hipLaunchKernelGGL((k_culled<MODE, POINTS, true, true>), grid, block, 0, stream, pc, out, pts, tj, tk, ntiles);
     else if (ljonly)
-        hipLaunchKernelGGL((k_culled<MODE, POINTS, true, false>), grid, block, 0, stream, pc, out, pts, tj, tk);
+        hipLaunchKernelGGL((k_culled<MODE, POINTS, true, false>), grid, block, 0, stream, pc, out, pts, tj, tk, ntiles);
     else if (fastew)
-        hipLaunchKernelGGL((k_culled<MODE, POINTS, false, true>), grid, block, 0, stream, pc, out, pts, tj, tk);
+        hipLaunchKernelGGL((k_culled<MODE, POINTS, false, true>), grid, block, 0, stream, pc, out, pts, tj, tk, ntiles);
     else
-        hipLaunchKernelGGL((k_culled<MODE, POINTS, false, false>), grid, block, 0, stream, pc, out, pts, tj, tk);
+        hipLaunchKernelGGL((k_culled<MODE, POINTS, false, false>), grid, block, 0, stream, pc, out, pts, tj, tk, ntiles);
 }
 
 template <bool POINTS>
 static hipError_t launch_cull_t(int mode, const PlanConst* pc, bool ljonly, bool fastew, const Output& out,
-                                const Points& pts, int64_t nblocks, int tj, int tk, hipStream_t stream)
+                                const Points& pts, int64_t ntiles, int tj, int tk, hipStream_t stream)
 {
-    if (nblocks <= 0) return hipSuccess;
+    if (ntiles <= 0) return hipSuccess;
+    constexpr int NW = CEG_WG / 64;
+    const int64_t nblocks = (ntiles + NW - 1) / NW;
     if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    dim3 grid((unsigned)nblocks), block(64);
+    dim3 grid((unsigned)nblocks), block(CEG_WG);
     switch (mode) {
-    case MODE_VDW: launch_cull_flags<MODE_VDW, POINTS>(ljonly, fastew, grid, block, stream, pc, out, pts, tj, tk); break;
-    case MODE_COULOMB: launch_cull_flags<MODE_COULOMB, POINTS>(ljonly, fastew, grid, block, stream, pc, out, pts, tj, tk); break;
-    default: launch_cull_flags<MODE_FUSED, POINTS>(ljonly, fastew, grid, block, stream, pc, out, pts, tj, tk); break;
+    case MODE_VDW: launch_cull_flags<MODE_VDW, POINTS>(ljonly, fastew, grid, block, stream, pc, out, pts, tj, tk, ntiles); break;
+    case MODE_COULOMB: launch_cull_flags<MODE_COULOMB, POINTS>(ljonly, fastew, grid, block, stream, pc, out, pts, tj, tk, ntiles); break;
+    default: launch_cull_flags<MODE_FUSED, POINTS>(ljonly, fastew, grid, block, stream, pc, out, pts, tj, tk, ntiles); break;
     }
     return hipGetLastError();
 }

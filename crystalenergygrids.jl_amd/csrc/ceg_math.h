@@ -21,6 +21,14 @@ __device__ __forceinline__ double fma_sc(double p, double t, double c)
     return r;
 }
 
+// a*b + c with b in a scalar pair and c a loop-invariant VGPR constant (3-address, no copy)
+__device__ __forceinline__ double fma_vsv(double a, double b, double c)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
+
 // min of two non-NaN doubles in one instruction (fmin() adds two canonicalising v_max_f64)
 __device__ __forceinline__ double min_nonan(double a, double b)
 {
@@ -81,6 +89,50 @@ __device__ __forceinline__ double fast_exp_neg(double y)
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
     return __builtin_ldexp(p, (int)k);
+}
+
+// ---- LDS-table variants used by the hot loop --------------------------------------------
+// erfcx on [x0, x0 + N*h]: N = ERFCX_TAB_N intervals, degree-5 polynomial in the local
+// coordinate s in [-0.5, 0.5] per interval (6 doubles, 48 B, 16-B aligned), fitted per plan on
+// the host in long double for the plan's [alpha*R_EXACT, alpha*cutoff] (max rel err 2e-15).
+// Coefficients arrive from LDS as fresh VGPRs, so every Horner step is one v_fma/v_fmac.
+constexpr int ERFCX_TAB_N = 128;
+
+__device__ __forceinline__ double erfcx_tab(const double* __restrict__ tab, double x, double inv_h, double mx0_inv_h)
+{
+    const double u = __builtin_fma(x, inv_h, mx0_inv_h);      // (x - x0)/h in [0, N)
+    const double fi = __builtin_floor(u);
+    unsigned idx = (unsigned)(int)fi;
+    idx = idx < (unsigned)(ERFCX_TAB_N - 1) ? idx : (unsigned)(ERFCX_TAB_N - 1);
+    const double sl = (u - fi) - 0.5;
+    const double2* c = reinterpret_cast<const double2*>(tab + idx * 6);
+    const double2 c01 = c[0], c23 = c[1], c45 = c[2];
+    double p = __builtin_fma(c45.y, sl, c45.x);
+    p = __builtin_fma(p, sl, c23.y);
+    p = __builtin_fma(p, sl, c23.x);
+    p = __builtin_fma(p, sl, c01.y);
+    p = __builtin_fma(p, sl, c01.x);
+    return p;
+}
+
+// exp(y), y in [-700, 0]: k = rint(64 y / ln2), exp(y) = 2^(k>>6) * 2^((k&63)/64) * exp(r),
+// |r| <= ln2/128, exp(r) by a degree-5 Taylor polynomial (truncation 4e-17).
+__device__ __forceinline__ double exp_neg_tab(const double* __restrict__ exp2_tab, double y)
+{
+    const double c64_log2e = 92.33248261689366;               // 64/ln2
+    const double ln2_64_hi = 0.01083042469326756;             // ln2/64 with 21 trailing zero bits: k*hi exact
+    const double ln2_64_lo = 2.9815858269852933e-12;
+    const double kf = __builtin_rint(y * c64_log2e);
+    const int k = (int)kf;
+    double r = __builtin_fma(-kf, ln2_64_hi, y);
+    r = __builtin_fma(-kf, ln2_64_lo, r);
+    const double T = exp2_tab[k & 63];
+    double q = fma_vsv(r, 8.3333333333333332e-03, 4.1666666666666664e-02);    // r/120 + 1/24
+    q = fma_sc(q, r, 1.6666666666666666e-01);
+    q = __builtin_fma(q, r, 0.5);
+    q = __builtin_fma(q, r, 1.0);
+    const double pr = q * r;                                  // exp(r) - 1
+    return __builtin_ldexp(__builtin_fma(T, pr, T), k >> 6);
 }
 
 // erfcx(x) = exp(x^2) erfc(x) for x in [0, ERFCX_XMAX]: degree-18 polynomial in
