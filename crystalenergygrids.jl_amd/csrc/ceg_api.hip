@@ -446,6 +446,7 @@ extern "C" int ceg_plan_create(ceg_plan_t** plan, int32_t device,
         hc.g = p->g;
         hc.ib = p->ib;
         hc.rt = RuleTable{p->d_rules, p->d_offset, p->nkinds};
+        hc.alpha2 = alpha * alpha;
         p->fast_ewald = false;
         if (p->has_charge && std::isfinite(alpha) && alpha > 0) {
             std::vector<double> tab, e2;

@@ -101,6 +101,7 @@ struct PlanConst {
     const double* exp2_tab;    // [64]  2^(j/64)
     double erfcx_inv_h;        // 1/h
     double erfcx_mx0_inv_h;    // -x0/h
+    double alpha2;             // alpha^2
 };
 
 // shared between the host table builder and the kernels

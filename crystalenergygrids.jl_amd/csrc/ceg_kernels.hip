@@ -320,22 +320,26 @@ constexpr int META_HASVDW = 1 << 25;      // the atom's kind has at least one Vd
 constexpr int META_KINDMASK = (1 << 24) - 1;
 
 // ------------------------------------------------------------------ culled kernel
-// Pairs the hot loop of k_culled sets aside (bit q of `slow` = candidate q of the current LDS
-// chunk): very close pairs, pairs within 1e-9 of a decision threshold, images that are not
-// provably the wrapped one.  Each is recomputed exactly like the reference does it -- original
-// atom position, invmat*d, wrap, mat*f, neighbour search (periodic_distance2_literal) -- and
-// evaluated with libm-grade radial functions.  Kept out of line so its registers do not weigh on
-// the hot loop.
+// Pairs the hot loop of k_culled sets aside: for candidate q of the current LDS chunk, s_odd[q] is
+// the mask of lanes whose pair with q is "odd" (very close, within 1e-9 of a decision threshold,
+// image not provably the wrapped one, stale-vector range); `cands` has bit q set when s_odd[q] is
+// valid.  Each such pair is recomputed exactly like the reference does it -- original atom
+// position, invmat*d, wrap, mat*f, neighbour search (periodic_distance2_literal) -- and evaluated
+// with the literal radial formulas.  Runs after the hot loop so that its registers do not
+// overlap the hot loop's.
 template <int MODE, bool FASTEW>
-__device__ __forceinline__ void slow_pairs(const PlanConst* __restrict__ pc, unsigned long long slow,
-                                        double px, double py, double pz,
-                                        const double4* s_cand, const int32_t* s_meta, const int32_t* s_atom,
-                                        Accum& av, Accum& ac, double& smallest_d2)
+__device__ __forceinline__ void slow_pairs(const PlanConst* __restrict__ pc, unsigned long long cands, int lane,
+                                           double px, double py, double pz,
+                                           const int32_t* s_meta, const int32_t* s_atom,
+                                           const unsigned long long* s_odd,
+                                           Accum& av, Accum& ac, double& smallest_d2)
 {
     const Geom& g = pc->g;
-    while (slow != 0ull) {
-        const int q = __builtin_ctzll(slow);
-        slow &= slow - 1ull;
+    while (cands != 0ull) {
+        const int q = __builtin_ctzll(cands);
+        cands &= cands - 1ull;
+        const unsigned long long lanes = s_odd[q];
+        if (!((lanes >> lane) & 1ull)) continue;
         const int mt = s_meta[q];
         const double4 O = pc->ib.atoms[s_atom[q]];
         double dx = px - O.x, dy = py - O.y, dz = pz - O.z;
@@ -393,6 +397,7 @@ __global__ __launch_bounds__(CEG_WG, CEG_WAVES) void k_culled(const PlanConst* _
     __shared__ int32_t s_atom_all[NW][64];
     __shared__ int32_t s_rowstart_all[NW][64];
     __shared__ int32_t s_rowprefix_all[NW][66];
+    __shared__ unsigned long long s_odd_all[NW][64];
     __shared__ __attribute__((aligned(16))) double s_erfcx[ERFCX_TAB_N * 6];
     __shared__ double s_exp2[64];
 
@@ -403,6 +408,7 @@ __global__ __launch_bounds__(CEG_WG, CEG_WAVES) void k_culled(const PlanConst* _
     int32_t* s_atom = s_atom_all[wave];
     int32_t* s_rowstart = s_rowstart_all[wave];
     int32_t* s_rowprefix = s_rowprefix_all[wave];
+    unsigned long long* s_odd = s_odd_all[wave];
 
     if (FASTEW && MODE != MODE_VDW) {
         for (int t = threadIdx.x; t < ERFCX_TAB_N * 6; t += CEG_WG) s_erfcx[t] = pc->erfcx_tab[t];
@@ -473,12 +479,14 @@ __global__ __launch_bounds__(CEG_WG, CEG_WAVES) void k_culled(const PlanConst* _
     accum_zero(av);
     accum_zero(ac);
     double smallest_d2 = __builtin_huge_val();
-    // widths of the "decide with the reference's arithmetic" bands (negative = band unused)
+    // width of the "decide with the reference's arithmetic" band around a threshold
     const double band_cut = 1e-9 * cutoff2;
-    const double band_safe = (ortho || safemin2 > cutoff2 * (1.0 + 1e-8)) ? -1.0 : 1e-9 * safemin2;
-    const double alpha2 = alpha * alpha;
+    const double alpha2 = pc->alpha2;
     const bool stale_possible = !ortho && safemin2 < cutoff2;
-    const double cut_lo = cutoff2 - band_cut, cut_hi = cutoff2 + band_cut;
+    const double cut_hi = cutoff2 + band_cut;
+    // upper end of the regular range: below the cutoff band and, when the stale-vector branch of
+    // the reference can fire (safemin2 < cutoff2, src/utils.jl:233-245), below safemin2's band too
+    const double reg_hi = stale_possible ? fmin(cutoff2 - band_cut, safemin2 * (1.0 - 1e-9)) : cutoff2 - band_cut;
     const double erf_inv_h = pc->erfcx_inv_h, erf_mx0 = pc->erfcx_mx0_inv_h;
 
     for (int rbase = 0; rbase < nrows; rbase += 64) {
@@ -542,7 +550,7 @@ __global__ __launch_bounds__(CEG_WG, CEG_WAVES) void k_culled(const PlanConst* _
                     hasvdw = rt.offset[kd + 1] > rb;
                     if (LJONLY && hasvdw && keep) {
                         const DevRule R = rt.rules[rb];
-                        LJ = make_double4(R.p0, R.p1, R.shift, 0.0);
+                        LJ = make_double4(4.0 * R.p0, R.p1, R.shift, 0.0);
                     }
                 }
                 if (MODE == MODE_VDW) keep = keep && hasvdw;   // kinds without a rule contribute exact zeros
@@ -579,27 +587,24 @@ __global__ __launch_bounds__(CEG_WG, CEG_WAVES) void k_culled(const PlanConst* _
             //    pair is between R_EXACT and the cutoff and away from every decision threshold.
             //    Anything else is recorded in a per-lane bit mask and redone after the loop with
             //    the reference's literal arithmetic (slow_pairs).
-            unsigned long long slow = 0ull;
+            unsigned long long slow = 0ull;     // wave-uniform: candidates with at least one odd lane
             for (int q = 0; q < nkeep; ++q) {
                 const double4 A = s_cand[q];
                 const int mt = __builtin_amdgcn_readfirstlane(s_meta[q]);
                 double dx = px - A.x, dy = py - A.y, dz = pz - A.z;
                 const double r2 = dx * dx + dy * dy + dz * dz;
-                // regular: R_EXACT2 <= r2 < cutoff2 - band, image provably the wrapped one, not at
-                // the safemin threshold.  odd: anything else that could contribute.
-                bool in = (r2 >= R_EXACT2) && (r2 < cut_lo);
-                bool odd = !in && (r2 <= cut_hi);
-                if (!(mt & META_SIMPLE) || (band_safe >= 0.0 && fabs(r2 - safemin2) <= band_safe)) {
-                    odd = odd || in;
-                    in = false;
+                // regular: R_EXACT2 <= r2 < min(cutoff2 - band, stale limit), image provably the
+                // wrapped one.  odd: anything else that could contribute.  (bitwise logic on
+                // purpose: no short-circuit branches in the hot loop)
+                const bool simple = (mt & META_SIMPLE) != 0;
+                const bool in = (r2 >= R_EXACT2) & (r2 < reg_hi) & simple;
+                const bool odd = (!in) & (r2 <= cut_hi);
+                const unsigned long long oddlanes = __ballot(odd);
+                if (oddlanes != 0ull) {              // scalar branch, rarely taken
+                    slow |= 1ull << q;
+                    if (lane == 0) s_odd[q] = oddlanes;
                 }
-                if (odd) slow |= 1ull << q;
                 if (!in) continue;
-                if (stale_possible && r2 > safemin2) {
-                    // wrapped image beyond safemin: the reference's neighbour search finds nothing
-                    // closer and leaves buffer = wrapped - c (src/utils.jl:233-245)
-                    dx -= g.mat[6]; dy -= g.mat[7]; dz -= g.mat[8];
-                }
 
                 // ---- regular pair: 2 A <= r < cutoff
                 const double dxy = dx * dy, dxz = dx * dz, dyz = dy * dz;
@@ -613,15 +618,15 @@ __global__ __launch_bounds__(CEG_WG, CEG_WAVES) void k_culled(const PlanConst* _
                     double v, p1, p2, p3;
                     if (LJONLY) {
                         // derivativesGrid, LJ branch (src/interactions.jl:434-441), with 1/r2 shared
-                        const double4 L = s_lj[q];             // eps, sigma^2, shift
+                        const double4 L = s_lj[q];             // 4 eps, sigma^2, shift
                         const double sx = L.y * inv;
                         const double x6 = sx * sx * sx;
-                        const double a = L.x * x6;
-                        const double inv2 = inv * inv;
-                        v = __builtin_fma(4.0 * a, x6 - 1.0, -L.z);
-                        p1 = 24.0 * a * __builtin_fma(-2.0, x6, 1.0) * inv;
-                        p2 = 96.0 * a * __builtin_fma(7.0, x6, -2.0) * inv2;
-                        p3 = 384.0 * a * __builtin_fma(-28.0, x6, 5.0) * (inv2 * inv2);
+                        const double t1 = L.x * x6;                        // 4 eps x6
+                        const double t1i = t1 * inv, t1ii = t1i * inv, inv2 = inv * inv;
+                        v = __builtin_fma(t1, x6, -t1) - L.z;              // 4 eps x6 (x6 - 1) - shift
+                        p1 = mul_sc(t1i * (x6 - 0.5), -12.0);                                // 24 eps x6 (1 - 2 x6)/r^2
+                        p2 = mul_sc(t1ii * add_sc(x6, -2.0 / 7.0), 168.0);                   // 96 eps x6 (7 x6 - 2)/r^4
+                        p3 = mul_sc((t1ii * inv2) * add_sc(x6, -5.0 / 28.0), -2688.0);       // 384 eps x6 (5 - 28 x6)/r^8
                     } else {
                         const int kd = mt & META_KINDMASK;
                         vdw_terms(rt.rules, rt.offset[kd], rt.offset[kd + 1], r2, v, p1, p2, p3);
@@ -650,8 +655,8 @@ __global__ __launch_bounds__(CEG_WG, CEG_WAVES) void k_culled(const PlanConst* _
                         const double q3 = q1 * inv, q5 = q3 * inv, q7 = q5 * inv;
                         v = q1 * c;
                         p1 = -q3 * (e + c);
-                        p2 = q5 * __builtin_fma(e, __builtin_fma(2.0, x2, 3.0), 3.0 * c);
-                        p3 = -q7 * __builtin_fma(e, __builtin_fma(x2, __builtin_fma(4.0, x2, 10.0), 15.0), 15.0 * c);
+                        p2 = q5 * __builtin_fma(e, fma2_sc(x2, 3.0), mul_sc(c, 3.0));
+                        p3 = -q7 * __builtin_fma(e, fma_sc(fma4_sc(x2, 10.0), x2, 15.0), mul_sc(c, 15.0));
                     } else {
                         smallest_d2 = min_nonan(smallest_d2, r2);
                         ewald_terms(alpha, A.w, r2, v, p1, p2, p3);
@@ -667,8 +672,10 @@ __global__ __launch_bounds__(CEG_WG, CEG_WAVES) void k_culled(const PlanConst* _
                 }
             }
             // -- the pairs set aside above, one per lane per round
-            if (__any(slow != 0ull))
-                slow_pairs<MODE, FASTEW>(pc, slow, px, py, pz, s_cand, s_meta, s_atom, av, ac, smallest_d2);
+            if (slow != 0ull) {
+                __builtin_amdgcn_wave_barrier();
+                slow_pairs<MODE, FASTEW>(pc, slow, lane, px, py, pz, s_meta, s_atom, s_odd, av, ac, smallest_d2);
+            }
         }
     }
     if (valid) write_results<MODE>(g, out, POINTS, pidx, i, j, k, av, ac, smallest_d2);

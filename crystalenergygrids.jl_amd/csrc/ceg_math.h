@@ -21,6 +21,34 @@ __device__ __forceinline__ double fma_sc(double p, double t, double c)
     return r;
 }
 
+// a + c, a*2 + c, a*4 + c with c in a scalar register pair (2.0 / 4.0 are inline constants)
+__device__ __forceinline__ double add_sc(double a, double c)
+{
+    double r;
+    asm("v_add_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(c));
+    return r;
+}
+__device__ __forceinline__ double fma2_sc(double a, double c)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, 2.0, %2" : "=v"(r) : "v"(a), "s"(c));
+    return r;
+}
+__device__ __forceinline__ double fma4_sc(double a, double c)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, 4.0, %2" : "=v"(r) : "v"(a), "s"(c));
+    return r;
+}
+
+// a * c with the constant c in a scalar register pair
+__device__ __forceinline__ double mul_sc(double a, double c)
+{
+    double r;
+    asm("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(c));
+    return r;
+}
+
 // a*b + c with b in a scalar pair and c a loop-invariant VGPR constant (3-address, no copy)
 __device__ __forceinline__ double fma_vsv(double a, double b, double c)
 {
