@@ -169,6 +169,38 @@ __device__ __forceinline__ void store_gridpoint(float* __restrict__ out, int64_t
     out[idx + 7 * cs] = (float)__dmul_rn(__dmul_rn(a.d3, __dmul_rn(__dmul_rn(D1, D2), D3)), lambda);
 }
 
+// _set_gridpoint! (src/grids.jl:118-135) into 8 registers (same arithmetic as store_gridpoint)
+__device__ __forceinline__ void gridpoint8(float r[8], const double* delta, double lambda, double thr, Accum a)
+{
+#pragma clang fp contract(off)
+    if (a.v > thr) {
+        a.v = 2.0 * thr;
+        a.d1x = clamp_julia(a.d1x, -thr, thr);
+        a.d1y = clamp_julia(a.d1y, -thr, thr);
+        a.d1z = clamp_julia(a.d1z, -thr, thr);
+        a.d2xy = a.d2xz = a.d2yz = 0.0;
+        a.d3 = 0.0;
+    }
+    const double D1 = delta[0], D2 = delta[1], D3 = delta[2];
+    r[0] = (float)__dmul_rn(a.v, lambda);
+    r[1] = (float)__dmul_rn(__dmul_rn(a.d1x, D1), lambda);
+    r[2] = (float)__dmul_rn(__dmul_rn(a.d1y, D2), lambda);
+    r[3] = (float)__dmul_rn(__dmul_rn(a.d1z, D3), lambda);
+    r[4] = (float)__dmul_rn(__dmul_rn(a.d2xy, __dmul_rn(D1, D2)), lambda);
+    r[5] = (float)__dmul_rn(__dmul_rn(a.d2xz, __dmul_rn(D1, D3)), lambda);
+    r[6] = (float)__dmul_rn(__dmul_rn(a.d2yz, __dmul_rn(D2, D3)), lambda);
+    r[7] = (float)__dmul_rn(__dmul_rn(a.d3, __dmul_rn(__dmul_rn(D1, D2), D3)), lambda);
+}
+
+// 16-byte global store that only needs 4-byte alignment (gfx950 global memory handles dword-aligned
+// vector accesses; hipcc would split a packed struct store into dword + dwordx3)
+typedef float ceg_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_float4_unaligned(float* dst, float4 v)
+{
+    const ceg_v4f u = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(dst), "v"(u) : "memory");
+}
+
 __device__ __forceinline__ void store_raw(double* __restrict__ out, int64_t p, const Accum& a)
 {
     double* o = out + 8 * p;
@@ -415,8 +447,9 @@ __global__ __launch_bounds__(CEG_WG, CEG_WAVES) void k_culled(const PlanConst* _
         if (threadIdx.x < 64) s_exp2[threadIdx.x] = pc->exp2_tab[threadIdx.x];
     }
     __syncthreads();
-    const int64_t tile = (int64_t)blockIdx.x * NW + wave;
-    if (tile >= ntiles) return;
+    const int64_t tile_raw = (int64_t)blockIdx.x * NW + wave;
+    const bool active = tile_raw < ntiles;          // inactive waves idle until the final barrier
+    const int64_t tile = active ? tile_raw : ntiles - 1;
 
     const Geom& g = pc->g;
     const ImageBins& ib = pc->ib;
@@ -429,22 +462,24 @@ __global__ __launch_bounds__(CEG_WG, CEG_WAVES) void k_culled(const PlanConst* _
 
     // ---- this lane's point
     int i = 0, j = 0, k = 0;
+    int i0 = 0, j0 = 0, k0 = 0;                       // tile origin (grid mode)
     int64_t pidx = 0;
     bool valid;
     double px, py, pz;
     if (POINTS) {
         pidx = tile * 64 + lane;
-        valid = pidx < pts.n;
+        valid = active && pidx < pts.n;
         const int64_t tt = valid ? pidx : (pts.n - 1);
         px = pts.xyz[3 * tt]; py = pts.xyz[3 * tt + 1]; pz = pts.xyz[3 * tt + 2];
     } else {
         const int tk = (int)(tile % tiles_k);
         const int tj = (int)((tile / tiles_k) % tiles_j);
         const int ti = (int)(tile / ((int64_t)tiles_k * tiles_j));
-        i = out.i_begin + 4 * ti + (lane >> 4);
-        j = 4 * tj + ((lane >> 2) & 3);
-        k = 4 * tk + (lane & 3);
-        valid = (i < out.i_end) && (j <= g.dims[1]) && (k <= g.dims[2]);
+        i0 = out.i_begin + 4 * ti; j0 = 4 * tj; k0 = 4 * tk;
+        i = i0 + (lane >> 4);
+        j = j0 + ((lane >> 2) & 3);
+        k = k0 + (lane & 3);
+        valid = active && (i < out.i_end) && (j <= g.dims[1]) && (k <= g.dims[2]);
         // out-of-range lanes take the tile's first point (always valid) so they stay inside the box
         const int ci = valid ? i : (out.i_begin + 4 * ti);
         const int cj = valid ? j : 4 * tj;
@@ -473,7 +508,7 @@ __global__ __launch_bounds__(CEG_WG, CEG_WAVES) void k_culled(const PlanConst* _
     const int bx0 = bin_of(blx - rc, 0), bx1 = bin_of(bhx + rc, 0);
     const int by0 = bin_of(bly - rc, 1), by1 = bin_of(bhy + rc, 1);
     const int nry = by1 - by0 + 1;
-    const int nrows = (bx1 - bx0 + 1) * nry;
+    const int nrows = active ? (bx1 - bx0 + 1) * nry : 0;
 
     Accum av, ac;
     accum_zero(av);
@@ -645,18 +680,22 @@ __global__ __launch_bounds__(CEG_WG, CEG_WAVES) void k_culled(const PlanConst* _
                     double v, p1, p2, p3;
                     if (FASTEW) {
                         // derivatives_ewald (src/ewald.jl:299-312): erfc(x) = exp(-x^2) erfcx(x)
-                        const double two_over_sqrtpi = 1.1283791670955125739;
+                        // with E = exp(-x^2), g = erfcx(x), k = 2/sqrt(pi):  erfc = E g,  e = k x E, so
+                        //   v  =  (q/r)   E  g
+                        //   p1 = -(q/r^3) E (k x + g)
+                        //   p2 =  (q/r^5) E (k x (3 + 2 x^2) + 3 g)
+                        //   p3 = -(q/r^7) E (k x (15 + 10 x^2 + 4 x^4) + 15 g)
                         const double x = alpha * rr;
                         const double x2 = alpha2 * r2;
                         const double E = exp_neg_tab(s_exp2, -x2);
-                        const double c = E * erfcx_tab(s_erfcx, x, erf_inv_h, erf_mx0);   // erfc(alpha r)
-                        const double e = two_over_sqrtpi * x * E;        // 2 alpha r exp(-alpha^2 r^2)/sqrt(pi)
-                        const double q1 = A.w * rinv;                    // q / r
-                        const double q3 = q1 * inv, q5 = q3 * inv, q7 = q5 * inv;
-                        v = q1 * c;
-                        p1 = -q3 * (e + c);
-                        p2 = q5 * __builtin_fma(e, fma2_sc(x2, 3.0), mul_sc(c, 3.0));
-                        p3 = -q7 * __builtin_fma(e, fma_sc(fma4_sc(x2, 10.0), x2, 15.0), mul_sc(c, 15.0));
+                        const double gx = erfcx_tab(s_erfcx, x, erf_inv_h, erf_mx0);
+                        const double kx = mul_sc(x, 1.1283791670955125739);
+                        const double qe1 = (A.w * rinv) * E;
+                        const double qe3 = qe1 * inv, qe5 = qe3 * inv, qe7 = qe5 * inv;
+                        v = qe1 * gx;
+                        p1 = -qe3 * (kx + gx);
+                        p2 = qe5 * __builtin_fma(kx, fma2_sc(x2, 3.0), mul_sc(gx, 3.0));
+                        p3 = -qe7 * __builtin_fma(kx, fma_sc(fma4_sc(x2, 10.0), x2, 15.0), mul_sc(gx, 15.0));
                     } else {
                         smallest_d2 = min_nonan(smallest_d2, r2);
                         ewald_terms(alpha, A.w, r2, v, p1, p2, p3);
@@ -678,7 +717,62 @@ __global__ __launch_bounds__(CEG_WG, CEG_WAVES) void k_culled(const PlanConst* _
             }
         }
     }
-    if (valid) write_results<MODE>(g, out, POINTS, pidx, i, j, k, av, ac, smallest_d2);
+    if (POINTS) {
+        if (valid) write_results<MODE>(g, out, true, pidx, i, j, k, av, ac, smallest_d2);
+        return;
+    }
+    // ---- grid mode: the NW tiles of a workgroup are consecutive along z (the fastest array
+    // axis), so the workgroup transposes its results through LDS and writes rows of 4*NW
+    // contiguous floats (64 B at NW = 4) per (channel, i, j) instead of 16-B fragments.
+    __shared__ int32_t s_org[NW][4];
+    float* smv = reinterpret_cast<float*>(s_cand_all[wave]);     // 512 floats per wave, staging is done
+    float* smc = reinterpret_cast<float*>(s_lj_all[wave]);
+    __builtin_amdgcn_wave_barrier();
+    if (MODE != MODE_COULOMB) {
+        float r[8];
+        gridpoint8(r, g.delta, out.lambda_vdw, out.thr_vdw, av);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) smv[c * 64 + lane] = r[c];
+    }
+    if (MODE != MODE_VDW) {
+        ac.v = (smallest_d2 < 1.0) ? __builtin_huge_val() : ac.v;      // src/probes.jl:116
+        float r[8];
+        gridpoint8(r, g.delta, out.lambda_coulomb, out.thr_coulomb, ac);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) smc[c * 64 + lane] = r[c];
+    }
+    if (lane == 0) {
+        s_org[wave][0] = active ? i0 : -1;
+        s_org[wave][1] = j0;
+        s_org[wave][2] = k0;
+    }
+    __syncthreads();
+    const int64_t nz = g.dims[2] + 1, ny = g.dims[1] + 1;
+    constexpr int NSEG = 8 * 16 * NW;                 // 16-byte segments per grid in this workgroup
+    for (int seg = threadIdx.x; seg < NSEG; seg += CEG_WG) {
+        const int w = seg % NW;
+        const int row = seg / NW;                     // (channel, li, lj)
+        const int c = row >> 4, li = (row >> 2) & 3, lj = row & 3;
+        const int oi = s_org[w][0];
+        if (oi < 0) continue;
+        const int gi = oi + li, gj = s_org[w][1] + lj, gk = s_org[w][2];
+        if (gi >= out.i_end || gj > g.dims[1] || gk > g.dims[2]) continue;
+        const int64_t idx = (int64_t)gk + nz * ((int64_t)gj + ny * (int64_t)(gi - out.i_origin)) + (int64_t)c * out.channel_stride;
+        const int so = c * 64 + li * 16 + lj * 4;
+        const int nvalid = (g.dims[2] + 1 - gk) < 4 ? (g.dims[2] + 1 - gk) : 4;
+        if (MODE != MODE_COULOMB) {
+            const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(s_cand_all[w]) + so);
+            float* dst = out.vdw + idx;
+            if (nvalid == 4) store_float4_unaligned(dst, v);
+            else { dst[0] = v.x; if (nvalid > 1) dst[1] = v.y; if (nvalid > 2) dst[2] = v.z; }
+        }
+        if (MODE != MODE_VDW) {
+            const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(s_lj_all[w]) + so);
+            float* dst = out.coulomb + idx;
+            if (nvalid == 4) store_float4_unaligned(dst, v);
+            else { dst[0] = v.x; if (nvalid > 1) dst[1] = v.y; if (nvalid > 2) dst[2] = v.z; }
+        }
+    }
 }
 
 // ------------------------------------------------------------------ launchers
