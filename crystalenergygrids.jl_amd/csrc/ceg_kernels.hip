@@ -67,22 +67,25 @@ __device__ __forceinline__ double grid_coord(int i, double size, int dims, doubl
 // ------------------------------------------------------------------ pair potentials
 // derivativesGrid over the rule run of one atom kind (src/interactions.jl:432-472,599-610).
 // `rb`,`re` are wave-uniform.
+template <bool LJONLY = false>
 __device__ __forceinline__ void vdw_terms(const DevRule* __restrict__ rules, int rb, int re, double r2,
-                                          double& v, double& p1, double& p2, double& p3)
+                                          double& v_out, double& p1_out, double& p2_out, double& p3_out)
 {
-    v = p1 = p2 = p3 = 0.0;
+    // local accumulators (plain values, not the caller's references: keeps them in registers)
+    double v = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
     for (int t = rb; t < re; ++t) {
         const int kind = rules[t].kind;
         const double q0 = rules[t].p0, q1 = rules[t].p1, q2 = rules[t].p2, sh = rules[t].shift;
-        if (kind == CEG_LENNARDJONES) {               // :434-441
+        double tv, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+        if (LJONLY || kind == CEG_LENNARDJONES) {     // :434-441 (LJONLY: the plan has no other kind)
             const double inv = 1.0 / r2;
             const double s = q1 * inv;                // sigma^2 / r2
             const double x6 = s * s * s;
             const double inv2 = inv * inv;
-            v += 4.0 * q0 * x6 * (x6 - 1.0) - sh;
-            p1 += 24.0 * q0 * (x6 * (1.0 - 2.0 * x6)) * inv;
-            p2 += 96.0 * q0 * (x6 * (7.0 * x6 - 2.0)) * inv2;
-            p3 += 384.0 * q0 * (x6 * (5.0 - 28.0 * x6)) * (inv2 * inv2);
+            tv = 4.0 * q0 * x6 * (x6 - 1.0);
+            t1 = 24.0 * q0 * (x6 * (1.0 - 2.0 * x6)) * inv;
+            t2 = 96.0 * q0 * (x6 * (7.0 * x6 - 2.0)) * inv2;
+            t3 = 384.0 * q0 * (x6 * (5.0 - 28.0 * x6)) * (inv2 * inv2);
         } else if (kind == CEG_BUCKINGHAM) {          // :447-457
             const double A = q0, B = q1, C = q2;
             const double r4 = r2 * r2;
@@ -90,14 +93,19 @@ __device__ __forceinline__ void vdw_terms(const DevRule* __restrict__ rules, int
             const double r6 = r4 * r2;
             const double x6 = C / r6;
             const double xe = A * exp(-B * r);
-            v += (xe - x6) - sh;
-            p1 += -B * xe / r + 6.0 * x6 / r2;
-            p2 += -48.0 * x6 / r4 + B * xe * (1.0 + B * r) / (r2 * r);
-            p3 += -(3.0 * B * r + B * B * r2 + 3.0) * B * xe * r / r6 + 480.0 * C / (r6 * r6);
+            tv = xe - x6;
+            t1 = -B * xe / r + 6.0 * x6 / r2;
+            t2 = -48.0 * x6 / r4 + B * xe * (1.0 + B * r) / (r2 * r);
+            t3 = -(3.0 * B * r + B * B * r2 + 3.0) * B * xe * r / r6 + 480.0 * C / (r6 * r6);
         } else {                                      // CEG_HARDSPHERE :444-446
-            v += ((r2 < q0) ? __builtin_huge_val() : 0.0) - sh;
+            tv = (r2 < q0) ? __builtin_huge_val() : 0.0;
         }
+        v += tv - sh;
+        p1 += t1;
+        p2 += t2;
+        p3 += t3;
     }
+    v_out = v; p1_out = p1; p2_out = p2; p3_out = p3;
 }
 
 // derivatives_ewald (src/ewald.jl:299-312)
@@ -359,7 +367,7 @@ constexpr int META_KINDMASK = (1 << 24) - 1;
 // position, invmat*d, wrap, mat*f, neighbour search (periodic_distance2_literal) -- and evaluated
 // with the literal radial formulas.  Runs after the hot loop so that its registers do not
 // overlap the hot loop's.
-template <int MODE, bool FASTEW>
+template <int MODE, bool FASTEW, bool LJONLY>
 __device__ __forceinline__ void slow_pairs(const PlanConst* __restrict__ pc, unsigned long long cands, int lane,
                                            double px, double py, double pz,
                                            const int32_t* s_meta, const int32_t* s_atom,
@@ -380,7 +388,7 @@ __device__ __forceinline__ void slow_pairs(const PlanConst* __restrict__ pc, uns
         if (MODE != MODE_COULOMB && (mt & META_HASVDW)) {
             const int kd = mt & META_KINDMASK;
             double v, p1, p2, p3;
-            vdw_terms(pc->rt.rules, pc->rt.offset[kd], pc->rt.offset[kd + 1], r2, v, p1, p2, p3);
+            vdw_terms<LJONLY>(pc->rt.rules, pc->rt.offset[kd], pc->rt.offset[kd + 1], r2, v, p1, p2, p3);
             accum_add(av, v, p1, p2, p3, dx, dy, dz);
         }
         if (MODE != MODE_VDW) {
@@ -713,7 +721,7 @@ __global__ __launch_bounds__(CEG_WG, CEG_WAVES) void k_culled(const PlanConst* _
             // -- the pairs set aside above, one per lane per round
             if (slow != 0ull) {
                 __builtin_amdgcn_wave_barrier();
-                slow_pairs<MODE, FASTEW>(pc, slow, lane, px, py, pz, s_meta, s_atom, s_odd, av, ac, smallest_d2);
+                slow_pairs<MODE, FASTEW, LJONLY>(pc, slow, lane, px, py, pz, s_meta, s_atom, s_odd, av, ac, smallest_d2);
             }
         }
     }
