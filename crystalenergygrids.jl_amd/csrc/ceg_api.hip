@@ -79,7 +79,10 @@ struct ceg_plan {
     PlanConst* d_pc = nullptr;   // device copy of {g, ib, rt, tables}
     double* d_erfcx = nullptr;
     double* d_exp2 = nullptr;
-    bool lj_only = false;        // every kind present has <= 1 rule and it is Lennard-Jones
+    int vdwk = 0;                // hot-loop VdW variant: 0 generic, 1 LJ-only, 2 LJ/Buckingham classes
+    double r_exact2 = CEG_R_EXACT2;
+    std::vector<FastVdw> h_fast;
+    FastVdw* d_fast = nullptr;
     bool fast_ewald = false;     // alpha*cutoff within the erfcx polynomial's domain
 };
 
@@ -172,12 +175,34 @@ int convert_rules(ceg_plan* p, const ceg_rule_t* rules, const int32_t* rule_offs
     }
     p->h_offset[nkinds] = (int32_t)p->h_rules.size();
     p->nkinds = nkinds;
-    p->lj_only = true;
+    // classify every kind for the hot loop of k_culled
+    p->h_fast.assign(nkinds, FastVdw{});
+    bool all_lj = true, all_fast = true;
+    double hs_max2 = 0.0;
     for (int32_t k = 0; k < nkinds; ++k) {
+        const int32_t b = p->h_offset[k], e = p->h_offset[k + 1];
+        FastVdw f{};
+        int nlj = 0, nbuck = 0, nhs = 0, nother = 0;
+        for (int32_t t = b; t < e; ++t) {
+            const DevRule& r = p->h_rules[t];
+            if (r.kind == CEG_LENNARDJONES) { ++nlj; f.p0 = 4.0 * r.p0; f.p1 = r.p1; f.shift += r.shift; }
+            else if (r.kind == CEG_BUCKINGHAM) { ++nbuck; f.p0 = r.p0; f.p1 = r.p1; f.p2 = r.p2; f.shift += r.shift; }
+            else if (r.kind == CEG_HARDSPHERE) { ++nhs; f.shift += r.shift; if (present[k]) hs_max2 = std::max(hs_max2, r.p0); }
+            else ++nother;
+        }
+        if (e == b) f.cls = 0;
+        else if (nlj == 1 && nbuck == 0 && nhs == 0 && nother == 0) f.cls = 1;
+        else if (nbuck == 1 && nlj == 0 && nother == 0) f.cls = 2;
+        else f.cls = 3;
+        p->h_fast[k] = f;
         if (!present[k]) continue;
-        const int32_t n = p->h_offset[k + 1] - p->h_offset[k];
-        if (n > 1 || (n == 1 && p->h_rules[p->h_offset[k]].kind != CEG_LENNARDJONES)) p->lj_only = false;
+        if (f.cls > 1) all_lj = false;
+        if (f.cls > 2) all_fast = false;
     }
+    p->vdwk = all_lj ? 1 : (all_fast ? 2 : 0);
+    // hard spheres must lie inside the exact-path radius for the fast Buckingham class
+    p->r_exact2 = std::max(CEG_R_EXACT2, hs_max2 * (1.0 + 1e-9) + 1e-9);
+    if (p->r_exact2 >= p->g.cutoff2) p->vdwk = 0, p->r_exact2 = CEG_R_EXACT2;
     return CEG_OK;
 }
 
@@ -447,18 +472,25 @@ extern "C" int ceg_plan_create(ceg_plan_t** plan, int32_t device,
         hc.ib = p->ib;
         hc.rt = RuleTable{p->d_rules, p->d_offset, p->nkinds};
         hc.alpha2 = alpha * alpha;
+        hc.r_exact2 = p->r_exact2;
+        if (p->h_fast.empty()) p->h_fast.assign(1, FastVdw{});
+        rc = upload(&p->d_fast, p->h_fast.data(), p->h_fast.size());
+        hc.fastvdw = p->d_fast;
         p->fast_ewald = false;
-        if (p->has_charge && std::isfinite(alpha) && alpha > 0) {
+        if (!rc && ((p->has_charge && std::isfinite(alpha) && alpha > 0) || p->vdwk == 2)) {
             std::vector<double> tab, e2;
             double inv_h = 0, mx0 = 0;
-            if (build_ewald_tables(alpha, cutoff2, tab, e2, &inv_h, &mx0)) {
+            const bool want_ewald = p->has_charge && std::isfinite(alpha) && alpha > 0;
+            const bool ok = build_ewald_tables(want_ewald ? alpha : 0.25, cutoff2, tab, e2, &inv_h, &mx0);
+            if (!ok && p->vdwk == 2) p->vdwk = 0;       // no exp table: Buckingham stays on the generic path
+            if (ok) {
                 rc = upload(&p->d_erfcx, tab.data(), tab.size());
                 if (!rc) rc = upload(&p->d_exp2, e2.data(), e2.size());
                 hc.erfcx_tab = p->d_erfcx;
                 hc.exp2_tab = p->d_exp2;
                 hc.erfcx_inv_h = inv_h;
                 hc.erfcx_mx0_inv_h = mx0;
-                p->fast_ewald = true;
+                p->fast_ewald = want_ewald;
             }
         }
         if (!rc) rc = upload(&p->d_pc, &hc, 1);
@@ -486,6 +518,7 @@ extern "C" int ceg_plan_destroy(ceg_plan_t* p)
     (void)hipFree(p->d_pc);
     (void)hipFree(p->d_erfcx);
     (void)hipFree(p->d_exp2);
+    (void)hipFree(p->d_fast);
     delete p;
     return CEG_OK;
 }
@@ -518,7 +551,7 @@ int run(ceg_plan* p, int mode, const Output& out, const Points& pts, bool culled
     RuleTable rt{p->d_rules, p->d_offset, p->nkinds};
     hipError_t e;
     if (culled) {
-        e = launch_culled(mode, p->d_pc, p->g, p->lj_only, p->fast_ewald, out, pts, stream);
+        e = launch_culled(mode, p->d_pc, p->g, p->vdwk, p->fast_ewald, out, pts, stream);
     } else {
         AtomTable at{p->d_atoms, p->has_rules ? p->d_kind : nullptr, p->natoms};
         e = launch_bruteforce(mode, p->g, at, rt, out, pts, stream);

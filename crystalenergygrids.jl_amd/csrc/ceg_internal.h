@@ -92,10 +92,20 @@ struct ImageBins {
 
 // Plan constants resident in device memory (uploaded once per plan): the culled kernel reads
 // them through a pointer so that only what the hot loop needs lives in scalar registers.
+// Per-kind record of the fast VdW classes of k_culled: cls 0 none, 1 Lennard-Jones
+// {4 eps, sigma^2, -, shift}, 2 Buckingham {A, B, C, shift} (hard spheres inside r_exact ignored).
+struct FastVdw {
+    double p0, p1, p2, shift;
+    int32_t cls;
+    int32_t _pad;
+};
+
 struct PlanConst {
     Geom g;
     ImageBins ib;
     RuleTable rt;
+    const FastVdw* fastvdw;    // [nkinds]
+    double r_exact2;           // pairs closer than this (A^2) take the exact path
     // function tables of the fast real-space Ewald term (ceg_math.h), built per plan
     const double* erfcx_tab;   // [ERFCX_TAB_N * 6]
     const double* exp2_tab;    // [64]  2^(j/64)
@@ -111,7 +121,7 @@ constexpr double CEG_R_EXACT2 = 4.0;     // pairs closer than this (A^2) take th
 // launchers (ceg_kernels.hip)
 hipError_t launch_bruteforce(int mode, const Geom& g, const AtomTable& atoms, const RuleTable& rt,
                              const Output& out, const Points& pts, hipStream_t stream);
-hipError_t launch_culled(int mode, const PlanConst* d_pc, const Geom& g, bool ljonly, bool fastew,
+hipError_t launch_culled(int mode, const PlanConst* d_pc, const Geom& g, int vdwk, bool fastew,
                          const Output& out, const Points& pts, hipStream_t stream);
 
 }  // namespace ceg

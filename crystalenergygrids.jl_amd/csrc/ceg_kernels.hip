@@ -353,10 +353,11 @@ __global__ __launch_bounds__(256) void k_bruteforce(Geom g, AtomTable atoms, Rul
 #define CEG_WG 256       // threads per workgroup of k_culled (one tile per wave)
 #endif
 // pairs closer than this (A^2) take the literal min-image arithmetic in the culled kernel
-constexpr double R_EXACT2 = CEG_R_EXACT2;
+[[maybe_unused]] constexpr double R_EXACT2 = CEG_R_EXACT2;
 static_assert(ERFCX_TAB_N == CEG_ERFCX_TAB_N, "table size mismatch");
 constexpr int META_SIMPLE = 1 << 24;      // image is the wrapped one for every point of the tile
 constexpr int META_HASVDW = 1 << 25;      // the atom's kind has at least one VdW rule
+constexpr int META_BUCK = 1 << 26;        // fast class 2 (Buckingham) instead of 1 (Lennard-Jones)
 constexpr int META_KINDMASK = (1 << 24) - 1;
 
 // ------------------------------------------------------------------ culled kernel
@@ -367,7 +368,7 @@ constexpr int META_KINDMASK = (1 << 24) - 1;
 // position, invmat*d, wrap, mat*f, neighbour search (periodic_distance2_literal) -- and evaluated
 // with the literal radial formulas.  Runs after the hot loop so that its registers do not
 // overlap the hot loop's.
-template <int MODE, bool FASTEW, bool LJONLY>
+template <int MODE, bool FASTEW, bool LJSLOW>
 __device__ __forceinline__ void slow_pairs(const PlanConst* __restrict__ pc, unsigned long long cands, int lane,
                                            double px, double py, double pz,
                                            const int32_t* s_meta, const int32_t* s_atom,
@@ -388,7 +389,7 @@ __device__ __forceinline__ void slow_pairs(const PlanConst* __restrict__ pc, uns
         if (MODE != MODE_COULOMB && (mt & META_HASVDW)) {
             const int kd = mt & META_KINDMASK;
             double v, p1, p2, p3;
-            vdw_terms<LJONLY>(pc->rt.rules, pc->rt.offset[kd], pc->rt.offset[kd + 1], r2, v, p1, p2, p3);
+            vdw_terms<LJSLOW>(pc->rt.rules, pc->rt.offset[kd], pc->rt.offset[kd + 1], r2, v, p1, p2, p3);
             accum_add(av, v, p1, p2, p3, dx, dy, dz);
         }
         if (MODE != MODE_VDW) {
@@ -419,11 +420,14 @@ __device__ __forceinline__ double wave_max(double x)
 // Template flags of k_culled
 //   MODE    what is accumulated (VdW / Coulomb / both in one pass)
 //   POINTS  arbitrary point list (eval_points) instead of 4x4x4 grid tiles
-//   LJONLY  every kind present has at most one rule and it is Lennard-Jones: eps, sigma^2, shift
-//           travel with the candidate through LDS and the pair term uses the shared 1/r
+//   VDWK    0: generic rule runs evaluated with vdw_terms in the hot loop;
+//           1: every kind present has at most one rule and it is Lennard-Jones;
+//           2: every kind present is none / LJ / Buckingham (+ hard spheres that lie inside the
+//              exact-path radius): the per-kind parameters travel with the candidate through LDS
+//              and the pair term uses the shared 1/r (and the table exp for Buckingham)
 //   FASTEW  alpha*cutoff <= ERFCX_XMAX: real-space Ewald term from ceg_math.h (one exp, erfcx
 //           polynomial, no division); otherwise libm-style erfc/exp
-template <int MODE, bool POINTS, bool LJONLY, bool FASTEW>
+template <int MODE, bool POINTS, int VDWK, bool FASTEW>
 __global__ __launch_bounds__(CEG_WG, CEG_WAVES) void k_culled(const PlanConst* __restrict__ pc, Output out, Points pts,
                                                               int tiles_j, int tiles_k, int64_t ntiles)
 {
@@ -450,10 +454,11 @@ __global__ __launch_bounds__(CEG_WG, CEG_WAVES) void k_culled(const PlanConst* _
     int32_t* s_rowprefix = s_rowprefix_all[wave];
     unsigned long long* s_odd = s_odd_all[wave];
 
-    if (FASTEW && MODE != MODE_VDW) {
+    constexpr bool FASTVDW = VDWK != 0;
+    if (FASTEW && MODE != MODE_VDW)
         for (int t = threadIdx.x; t < ERFCX_TAB_N * 6; t += CEG_WG) s_erfcx[t] = pc->erfcx_tab[t];
+    if ((FASTEW && MODE != MODE_VDW) || (VDWK == 2 && MODE != MODE_COULOMB))
         if (threadIdx.x < 64) s_exp2[threadIdx.x] = pc->exp2_tab[threadIdx.x];
-    }
     __syncthreads();
     const int64_t tile_raw = (int64_t)blockIdx.x * NW + wave;
     const bool active = tile_raw < ntiles;          // inactive waves idle until the final barrier
@@ -464,6 +469,7 @@ __global__ __launch_bounds__(CEG_WG, CEG_WAVES) void k_culled(const PlanConst* _
     const RuleTable& rt = pc->rt;
     const int lane = threadIdx.x & 63;
     const double cutoff2 = g.cutoff2;
+    const double r_exact2 = pc->r_exact2;          // >= R_EXACT2, and beyond every hard-sphere radius
     const double alpha = g.alpha;
     const int32_t ortho = g.ortho;
     const double safemin2 = g.safemin2;
@@ -588,12 +594,14 @@ __global__ __launch_bounds__(CEG_WG, CEG_WAVES) void k_culled(const PlanConst* _
                 const double qz = fmax(0.0, fabs(cz - P.z) - hz);
                 keep = (qx * qx + qy * qy + qz * qz) < rc2;
                 bool hasvdw = false;
+                int vclass = 0;
                 if (MODE != MODE_COULOMB && kd >= 0) {
                     const int rb = rt.offset[kd];
                     hasvdw = rt.offset[kd + 1] > rb;
-                    if (LJONLY && hasvdw && keep) {
-                        const DevRule R = rt.rules[rb];
-                        LJ = make_double4(4.0 * R.p0, R.p1, R.shift, 0.0);
+                    if (FASTVDW && hasvdw && keep) {
+                        const FastVdw F = pc->fastvdw[kd];          // class + parameters of this kind
+                        LJ = make_double4(F.p0, F.p1, F.p2, F.shift);
+                        vclass = F.cls;
                     }
                 }
                 if (MODE == MODE_VDW) keep = keep && hasvdw;   // kinds without a rule contribute exact zeros
@@ -610,7 +618,8 @@ __global__ __launch_bounds__(CEG_WG, CEG_WAVES) void k_culled(const PlanConst* _
                     const double e2 = fabs(I[2]) * hx + fabs(I[5]) * hy + fabs(I[8]) * hz + 1e-9;
                     simple = (fabs(f0) + e0 < 0.5) && (fabs(f1) + e1 < 0.5) && (fabs(f2) + e2 < 0.5);
                 }
-                meta = (kd & META_KINDMASK) | (simple ? META_SIMPLE : 0) | (hasvdw ? META_HASVDW : 0);
+                meta = (kd & META_KINDMASK) | (simple ? META_SIMPLE : 0) | (hasvdw ? META_HASVDW : 0) |
+                       (vclass == 2 ? META_BUCK : 0);
             }
             const unsigned long long mask = __ballot(keep);
             const int nkeep = __popcll(mask);
@@ -619,7 +628,7 @@ __global__ __launch_bounds__(CEG_WG, CEG_WAVES) void k_culled(const PlanConst* _
                 const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                                            __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
                 s_cand[slot] = P;
-                if (LJONLY && MODE != MODE_COULOMB) s_lj[slot] = LJ;
+                if (FASTVDW && MODE != MODE_COULOMB) s_lj[slot] = LJ;
                 s_meta[slot] = meta;
                 s_atom[slot] = aidx;
             }
@@ -640,7 +649,7 @@ __global__ __launch_bounds__(CEG_WG, CEG_WAVES) void k_culled(const PlanConst* _
                 // wrapped one.  odd: anything else that could contribute.  (bitwise logic on
                 // purpose: no short-circuit branches in the hot loop)
                 const bool simple = (mt & META_SIMPLE) != 0;
-                const bool in = (r2 >= R_EXACT2) & (r2 < reg_hi) & simple;
+                const bool in = (r2 >= r_exact2) & (r2 < reg_hi) & simple;
                 const bool odd = (!in) & (r2 <= cut_hi);
                 const unsigned long long oddlanes = __ballot(odd);
                 if (oddlanes != 0ull) {              // scalar branch, rarely taken
@@ -653,20 +662,35 @@ __global__ __launch_bounds__(CEG_WG, CEG_WAVES) void k_culled(const PlanConst* _
                 const double dxy = dx * dy, dxz = dx * dz, dyz = dy * dz;
                 const double dxyz = dxz * dy;
                 double rr = 0.0, rinv = 0.0, inv = 0.0;
-                if (LJONLY || (FASTEW && MODE != MODE_VDW)) {
+                if (FASTVDW || (FASTEW && MODE != MODE_VDW)) {
                     fast_sqrt_rsqrt(r2, rr, rinv);
                     inv = rinv * rinv;
                 }
                 if (MODE != MODE_COULOMB && (mt & META_HASVDW)) {
                     double v, p1, p2, p3;
-                    if (LJONLY) {
+                    if (VDWK == 2 && (mt & META_BUCK)) {
+                        // derivativesGrid, Buckingham branch (src/interactions.jl:447-457); a hard
+                        // sphere summed with it is 0 here (its radius lies inside the exact path)
+                        const double4 L = s_lj[q];             // A, B, C, shift
+                        const double Br = L.y * rr;
+                        const double xe = L.x * exp_neg_tab(s_exp2, -Br);
+                        const double inv2 = inv * inv;
+                        const double x6 = L.z * (inv2 * inv);              // C / r^6
+                        const double Bxe = L.y * xe;
+                        const double rinv3 = rinv * inv;
+                        v = (xe - x6) - L.w;
+                        p1 = __builtin_fma(mul_sc(x6, 6.0), inv, -Bxe * rinv);
+                        p2 = __builtin_fma(mul_sc(x6, -48.0), inv2, (Bxe * rinv3) * (1.0 + Br));
+                        p3 = __builtin_fma(mul_sc(x6, 480.0), inv2 * inv,
+                                           -((Bxe * rinv3) * inv) * __builtin_fma(Br, add_sc(Br, 3.0), 3.0));
+                    } else if (FASTVDW) {
                         // derivativesGrid, LJ branch (src/interactions.jl:434-441), with 1/r2 shared
-                        const double4 L = s_lj[q];             // 4 eps, sigma^2, shift
+                        const double4 L = s_lj[q];             // 4 eps, sigma^2, -, shift
                         const double sx = L.y * inv;
                         const double x6 = sx * sx * sx;
                         const double t1 = L.x * x6;                        // 4 eps x6
                         const double t1i = t1 * inv, t1ii = t1i * inv, inv2 = inv * inv;
-                        v = __builtin_fma(t1, x6, -t1) - L.z;              // 4 eps x6 (x6 - 1) - shift
+                        v = __builtin_fma(t1, x6, -t1) - L.w;              // 4 eps x6 (x6 - 1) - shift
                         p1 = mul_sc(t1i * (x6 - 0.5), -12.0);                                // 24 eps x6 (1 - 2 x6)/r^2
                         p2 = mul_sc(t1ii * add_sc(x6, -2.0 / 7.0), 168.0);                   // 96 eps x6 (7 x6 - 2)/r^4
                         p3 = mul_sc((t1ii * inv2) * add_sc(x6, -5.0 / 28.0), -2688.0);       // 384 eps x6 (5 - 28 x6)/r^8
@@ -721,7 +745,7 @@ __global__ __launch_bounds__(CEG_WG, CEG_WAVES) void k_culled(const PlanConst* _
             // -- the pairs set aside above, one per lane per round
             if (slow != 0ull) {
                 __builtin_amdgcn_wave_barrier();
-                slow_pairs<MODE, FASTEW, LJONLY>(pc, slow, lane, px, py, pz, s_meta, s_atom, s_odd, av, ac, smallest_d2);
+                slow_pairs<MODE, FASTEW, VDWK == 1>(pc, slow, lane, px, py, pz, s_meta, s_atom, s_odd, av, ac, smallest_d2);
             }
         }
     }
@@ -815,25 +839,24 @@ hipError_t launch_bruteforce(int mode, const Geom& g, const AtomTable& atoms, co
 }
 
 template <int MODE, bool POINTS>
-static void launch_cull_flags(bool ljonly, bool fastew, dim3 grid, dim3 block, hipStream_t stream,
+static void launch_cull_flags(int vdwk, bool fastew, dim3 grid, dim3 block, hipStream_t stream,
                               const PlanConst* pc, const Output& out, const Points& pts, int tj, int tk,
                               int64_t ntiles)
 {
     // flags that do not matter for a mode are normalised so fewer variants get instantiated
     if (MODE == MODE_VDW) fastew = true;
-    if (MODE == MODE_COULOMB) ljonly = true;
-    if (ljonly && fastew)
-        hipLaunchKernelGGL((k_culled<MODE, POINTS, true, true>), grid, block, 0, stream, pc, out, pts, tj, tk, ntiles);
-    else if (ljonly)
-        hipLaunchKernelGGL((k_culled<MODE, POINTS, true, false>), grid, block, 0, stream, pc, out, pts, tj, tk, ntiles);
-    else if (fastew)
-        hipLaunchKernelGGL((k_culled<MODE, POINTS, false, true>), grid, block, 0, stream, pc, out, pts, tj, tk, ntiles);
-    else
-        hipLaunchKernelGGL((k_culled<MODE, POINTS, false, false>), grid, block, 0, stream, pc, out, pts, tj, tk, ntiles);
+    if (MODE == MODE_COULOMB) vdwk = 1;
+#define CEG_LAUNCH(V, F) hipLaunchKernelGGL((k_culled<MODE, POINTS, V, F>), grid, block, 0, stream, pc, out, pts, tj, tk, ntiles)
+    if (fastew) {
+        if (vdwk == 1) CEG_LAUNCH(1, true); else if (vdwk == 2) CEG_LAUNCH(2, true); else CEG_LAUNCH(0, true);
+    } else {
+        if (vdwk == 1) CEG_LAUNCH(1, false); else if (vdwk == 2) CEG_LAUNCH(2, false); else CEG_LAUNCH(0, false);
+    }
+#undef CEG_LAUNCH
 }
 
 template <bool POINTS>
-static hipError_t launch_cull_t(int mode, const PlanConst* pc, bool ljonly, bool fastew, const Output& out,
+static hipError_t launch_cull_t(int mode, const PlanConst* pc, int vdwk, bool fastew, const Output& out,
                                 const Points& pts, int64_t ntiles, int tj, int tk, hipStream_t stream)
 {
     if (ntiles <= 0) return hipSuccess;
@@ -842,20 +865,20 @@ static hipError_t launch_cull_t(int mode, const PlanConst* pc, bool ljonly, bool
     if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
     dim3 grid((unsigned)nblocks), block(CEG_WG);
     switch (mode) {
-    case MODE_VDW: launch_cull_flags<MODE_VDW, POINTS>(ljonly, fastew, grid, block, stream, pc, out, pts, tj, tk, ntiles); break;
-    case MODE_COULOMB: launch_cull_flags<MODE_COULOMB, POINTS>(ljonly, fastew, grid, block, stream, pc, out, pts, tj, tk, ntiles); break;
-    default: launch_cull_flags<MODE_FUSED, POINTS>(ljonly, fastew, grid, block, stream, pc, out, pts, tj, tk, ntiles); break;
+    case MODE_VDW: launch_cull_flags<MODE_VDW, POINTS>(vdwk, fastew, grid, block, stream, pc, out, pts, tj, tk, ntiles); break;
+    case MODE_COULOMB: launch_cull_flags<MODE_COULOMB, POINTS>(vdwk, fastew, grid, block, stream, pc, out, pts, tj, tk, ntiles); break;
+    default: launch_cull_flags<MODE_FUSED, POINTS>(vdwk, fastew, grid, block, stream, pc, out, pts, tj, tk, ntiles); break;
     }
     return hipGetLastError();
 }
 
-hipError_t launch_culled(int mode, const PlanConst* d_pc, const Geom& g, bool ljonly, bool fastew,
+hipError_t launch_culled(int mode, const PlanConst* d_pc, const Geom& g, int vdwk, bool fastew,
                          const Output& out, const Points& pts, hipStream_t stream)
 {
-    if (pts.xyz) return launch_cull_t<true>(mode, d_pc, ljonly, fastew, out, pts, (pts.n + 63) / 64, 1, 1, stream);
+    if (pts.xyz) return launch_cull_t<true>(mode, d_pc, vdwk, fastew, out, pts, (pts.n + 63) / 64, 1, 1, stream);
     const int ni = out.i_end - out.i_begin;
     const int ti = (ni + 3) / 4, tj = (g.dims[1] + 1 + 3) / 4, tk = (g.dims[2] + 1 + 3) / 4;
-    return launch_cull_t<false>(mode, d_pc, ljonly, fastew, out, pts, (int64_t)ti * tj * tk, tj, tk, stream);
+    return launch_cull_t<false>(mode, d_pc, vdwk, fastew, out, pts, (int64_t)ti * tj * tk, tj, tk, stream);
 }
 
 }  // namespace ceg
