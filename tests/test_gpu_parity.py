@@ -129,6 +129,37 @@ def test_cells_and_min_image_branches(hip_lib, oracle, name, lengths, angles):
     plan.close()
 
 
+@pytest.mark.parametrize("variant", ["generic-vdw", "wide-hard-sphere", "libm-ewald"])
+def test_kernel_variants_off_the_fast_path(hip_lib, oracle, variant):
+    """Template variants the fixtures never select: generic rule runs in the hot loop (a LJ+Buckingham
+    sum has no fast class), a hard sphere wider than the default exact-path radius (the radius must
+    grow past it), and alpha*cutoff beyond the erfcx table's domain (libm-grade erfc/exp)."""
+    mat = mat_from_parameters((27.0, 29.0, 33.0), (94.07, 100.0, 85.0))
+    rng = np.random.default_rng(2024)
+    n = 150
+    pos = random_atoms(mat, n, rng)
+    kinds = rng.integers(1, 5, n)
+    q = rng.uniform(-1.2, 1.9, n)
+    ffkw, alpha = {}, 0.26505830360350674
+    if variant == "generic-vdw":
+        ffkw = {"generic": True}
+    elif variant == "wide-hard-sphere":
+        ffkw = {"hs_radius": 2.7}
+    else:
+        alpha = 0.5                                        # alpha*12 = 6 > 5
+    pv, pc = synthetic_probes(mat, pos, kinds, q, **ffkw)
+    cset = W.grid_setup_with_dims(mat, (21, 19, 23))
+    plan = GridPlan(cset, pv, pc, alpha)
+    ref_v, ref_c = _check_all(plan, pv, pc, alpha, cset, oracle, variant)
+    if variant == "wide-hard-sphere":
+        assert np.isinf(ref_v[:, 0]).any()
+    plan.close()
+    lam, thr = G.vdw_scaling()
+    compare_grids(G.build_vdw_array(pv, cset), oracle.grid_vdw(pv, cset, lam, thr)[0], variant + "/grid")
+    lam, thr = G.coulomb_scaling()
+    compare_grids(G.build_coulomb_array(pc, alpha, cset), oracle.grid_coulomb(pc, alpha, cset, lam, thr)[0], variant + "/cgrid")
+
+
 def test_fast_math_accuracy_single_pair(hip_lib, oracle):
     """One atom, points at r in [2, 12) A in random directions: the culled kernel's hot-loop
     arithmetic (v_rsq/v_rcp Newton steps, table exp, erfcx table, csrc/ceg_math.h) against the

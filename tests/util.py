@@ -10,14 +10,17 @@ from ceg_hip.probes import ProbeSystem
 from ceg_hip.workloads import grid_setup_with_dims
 
 
-def tiny_forcefield(cutoff: float = 12.0) -> ForceField:
-    """kinds: 1 LJ-shifted, 2 Buckingham+HardSphere, 3 none, 4 LJ (other params); probe = 5."""
+def tiny_forcefield(cutoff: float = 12.0, hs_radius: float = 1.5, generic: bool = False) -> ForceField:
+    """kinds: 1 LJ-shifted, 2 Buckingham+HardSphere(hs_radius), 3 none, 4 LJ (other params) -- or,
+    with generic=True, a LJ+Buckingham sum that has no fast class in the kernel; probe = 5."""
     lj = InteractionRule(FF.LennardJones, [107.69, 3.15], 0.0, False)
     lj = InteractionRule(FF.LennardJones, [107.69, 3.15], lj(cutoff), False)
-    buck = InteractionRuleSum([InteractionRule(FF.HardSphere, [1.5, 0.0]), InteractionRule(FF.Buckingham, [5.581e7, 3.985, 9.167e5]),
+    buck = InteractionRuleSum([InteractionRule(FF.HardSphere, [hs_radius, 0.0]), InteractionRule(FF.Buckingham, [5.581e7, 3.985, 9.167e5]),
                                InteractionRule(FF.CoulombEwaldDirect, [0.265, 0.9, -0.9], 0.0, False)])
     none = make_rule(FF.NoInteraction)
     lj2 = InteractionRule(FF.LennardJones, [262.0, 2.396])
+    if generic:
+        lj2 = InteractionRuleSum([InteractionRule(FF.LennardJones, [40.0, 2.9]), InteractionRule(FF.Buckingham, [3.0e6, 3.2, 2.0e4])])
     n = 5
     inter = [[none] * n for _ in range(n)]
     for k, r in enumerate((lj, buck, none, lj2)):
@@ -26,10 +29,10 @@ def tiny_forcefield(cutoff: float = 12.0) -> ForceField:
     return ForceField(inter, sdict, list(sdict), cutoff, "tiny")
 
 
-def synthetic_probes(mat, positions, kinds, charges, cutoff: float = 12.0):
+def synthetic_probes(mat, positions, kinds, charges, cutoff: float = 12.0, **ffkw):
     """(vdw probe, coulomb probe) over an explicit supercell `mat` -- bypasses find_supercell so
     that cells violating the 2*cutoff rule can be tested too."""
-    ff = tiny_forcefield(cutoff)
+    ff = tiny_forcefield(cutoff, **ffkw)
     mat = np.array(mat, dtype=np.float64)
     pos = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, 3)
     kinds = np.asarray(kinds, dtype=np.int64)
