@@ -334,7 +334,7 @@ bool build_ewald_tables(double alpha, double cutoff2, std::vector<double>& tab, 
     tab.assign((size_t)N * 6, 0.0);
     const long double PI = 3.14159265358979323846264338327950288L;
     long double node[6];
-    for (int k = 0; k < 6; ++k) node[k] = 0.5L * cosl(PI * (k + 0.5L) / 6.0L);   // s in [-0.5, 0.5]
+    for (int k = 0; k < 6; ++k) node[k] = 0.5L + 0.5L * cosl(PI * (k + 0.5L) / 6.0L);   // s in [0, 1]
     double worst = 0.0;
     for (int i = 0; i < N; ++i) {
         const long double lo = x0 + i * h;
@@ -342,7 +342,7 @@ bool build_ewald_tables(double alpha, double cutoff2, std::vector<double>& tab, 
         for (int r = 0; r < 6; ++r) {
             long double pw = 1.0L;
             for (int c = 0; c < 6; ++c) { V[r][c] = pw; pw *= node[r]; }
-            V[r][6] = erfcx(lo + (node[r] + 0.5L) * h);
+            V[r][6] = erfcx(lo + node[r] * h);
         }
         for (int c = 0; c < 6; ++c) {                       // Gauss-Jordan with partial pivoting
             int piv = c;
@@ -357,10 +357,10 @@ bool build_ewald_tables(double alpha, double cutoff2, std::vector<double>& tab, 
         }
         for (int c = 0; c < 6; ++c) tab[(size_t)i * 6 + c] = (double)V[c][6];
         for (int t = 0; t <= 8; ++t) {                      // accuracy check with a double Horner
-            const double sl = -0.5 + t / 8.0;
+            const double sl = t / 8.0;
             double pv = tab[(size_t)i * 6 + 5];
             for (int c = 4; c >= 0; --c) pv = pv * sl + tab[(size_t)i * 6 + c];
-            const long double ref = erfcx(lo + ((long double)sl + 0.5L) * h);
+            const long double ref = erfcx(lo + (long double)sl * h);
             worst = std::max(worst, (double)fabsl(((long double)pv - ref) / ref));
         }
     }

@@ -65,7 +65,9 @@ __device__ __forceinline__ double min_nonan(double a, double b)
     return r;
 }
 
-// sqrt(a) and 1/sqrt(a) for a normal positive a: hardware seed + 2 Goldschmidt steps.
+// sqrt(a) and 1/sqrt(a) for a normal positive a: v_rsq_f64 seed + one coupled Goldschmidt step
+// (measured on MI355X: pair terms accurate to 1.3e-13 with one step, 3e-14 with two --
+// tests/test_gpu_parity.py::test_fast_math_accuracy_single_pair; define CEG_RSQ_TWO_ITER for two).
 __device__ __forceinline__ void fast_sqrt_rsqrt(double a, double& s, double& rs)
 {
     const double y = __builtin_amdgcn_rsq(a);
@@ -74,9 +76,11 @@ __device__ __forceinline__ void fast_sqrt_rsqrt(double a, double& s, double& rs)
     double r = __builtin_fma(-h, g, 0.5);
     g = __builtin_fma(g, r, g);
     h = __builtin_fma(h, r, h);
+#ifdef CEG_RSQ_TWO_ITER
     r = __builtin_fma(-h, g, 0.5);
     g = __builtin_fma(g, r, g);
     h = __builtin_fma(h, r, h);
+#endif
     s = g;
     rs = h + h;
 }
@@ -121,7 +125,7 @@ __device__ __forceinline__ double fast_exp_neg(double y)
 
 // ---- LDS-table variants used by the hot loop --------------------------------------------
 // erfcx on [x0, x0 + N*h]: N = ERFCX_TAB_N intervals, degree-5 polynomial in the local
-// coordinate s in [-0.5, 0.5] per interval (6 doubles, 48 B, 16-B aligned), fitted per plan on
+// coordinate s in [0, 1) per interval (6 doubles, 48 B, 16-B aligned), fitted per plan on
 // the host in long double for the plan's [alpha*R_EXACT, alpha*cutoff] (max rel err 2e-15).
 // Coefficients arrive from LDS as fresh VGPRs, so every Horner step is one v_fma/v_fmac.
 constexpr int ERFCX_TAB_N = 128;
@@ -129,10 +133,9 @@ constexpr int ERFCX_TAB_N = 128;
 __device__ __forceinline__ double erfcx_tab(const double* __restrict__ tab, double x, double inv_h, double mx0_inv_h)
 {
     const double u = __builtin_fma(x, inv_h, mx0_inv_h);      // (x - x0)/h in [0, N)
-    const double fi = __builtin_floor(u);
-    unsigned idx = (unsigned)(int)fi;
+    unsigned idx = (unsigned)u;                                 // u >= 0: truncation = floor
     idx = idx < (unsigned)(ERFCX_TAB_N - 1) ? idx : (unsigned)(ERFCX_TAB_N - 1);
-    const double sl = (u - fi) - 0.5;
+    const double sl = __builtin_amdgcn_fract(u);                // local coordinate in [0, 1)
     const double2* c = reinterpret_cast<const double2*>(tab + idx * 6);
     const double2 c01 = c[0], c23 = c[1], c45 = c[2];
     double p = __builtin_fma(c45.y, sl, c45.x);

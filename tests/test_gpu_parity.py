@@ -184,6 +184,7 @@ def test_fast_math_accuracy_single_pair(hip_lib, oracle):
             # local magnitude of its column (+-0.1 A window along r), not against a zero crossing
             env = maximum_filter1d(np.abs(ref), size=81, axis=0, mode="nearest")
             rel = np.abs(got - ref) / env
+            print(f"fast-math max rel err {which} kind {kind}: {rel.max():.2e}")
             assert rel.max() < 1e-12, (which, kind, float(rel.max()), int(np.argmax(rel.max(axis=1))))
         plan.close()
 
