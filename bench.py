@@ -46,6 +46,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--mode", choices=("fused", "vdw", "coulomb"), default="fused")
     ap.add_argument("--algo", choices=("auto", "bruteforce", "culled"), default="auto")
+    ap.add_argument("--chunks", type=int, default=4, help="x-chunks per rank pipelined with the all-gather (N > 1)")
     ap.add_argument("--n", type=int, default=255, help="dims per axis (odd); grid has (n+1)^3 points")
     ap.add_argument("--cpu-rows", type=int, default=-1, help="y-rows per x-plane the CPU baseline times, one plane per thread (-1 = auto ~12 s, 0 = skip)")
     ap.add_argument("--no-check", action="store_true", help="skip the built-in oracle spot check")
@@ -106,7 +107,7 @@ def main():
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
     from ceg_hip import _abi, workloads as W
-    from ceg_hip.distributed import allgather_grid, slab_range
+    from ceg_hip.distributed import PipelinedGather, allgather_grid, cyclic_plan, slab_range
     from ceg_hip.plan import GridPlan
 
     w = W.roofline_workload("Ar", args.n)
@@ -114,11 +115,18 @@ def main():
     npts = nx * ny * nz
     algo = {"auto": _abi.ALGO_AUTO, "bruteforce": _abi.ALGO_BRUTEFORCE, "culled": _abi.ALGO_CULLED}[args.algo]
     plan = GridPlan(w.cset, w.probe_vdw, w.probe_coulomb, w.alpha, device=local_rank)
-    b, e = slab_range(nx, world, rank)
-    n_local = e - b
     need_v = args.mode in ("fused", "vdw")
     need_c = args.mode in ("fused", "coulomb")
-    # full grids live on every rank (that is what the gather produces); rank-local slab buffers
+    plane = ny * nz
+    # N > 1: block-cyclic x-chunks so that each chunk is all-gathered in place (RCCL, side stream)
+    # while the next one is computed; contiguous slabs + one gather at the end if nx does not divide.
+    cyc = cyclic_plan(nx, world, rank, nchunks=args.chunks) if world > 1 else None
+    if cyc is not None:
+        n_local = cyc.n_local
+    else:
+        b, e = slab_range(nx, world, rank)
+        n_local = e - b
+    # full grids live on every rank (that is what the gather produces); rank-local buffers
     full_v = torch.empty((8, nx, ny, nz), dtype=torch.float32, device=dev) if need_v else None
     full_c = torch.empty((8, nx, ny, nz), dtype=torch.float32, device=dev) if need_c else None
     if world == 1:
@@ -126,32 +134,37 @@ def main():
     else:
         loc_v = torch.empty((8, n_local, ny, nz), dtype=torch.float32, device=dev) if need_v else None
         loc_c = torch.empty((8, n_local, ny, nz), dtype=torch.float32, device=dev) if need_c else None
-    cs = n_local * ny * nz if world > 1 else npts
-    origin = b if world > 1 else 0
+    cs = n_local * plane
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
-    def launch():
+    def launch(i_begin, i_end, i_origin):
         s = torch.cuda.current_stream().cuda_stream
         if args.mode == "fused":
-            plan.build_fused(loc_v.data_ptr(), loc_c.data_ptr(), cs, b, e, origin, algo, s)
+            plan.build_fused(loc_v.data_ptr(), loc_c.data_ptr(), cs, i_begin, i_end, i_origin, algo, s)
         elif args.mode == "vdw":
-            plan.build_vdw(loc_v.data_ptr(), cs, b, e, origin, algo, s)
+            plan.build_vdw(loc_v.data_ptr(), cs, i_begin, i_end, i_origin, algo, s)
         else:
-            plan.build_coulomb(loc_c.data_ptr(), cs, b, e, origin, algo, s)
+            plan.build_coulomb(loc_c.data_ptr(), cs, i_begin, i_end, i_origin, algo, s)
+
+    fulls = [t for t in (full_v, full_c) if t is not None]
+    locs = [t for t in (loc_v, loc_c) if t is not None]
+    pipe = PipelinedGather(cyc, fulls, locs) if cyc is not None else None
 
     def step(k=None):
         if k is not None:
             ev0[k].record()
-        launch()
-        if k is not None:
-            ev1[k].record()
-        if world > 1:
-            if need_v:
-                allgather_grid(full_v, loc_v)
-            if need_c:
-                allgather_grid(full_c, loc_c)
+        if pipe is not None:
+            pipe.run(lambda j, ib, ie, off: launch(ib, ie, ib - off),
+                     on_compute_done=(lambda: ev1[k].record()) if k is not None else None)
+        else:
+            launch(b, e, b if world > 1 else 0)
+            if k is not None:
+                ev1[k].record()
+            if world > 1:
+                for full, loc in zip(fulls, locs):
+                    allgather_grid(full, loc)
 
     for _ in range(args.warmup):
         step()
@@ -200,6 +213,7 @@ def main():
         # algorithmic (compulsory) HBM bytes per launch: 32 B per point per grid written + the
         # image/atom table read once (32 B position+charge, 4 B kind)  -- SURVEY §8d
         slab_pts = n_local * ny * nz
+        nlaunch = cyc.nchunks if cyc is not None else 1
         alg_bytes = 32.0 * slab_pts * ngrids + 36.0 * max(plan.num_images, w.natoms)
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         min_flops = slab_pts * N_CUT * ((F_DIST + F_LJ if need_v else 0.0) + (F_DIST + F_EWALD if need_c else 0.0)
@@ -220,11 +234,12 @@ def main():
             "config": {"workload": w.name, "grid_points": npts, "framework_atoms": w.natoms,
                        "lattice_images": plan.num_images, "grids_per_step": ngrids, "mode": args.mode,
                        "algo": "culled" if (algo != _abi.ALGO_BRUTEFORCE and plan.can_cull) else "bruteforce",
-                       "parallelism": f"x-slab sharding over {world} GPU(s)" + (", RCCL all-gather of slabs" if world > 1 else "")},
+                       "parallelism": (f"block-cyclic x-chunks over {world} GPUs ({cyc.nchunks} chunks of {cyc.m} planes per rank), each chunk all-gathered in place over RCCL while the next is computed" if cyc is not None
+                                       else f"x-slab sharding over {world} GPU(s)" + (", RCCL all-gather of slabs" if world > 1 else ""))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": f"k_culled<{args.mode}>" if plan.can_cull and algo != _abi.ALGO_BRUTEFORCE else f"k_bruteforce<{args.mode}>",
-                         "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes,
+                         "kernel_ms": kern_ms, "launches_per_step": nlaunch, "algorithmic_bytes": alg_bytes,
                          "note": "HBM is not the binding roofline of this path (>=1e3 flop/B); see roofline_fp64"},
             "roofline_fp64": {"bound": "fp64-valu", "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": tflops / FP64_VALU_PEAK_TFLOPS,

@@ -42,6 +42,19 @@ def _worker(rank, world, port, spacing, outdir):
         full = torch.full((8, nx, ny, nz), float("nan"), dtype=torch.float32)
         allgather_grid(full, local)
         np.save(os.path.join(outdir, f"rank{rank}.npy"), full.numpy())
+        # block-cyclic chunks gathered in place (the pipelined path of bench.py), when nx divides
+        from ceg_hip.distributed import PipelinedGather, cyclic_plan
+        cyc = cyclic_plan(nx, world, rank, nchunks=4, align=1)
+        if cyc is not None:
+            loc = torch.full((8, cyc.n_local, ny, nz), float("nan"), dtype=torch.float32)
+            full2 = torch.full((8, nx, ny, nz), float("nan"), dtype=torch.float32)
+
+            def launch(j, ib, ie, off):
+                gg, _ = O.grid_vdw(w.probe_vdw, w.cset, lam, thr, ib, ie, nthreads=2)
+                loc[:, off:off + (ie - ib)] = torch.from_numpy(gg[:, ib:ie])
+
+            PipelinedGather(cyc, [full2], [loc]).run(launch)
+            np.save(os.path.join(outdir, f"rank{rank}_cyclic.npy"), full2.numpy())
     finally:
         dist.destroy_process_group()
 
@@ -55,6 +68,26 @@ def test_slab_gather_gloo(tmp_path, world, spacing, oracle):
     lam, thr = G.vdw_scaling()
     ref, _ = oracle.grid_vdw(w.probe_vdw, w.cset, lam, thr)
     assert not np.isnan(ref).any()
+    ncyc = 0
     for r in range(world):
         got = np.load(tmp_path / f"rank{r}.npy")
         np.testing.assert_array_equal(got, ref)
+        f = tmp_path / f"rank{r}_cyclic.npy"
+        if f.exists():
+            np.testing.assert_array_equal(np.load(f), ref)
+            ncyc += 1
+    assert ncyc in (0, world)
+
+
+def test_cyclic_plan_shapes():
+    from ceg_hip.distributed import cyclic_plan
+    for world in (1, 2, 4, 8):
+        p = cyclic_plan(256, world, world - 1, nchunks=4)
+        assert p is not None and p.nchunks == 4 and p.m == 256 // (4 * world) and p.n_local * world == 256
+        covered = sorted(x for r in range(world) for j in range(p.nchunks)
+                         for x in range(*cyclic_plan(256, world, r, 4).chunk(j)))
+        assert covered == list(range(256))
+        assert p.block(p.nchunks - 1)[1] == 256
+    assert cyclic_plan(218, 8, 0) is None            # falls back to contiguous slabs
+    q = cyclic_plan(64, 8, 3, nchunks=4)             # only 2 chunks keep m a multiple of the tile edge
+    assert q.nchunks == 2 and q.m == 4

@@ -325,6 +325,43 @@ def test_slabs_fused_and_layouts(hip_lib, oracle):
     plan.close()
 
 
+def test_block_cyclic_chunk_launches(hip_lib):
+    """The launch pattern of bench.py at N > 1 (ceg_hip.distributed.CyclicPlan): every rank's chunks,
+    written into compact rank-local buffers with the (i_begin, i_origin) arithmetic of the bench,
+    then placed like the in-place all-gather would place them, reproduce the single-launch grid
+    bit for bit (chunks start on tile boundaries)."""
+    import torch
+    from ceg_hip.distributed import cyclic_plan
+    w = W.fixture_workload("CHA_1.4_3b4eeb96", "Ar", 0.5, dims=(63, 61, 57))        # nx = 64
+    nx, ny, nz = w.cset.npoints
+    plane = ny * nz
+    plan = GridPlan(w.cset, w.probe_vdw, w.probe_coulomb, w.alpha)
+    dev = torch.device("cuda", 0)
+    s = torch.cuda.current_stream().cuda_stream
+    ref_v = torch.empty((8, nx, ny, nz), dtype=torch.float32, device=dev)
+    ref_c = torch.empty_like(ref_v)
+    plan.build_fused(ref_v.data_ptr(), ref_c.data_ptr(), nx * plane, 0, nx, 0, CULLED, s)
+    for world in (2, 4):
+        full_v = torch.full_like(ref_v, float("nan"))
+        full_c = torch.full_like(ref_c, float("nan"))
+        for rank in range(world):
+            cyc = cyclic_plan(nx, world, rank, nchunks=4)
+            assert cyc is not None and cyc.m % 4 == 0
+            loc_v = torch.full((8, cyc.n_local, ny, nz), float("nan"), dtype=torch.float32, device=dev)
+            loc_c = torch.full_like(loc_v, float("nan"))
+            for j in range(cyc.nchunks):
+                b, e = cyc.chunk(j)
+                off = j * cyc.m
+                plan.build_fused(loc_v.data_ptr(), loc_c.data_ptr(), cyc.n_local * plane, b, e, b - off, CULLED, s)
+            torch.cuda.synchronize()
+            for j in range(cyc.nchunks):
+                b, e = cyc.chunk(j)
+                full_v[:, b:e] = loc_v[:, j * cyc.m:(j + 1) * cyc.m]
+                full_c[:, b:e] = loc_c[:, j * cyc.m:(j + 1) * cyc.m]
+        assert torch.equal(full_v, ref_v) and torch.equal(full_c, ref_c)
+    plan.close()
+
+
 # ------------------------------------------------------------------ BASELINE size, size-independent properties
 def test_roofline_workload_properties(hip_lib, oracle):
     """256^3 x 11 664 atoms (BASELINE config 3).  The oracle would need ~15 CPU-hours for the full
