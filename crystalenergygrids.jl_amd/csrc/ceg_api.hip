@@ -38,6 +38,9 @@ static int fail(int code, const char* fmt, ...)
                         __FILE__, __LINE__);                                               \
     } while (0)
 
+// used by the other translation units (ceg_interp.hip) to report through ceg_last_error()
+extern "C" void ceg_set_last_error_(const char* msg) { g_err = msg ? msg : ""; }
+
 extern "C" int ceg_abi_version(void) { return CEG_ABI_VERSION; }
 
 extern "C" const char* ceg_last_error(void) { return g_err.c_str(); }

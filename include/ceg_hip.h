@@ -199,6 +199,38 @@ CEG_API int ceg_plan_build_fused(ceg_plan_t* plan,
 CEG_API int ceg_plan_eval_points(ceg_plan_t* plan, int32_t which, int32_t algo,
                          const double* points, int64_t npoints, double* out);
 
+/* ---- grid consumer: batched tricubic interpolation --------------- */
+/*
+ * interpolate_grid (src/grids.jl:212-273) for many points at once on a device-resident
+ * EnergyGrid: offsetpoint/wrap_atom (src/coordinates.jl:58-66), 8 corners x 8 channels gather
+ * (grids.jl:227-244), the VdW "any corner value > 5e6 -> 1e100 K" rule (:245-248) and the
+ * tricubic polynomial (:252-258, evaluated as the equivalent tensor product of cubic Hermite
+ * bases instead of the 64x64 COEFF product).  This is what framework_interactions
+ * (src/montecarlo.jl:490-504) and energy_grid (src/grids.jl:394-419) call per atom.
+ *
+ *  grid        [8*(dims[0]+1)*(dims[1]+1)*(dims[2]+1)] float, layout as above, ALREADY in K
+ *              (i.e. after parse_grid's `grid .*= GRID_TO_KELVIN`, grids.jl:78);
+ *              host memory if grid_on_device == 0 (copied), else a device pointer that is
+ *              used in place and must outlive the handle
+ *  mat,invmat  UNIT-cell matrix of csetup.cell (not the supercell), column-major
+ *  is_vdw      1 for a VdW grid (ewald_precision == Inf): enables the 5e6 rule
+ */
+typedef struct ceg_interp ceg_interp_t;
+
+CEG_API int ceg_interp_create(ceg_interp_t** handle, int32_t device,
+                              const float* grid, int32_t grid_on_device,
+                              const int32_t dims[3], const double size[3], const double shift[3],
+                              const double mat[9], const double invmat[9], int32_t is_vdw);
+CEG_API int ceg_interp_destroy(ceg_interp_t* handle);
+/* points [3*n] cartesian A, out [n] K; host memory, synchronous */
+CEG_API int ceg_interp_points(ceg_interp_t* handle, const double* points, int64_t npoints, double* out);
+/* device memory on the handle's device, asynchronous on `stream` */
+CEG_API int ceg_interp_points_device(ceg_interp_t* handle, const double* d_points, int64_t npoints,
+                                     double* d_out, void* stream);
+/* in-place `grid .*= scale` in Float32 on device memory (parse_grid, grids.jl:78), so a grid
+ * that was just built by ceg_plan_build_* can be interpolated without leaving the GPU */
+CEG_API int ceg_scale_grid_device(float* d_grid, int64_t nfloats, double scale, int32_t device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

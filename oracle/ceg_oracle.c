@@ -432,6 +432,78 @@ ORACLE_API int oracle_points_coulomb(
     return 0;
 }
 
+/* ---- src/grids.jl:212-273 interpolate_grid(g, point) with src/coordinates.jl:58-66
+ * (wrap_atom, offsetpoint).  grid: float[8][nx][ny][nz] already in K; mat/invmat: unit-cell
+ * matrix (column-major); coeff: the 64x64 matrix COEFF of src/constants.jl:24-89, row-major,
+ * passed in by the caller.  Literal evaluation: a = COEFF*X, then the 64-term polynomial in the
+ * reference's loop order. */
+ORACLE_API double oracle_interpolate_grid(const float* grid, const int32_t dims[3], const double size[3],
+                                          const double shift[3], const double mat[9], const double invmat[9],
+                                          int is_vdw, const double* coeff, const double point[3])
+{
+    double abc[3], frac[3], np_[3], shifted[3];
+    matvec3(abc, invmat, point);                               /* coordinates.jl:59 */
+    for (int i = 0; i < 3; ++i) frac[i] = abc[i] - floor(abc[i]);
+    matvec3(np_, mat, frac);                                   /* :60 */
+    for (int i = 0; i < 3; ++i)                                /* :65 */
+        shifted[i] = (np_[i] - shift[i]) * (double)dims[i] / size[i] + 1;
+    const int64_t nx = dims[0] + 1, ny = dims[1] + 1, nz = dims[2] + 1;
+    const int64_t ext[3] = {nx, ny, nz};
+    int64_t p0[3], p1[3];
+    double r[3];
+    for (int i = 0; i < 3; ++i) {                              /* grids.jl:216-219 */
+        p0[i] = (int64_t)floor(shifted[i]);
+        p1[i] = p0[i] + (p0[i] != ext[i]);
+        r[i] = shifted[i] - (double)p0[i];
+    }
+    const int64_t x0 = p0[0] - 1, y0 = p0[1] - 1, z0 = p0[2] - 1, x1 = p1[0] - 1, y1 = p1[1] - 1, z1 = p1[2] - 1;
+    const int64_t cs = nx * ny * nz;
+#define G_(c, x, y, z) grid[(c) * cs + ((x) * ny + (y)) * nz + (z)]
+    float X[64];
+    for (int c = 0; c < 8; ++c) {                              /* :227-244 */
+        X[8 * c + 0] = G_(c, x0, y0, z0); X[8 * c + 1] = G_(c, x1, y0, z0);
+        X[8 * c + 2] = G_(c, x0, y1, z0); X[8 * c + 3] = G_(c, x1, y1, z0);
+        X[8 * c + 4] = G_(c, x0, y0, z1); X[8 * c + 5] = G_(c, x1, y0, z1);
+        X[8 * c + 6] = G_(c, x0, y1, z1); X[8 * c + 7] = G_(c, x1, y1, z1);
+    }
+#undef G_
+    if (is_vdw)                                                /* :245-248 */
+        for (int t = 0; t < 8; ++t)
+            if (X[t] > 5e6f) return 1e100;
+    double a[64];
+    for (int row = 0; row < 64; ++row) {                       /* :252 mul!(a, COEFF, X) */
+        double acc = 0.0;
+        for (int col = 0; col < 64; ++col) acc += coeff[row * 64 + col] * (double)X[col];
+        a[row] = acc;
+    }
+    const double rx = r[0], ry = r[1], rz = r[2];
+    const double rx2 = rx * rx, ry2 = ry * ry, rz2 = rz * rz;
+    const double rxs[4] = {1.0, rx, rx2, rx2 * rx};
+    const double rys[4] = {1.0, ry, ry2, ry2 * ry};
+    const double rzs[4] = {1.0, rz, rz2, rz2 * rz};
+    double ret = 0.0;
+    for (int k = 0; k < 4; ++k)                                /* :256-258 */
+        for (int j = 0; j < 4; ++j)
+            for (int i = 0; i < 4; ++i)
+                ret += a[i + 4 * j + 16 * k] * rxs[i] * rys[j] * rzs[k];
+    return ret;
+}
+
+ORACLE_API void oracle_interpolate_points(const float* grid, const int32_t dims[3], const double size[3],
+                                          const double shift[3], const double mat[9], const double invmat[9],
+                                          int is_vdw, const double* coeff, const double* points, int64_t n,
+                                          double* out, int32_t nthreads)
+{
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < n; ++p)
+        out[p] = oracle_interpolate_grid(grid, dims, size, shift, mat, invmat, is_vdw, coeff, points + 3 * p);
+}
+
 ORACLE_API int oracle_max_threads(void)
 {
 #ifdef _OPENMP

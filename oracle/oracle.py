@@ -65,6 +65,8 @@ def lib() -> C.CDLL:
         l.oracle_points_coulomb.restype = C.c_int
         l.oracle_points_coulomb.argtypes = [_dp, _dp, C.c_int64, _dp, _dp, C.c_int, C.c_double, C.c_double,
                                             C.c_double, _dp, C.c_int64, _dp, C.c_int32]
+        l.oracle_interpolate_points.restype = None
+        l.oracle_interpolate_points.argtypes = [_fp, _i32p, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp, C.c_int64, _dp, C.c_int32]
         l.oracle_max_threads.restype = C.c_int
         l.oracle_max_threads.argtypes = []
         _lib = l
@@ -193,6 +195,25 @@ def derivatives_grid(rules: np.ndarray, r2: float) -> np.ndarray:
 def derivatives_ewald(alpha: float, charge: float, r2: float) -> np.ndarray:
     out = np.empty(4)
     lib().oracle_derivatives_ewald(alpha, charge, r2, _d(out))
+    return out
+
+
+def interpolate_points(g, points, nthreads=0) -> np.ndarray:
+    """interpolate_grid (grids.jl:212-273) of an EnergyGrid (values in K) at many points, literal
+    COEFF*X evaluation; the COEFF matrix comes from ceg_hip.constants.tricubic_coeff()."""
+    import math
+    from ceg_hip.constants import tricubic_coeff
+    cs = g.csetup
+    grid = np.ascontiguousarray(g.grid, dtype=np.float32)
+    dims = np.ascontiguousarray(cs.dims, dtype=np.int32)
+    size = np.ascontiguousarray(cs.size, dtype=np.float64)
+    shift = np.ascontiguousarray(cs.shift, dtype=np.float64)
+    coeff = np.ascontiguousarray(tricubic_coeff(), dtype=np.float64)
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    out = np.empty(len(pts), dtype=np.float64)
+    lib().oracle_interpolate_points(grid.ctypes.data_as(_fp), dims.ctypes.data_as(_i32p), _d(size), _d(shift),
+                                    _d(_cm(cs.cell.mat)), _d(_cm(cs.cell.invmat)),
+                                    1 if g.ewald_precision == math.inf else 0, _d(coeff), _d(pts), len(pts), _d(out), nthreads)
     return out
 
 

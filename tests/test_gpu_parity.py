@@ -362,6 +362,58 @@ def test_block_cyclic_chunk_launches(hip_lib):
     plan.close()
 
 
+# ------------------------------------------------------------------ row f1: batched interpolation
+def test_interpolation_batch_vs_oracle(hip_lib, oracle):
+    """GPU interpolate_grid (ceg_interp_*) against the literal COEFF*X oracle: random points far
+    outside the cell (wrap), points exactly on grid nodes and on the upper faces (p0 == extent
+    guard), VdW blocking rule, Coulomb-style grid without it; then the device-resident path:
+    grid built on the GPU, scaled in place like parse_grid, interpolated without leaving the GPU."""
+    import torch
+    from ceg_hip.interp import GridInterpolator
+    for fwname, atom, sp in (("CIT-7", "Ar", 0.4), ("CHA_1.4_3b4eeb96", "Na", 0.8)):
+        w = W.fixture_workload(fwname, atom, sp)
+        nx, ny, nz = w.cset.npoints
+        rng = np.random.default_rng(5)
+        nodes = np.stack([rng.integers(0, nx, 200), rng.integers(0, ny, 200), rng.integers(0, nz, 200)], axis=1)
+        nodes[:20] = [nx - 1, ny - 1, nz - 1]
+        nodes[20:40, 0] = nx - 1
+        on_nodes = nodes * w.cset.size / w.cset.dims + w.cset.shift
+        pts = np.concatenate([rng.uniform(-70, 90, (4000, 3)), on_nodes, w.cset.shift + rng.uniform(0, 1, (2000, 3)) * w.cset.size])
+        gv = G.build_vdw_array(w.probe_vdw, w.cset)
+        gc = G.build_coulomb_array(w.probe_coulomb, w.alpha, w.cset)
+        for grid, prec in ((gv, math.inf), (gc, 1e-6)):
+            gk = (grid.astype(np.float64) * ceg.GRID_TO_KELVIN).astype(np.float32)
+            eg = G.EnergyGrid(w.cset, w.probe_vdw.num_supercell, prec, True, gk)
+            ref = oracle.interpolate_points(eg, pts)
+            it = GridInterpolator(eg)
+            got = it(pts)
+            it.close()
+            assert np.array_equal(got == 1e100, ref == 1e100), "blocked pattern differs"
+            m = ref != 1e100
+            scale = np.median(np.abs(ref[m]))
+            assert np.all(np.abs(got[m] - ref[m]) <= 1e-9 * np.abs(ref[m]) + 1e-10 * scale)
+            assert (prec == math.inf) == bool((ref == 1e100).any())
+        # device-resident: build -> scale in place -> interpolate, no host round trip of the grid
+        plan = GridPlan(w.cset, w.probe_vdw, None, 0.0)
+        dev = torch.device("cuda", 0)
+        d_grid = torch.empty((8, nx, ny, nz), dtype=torch.float32, device=dev)
+        s = torch.cuda.current_stream().cuda_stream
+        plan.build_vdw(d_grid.data_ptr(), nx * ny * nz, 0, nx, 0, AUTO, s)
+        _abi.check(hip_lib, hip_lib.ceg_scale_grid_device(d_grid.data_ptr(), d_grid.numel(), ceg.GRID_TO_KELVIN, 0, s))
+        torch.cuda.synchronize()
+        gk = (gv.astype(np.float64) * ceg.GRID_TO_KELVIN).astype(np.float32)
+        assert np.array_equal(d_grid.cpu().numpy(), gk, equal_nan=True)           # parse_grid's Float32 scaling, bitwise
+        eg = G.EnergyGrid(w.cset, w.probe_vdw.num_supercell, math.inf, True, gk)
+        it = GridInterpolator(eg, device_ptr=d_grid.data_ptr())
+        d_pts = torch.from_numpy(pts).to(dev)
+        d_out = torch.empty(len(pts), dtype=torch.float64, device=dev)
+        it.on_device(d_pts.data_ptr(), len(pts), d_out.data_ptr(), s)
+        torch.cuda.synchronize()
+        host = GridInterpolator(eg)
+        assert np.array_equal(d_out.cpu().numpy(), host(pts))
+        host.close(); it.close(); plan.close()
+
+
 # ------------------------------------------------------------------ BASELINE size, size-independent properties
 def test_roofline_workload_properties(hip_lib, oracle):
     """256^3 x 11 664 atoms (BASELINE config 3).  The oracle would need ~15 CPU-hours for the full

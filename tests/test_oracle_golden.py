@@ -51,3 +51,24 @@ def test_oracle_grid_driver_equals_pointwise(oracle):
     lamc, thrc = G.coulomb_scaling()
     gc, rawc = oracle.grid_coulomb(w.probe_coulomb, w.alpha, w.cset, lamc, thrc, i_begin=1, i_end=3, want_raw=True)
     assert np.isnan(gc[:, 0]).all() and np.isnan(gc[:, 3:]).all() and not np.isnan(gc[0, 1:3]).any()
+
+
+def test_oracle_interpolation_equals_host_mirror(oracle):
+    """Row f1: the C restatement of interpolate_grid (literal COEFF*X) against the Python mirror
+    that tests/test_reference_pins.py pins to the reference's literals."""
+    import math
+    import ceg_hip as ceg
+    w = W.fixture_workload("CIT-7", "Ar", 1.0)
+    lam, thr = G.vdw_scaling()
+    grid, _ = oracle.grid_vdw(w.probe_vdw, w.cset, lam, thr)
+    gk = (grid.astype(np.float64) * ceg.GRID_TO_KELVIN).astype(np.float32)
+    rng = np.random.default_rng(0)
+    pts = rng.uniform(-20, 40, (300, 3))
+    for prec in (math.inf, 1e-6):                 # VdW grid (blocking rule on) / Coulomb-style grid (off)
+        eg = G.EnergyGrid(w.cset, (2, 3, 3), prec, True, gk)
+        a = oracle.interpolate_points(eg, pts)
+        b = np.array([G.interpolate_grid(eg, p) for p in pts])
+        assert np.array_equal(a == 1e100, b == 1e100)
+        m = a != 1e100
+        np.testing.assert_allclose(a[m], b[m], rtol=1e-11, atol=1e-9)
+        assert (prec == math.inf) == bool((a == 1e100).any())
