@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256) void k_interpolate(InterpGeom g, const float* 
         p0[a] = i0;
         p1[a] = i0 + (i0 != ext[a] ? 1 : 0);
     }
-    const int64_t sx = (int64_t)ny * nz, sy = nz, cs = (int64_t)nx * ny * nz;
+    // node-major layout [x][y][z][8 channels]: the 8 channels of a corner are 32 contiguous bytes and
+    // the two z neighbours of an (x, y) row 64 contiguous bytes
+    const int64_t sx = (int64_t)ny * nz, sy = nz;
     const int64_t bx[2] = {(int64_t)(p0[0] - 1) * sx, (int64_t)(p1[0] - 1) * sx};
     const int64_t by[2] = {(int64_t)(p0[1] - 1) * sy, (int64_t)(p1[1] - 1) * sy};
     const int z0 = p0[2] - 1, z1 = p1[2] - 1;
@@ -89,26 +91,40 @@ __global__ __launch_bounds__(256) void k_interpolate(InterpGeom g, const float* 
 
     double ret = 0.0;
     bool blocked = false;
-    // channels: value, dx, dy, dz, dxy, dxz, dyz, dxyz  (derivatives pre-scaled by the grid step)
+    const float4* g4 = reinterpret_cast<const float4*>(grid);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const int ox = (c == 1 || c == 4 || c == 5 || c == 7) ? 1 : 0;
-        const int oy = (c == 2 || c == 4 || c == 6 || c == 7) ? 1 : 0;
-        const int oz = (c == 3 || c == 5 || c == 6 || c == 7) ? 1 : 0;
-        const float* gc = grid + c * cs;
+    for (int ax = 0; ax < 2; ++ax)
 #pragma unroll
-        for (int ax = 0; ax < 2; ++ax)
+        for (int ay = 0; ay < 2; ++ay) {
+            const int64_t node0 = bx[ax] + by[ay] + z0, node1 = bx[ax] + by[ay] + z1;
+            const float4 a0 = g4[2 * node0], b0 = g4[2 * node0 + 1];      // channels 0-3, 4-7 at z0
+            const float4 a1 = g4[2 * node1], b1 = g4[2 * node1 + 1];      // ... at z1
+            blocked = blocked || (a0.x > 5e6f) || (a1.x > 5e6f);
+            // channels: value, dx, dy, dz, dxy, dxz, dyz, dxyz (derivatives pre-scaled by the grid step)
+            const double v0[8] = {a0.x, a0.y, a0.z, a0.w, b0.x, b0.y, b0.z, b0.w};
+            const double v1[8] = {a1.x, a1.y, a1.z, a1.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-            for (int ay = 0; ay < 2; ++ay) {
-                const float* row = gc + bx[ax] + by[ay];
-                const double v0 = (double)row[z0], v1 = (double)row[z1];
-                if (c == 0) blocked = blocked || (v0 > 5e6) || (v1 > 5e6);
+            for (int c = 0; c < 8; ++c) {
+                const int ox = (c == 1 || c == 4 || c == 5 || c == 7) ? 1 : 0;
+                const int oy = (c == 2 || c == 4 || c == 6 || c == 7) ? 1 : 0;
+                const int oz = (c == 3 || c == 5 || c == 6 || c == 7) ? 1 : 0;
                 const double wxy = wx[ox][ax] * wy[oy][ay];
-                ret += wxy * (v0 * wz[oz][0] + v1 * wz[oz][1]);
+                ret += wxy * (v0[c] * wz[oz][0] + v1[c] * wz[oz][1]);
             }
-    }
+        }
     // VdW grid with any corner value > 5e6 -> 1e100 K                             grids.jl:245-248
     out[t] = (g.is_vdw && blocked) ? 1e100 : ret;
+}
+
+// [c][x][y][z] (the reference's array) -> [x][y][z][c]
+__global__ void k_to_node_major(const float* __restrict__ in, float* __restrict__ out, int64_t nodes)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nodes * 8; i += stride) {
+        const int64_t node = i >> 3;
+        const int c = (int)(i & 7);
+        out[i] = in[c * nodes + node];
+    }
 }
 
 __global__ void k_scale(float* __restrict__ x, int64_t n, double scale)
@@ -176,19 +192,30 @@ extern "C" int ceg_interp_create(ceg_interp_t** handle, int32_t device, const fl
     for (int a = 0; a < 9; ++a) { h->g.mat[a] = mat[a]; h->g.invmat[a] = invmat[a]; }
     for (int a = 0; a < 3; ++a) { h->g.size[a] = size[a]; h->g.shift[a] = shift[a]; h->g.dims[a] = dims[a]; }
     h->g.is_vdw = is_vdw ? 1 : 0;
-    const size_t n = (size_t)8 * (dims[0] + 1) * (dims[1] + 1) * (dims[2] + 1);
-    if (grid_on_device) {
-        h->d_grid = grid;
-    } else {
-        if (hipMalloc((void**)&h->owned, n * sizeof(float)) != hipSuccess ||
-            hipMemcpy(h->owned, grid, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
-            if (h->owned) (void)hipFree(h->owned);
-            delete h;
-            if (prev >= 0) (void)hipSetDevice(prev);
-            return ierr(CEG_ERR_HIP, "could not upload the grid");
-        }
-        h->d_grid = h->owned;
+    const size_t nodes = (size_t)(dims[0] + 1) * (dims[1] + 1) * (dims[2] + 1);
+    const size_t n = 8 * nodes;
+    // the handle owns a node-major copy [x][y][z][8]: one interpolation touches 8 x 64 contiguous
+    // bytes instead of 32 scattered 8-byte pairs of the channel-major array
+    float* staged = nullptr;
+    const float* src = grid;
+    bool ok = hipMalloc((void**)&h->owned, n * sizeof(float)) == hipSuccess;
+    if (ok && !grid_on_device) {
+        ok = hipMalloc((void**)&staged, n * sizeof(float)) == hipSuccess &&
+             hipMemcpy(staged, grid, n * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+        src = staged;
     }
+    if (ok) {
+        hipLaunchKernelGGL(k_to_node_major, dim3(4096), dim3(256), 0, nullptr, src, h->owned, (int64_t)nodes);
+        ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    }
+    if (staged) (void)hipFree(staged);
+    if (!ok) {
+        if (h->owned) (void)hipFree(h->owned);
+        delete h;
+        if (prev >= 0) (void)hipSetDevice(prev);
+        return ierr(CEG_ERR_HIP, "could not stage the grid on the device");
+    }
+    h->d_grid = h->owned;
     if (prev >= 0) (void)hipSetDevice(prev);
     *handle = h;
     return CEG_OK;

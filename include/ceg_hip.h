@@ -210,8 +210,8 @@ CEG_API int ceg_plan_eval_points(ceg_plan_t* plan, int32_t which, int32_t algo,
  *
  *  grid        [8*(dims[0]+1)*(dims[1]+1)*(dims[2]+1)] float, layout as above, ALREADY in K
  *              (i.e. after parse_grid's `grid .*= GRID_TO_KELVIN`, grids.jl:78);
- *              host memory if grid_on_device == 0 (copied), else a device pointer that is
- *              used in place and must outlive the handle
+ *              host memory if grid_on_device == 0, else a device pointer; either way the handle
+ *              keeps its own node-major copy ([x][y][z][8]), the input is not referenced later
  *  mat,invmat  UNIT-cell matrix of csetup.cell (not the supercell), column-major
  *  is_vdw      1 for a VdW grid (ewald_precision == Inf): enables the 5e6 rule
  */
