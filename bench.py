@@ -46,6 +46,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--mode", choices=("fused", "vdw", "coulomb"), default="fused")
     ap.add_argument("--algo", choices=("auto", "bruteforce", "culled"), default="auto")
+    ap.add_argument("--gather", choices=("staged", "inplace"), default="staged", help="how a gathered chunk is placed (N > 1)")
     ap.add_argument("--chunks", type=int, default=4, help="x-chunks per rank pipelined with the all-gather (N > 1)")
     ap.add_argument("--n", type=int, default=255, help="dims per axis (odd); grid has (n+1)^3 points")
     ap.add_argument("--cpu-rows", type=int, default=-1, help="y-rows per x-plane the CPU baseline times, one plane per thread (-1 = auto ~12 s, 0 = skip)")
@@ -131,35 +132,43 @@ def main():
     full_c = torch.empty((8, nx, ny, nz), dtype=torch.float32, device=dev) if need_c else None
     if world == 1:
         loc_v, loc_c = full_v, full_c
+    elif cyc is not None:      # one compact [8, m, ny, nz] block per chunk
+        loc_v = torch.empty((cyc.nchunks, 8, cyc.m, ny, nz), dtype=torch.float32, device=dev) if need_v else None
+        loc_c = torch.empty((cyc.nchunks, 8, cyc.m, ny, nz), dtype=torch.float32, device=dev) if need_c else None
     else:
         loc_v = torch.empty((8, n_local, ny, nz), dtype=torch.float32, device=dev) if need_v else None
         loc_c = torch.empty((8, n_local, ny, nz), dtype=torch.float32, device=dev) if need_c else None
-    cs = n_local * plane
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
-    def launch(i_begin, i_end, i_origin):
+    def launch(i_begin, i_end, i_origin, ptr_v, ptr_c, cs):
         s = torch.cuda.current_stream().cuda_stream
         if args.mode == "fused":
-            plan.build_fused(loc_v.data_ptr(), loc_c.data_ptr(), cs, i_begin, i_end, i_origin, algo, s)
+            plan.build_fused(ptr_v, ptr_c, cs, i_begin, i_end, i_origin, algo, s)
         elif args.mode == "vdw":
-            plan.build_vdw(loc_v.data_ptr(), cs, i_begin, i_end, i_origin, algo, s)
+            plan.build_vdw(ptr_v, cs, i_begin, i_end, i_origin, algo, s)
         else:
-            plan.build_coulomb(loc_c.data_ptr(), cs, i_begin, i_end, i_origin, algo, s)
+            plan.build_coulomb(ptr_c, cs, i_begin, i_end, i_origin, algo, s)
 
     fulls = [t for t in (full_v, full_c) if t is not None]
     locs = [t for t in (loc_v, loc_c) if t is not None]
-    pipe = PipelinedGather(cyc, fulls, locs) if cyc is not None else None
+    pipe = PipelinedGather(cyc, fulls, locs, mode=args.gather) if cyc is not None else None
+
+    def launch_chunk(j, ib, ie, blocks):
+        it = iter(blocks)
+        pv = next(it).data_ptr() if need_v else 0
+        pc = next(it).data_ptr() if need_c else 0
+        launch(ib, ie, ib, pv, pc, cyc.m * plane)
 
     def step(k=None):
         if k is not None:
             ev0[k].record()
         if pipe is not None:
-            pipe.run(lambda j, ib, ie, off: launch(ib, ie, ib - off),
-                     on_compute_done=(lambda: ev1[k].record()) if k is not None else None)
+            pipe.run(launch_chunk, on_compute_done=(lambda: ev1[k].record()) if k is not None else None)
         else:
-            launch(b, e, b if world > 1 else 0)
+            launch(b, e, b if world > 1 else 0, loc_v.data_ptr() if need_v else 0, loc_c.data_ptr() if need_c else 0,
+                   n_local * plane)
             if k is not None:
                 ev1[k].record()
             if world > 1:
@@ -234,7 +243,7 @@ def main():
             "config": {"workload": w.name, "grid_points": npts, "framework_atoms": w.natoms,
                        "lattice_images": plan.num_images, "grids_per_step": ngrids, "mode": args.mode,
                        "algo": "culled" if (algo != _abi.ALGO_BRUTEFORCE and plan.can_cull) else "bruteforce",
-                       "parallelism": (f"block-cyclic x-chunks over {world} GPUs ({cyc.nchunks} chunks of {cyc.m} planes per rank), each chunk all-gathered in place over RCCL while the next is computed" if cyc is not None
+                       "parallelism": (f"block-cyclic x-chunks over {world} GPUs ({cyc.nchunks} chunks of {cyc.m} planes per rank), each chunk all-gathered over RCCL ({args.gather}) while the next is computed" if cyc is not None
                                        else f"x-slab sharding over {world} GPU(s)" + (", RCCL all-gather of slabs" if world > 1 else ""))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -13,9 +13,9 @@ Two distributions of the x-planes:
 
 * **block-cyclic chunks** (``cyclic_plan``): the planes are cut into ``nchunks`` super-blocks of
   ``world*m`` planes, rank r owning the r-th ``m`` planes of every super-block.  For one chunk the
-  ranks' pieces are adjacent in the final array, so each chunk is gathered in place *while the
-  next chunk is being computed* (collectives on a side stream): the exchange over xGMI hides
-  behind the FP64 kernels instead of following them.
+  ranks' pieces are adjacent in the final array, so each chunk is gathered and put in place
+  *while the next chunk is being computed* (collectives on a side stream, ``PipelinedGather``):
+  the exchange over xGMI hides behind the FP64 kernels instead of following them.
 
 One process per GPU, ``torch.distributed`` (backend ``nccl`` = RCCL over xGMI on ROCm; ``gloo``
 in the CPU tests).
@@ -67,35 +67,18 @@ def allgather_grid(full: torch.Tensor, local: torch.Tensor, group=None) -> torch
     return full
 
 
-_COALESCE_OK = True
-
-
 def _gather_block(full: torch.Tensor, local: torch.Tensor, lo: int, hi: int, l0: int, m: int, world: int, group=None) -> None:
     """all-gather ``local[:, l0:l0+m]`` of every rank into ``full[:, lo:hi]`` (``hi-lo == world*m``,
-    rank r's piece at ``lo + r*m``), one collective per channel, coalesced into one group launch
-    where the backend allows it."""
-    global _COALESCE_OK
+    rank r's piece at ``lo + r*m``), one collective per channel."""
     nchan = full.shape[0]
     assert hi - lo == world * m
     backend = dist.get_backend(group)
-    if backend == "gloo":
-        for c in range(nchan):
+    for c in range(nchan):
+        if backend == "gloo":
             outs = [full[c, lo + r * m: lo + (r + 1) * m] for r in range(world)]
             dist.all_gather(outs, local[c, l0:l0 + m].contiguous(), group=group)
-        return
-
-    def issue():
-        for c in range(nchan):
+        else:
             dist.all_gather_into_tensor(full[c, lo:hi], local[c, l0:l0 + m], group=group)
-
-    if _COALESCE_OK:
-        try:
-            with dist._coalescing_manager(group=group, device=full.device, async_ops=False):
-                issue()
-            return
-        except Exception:            # private API: fall back to plain per-channel calls
-            _COALESCE_OK = False
-    issue()
 
 
 @dataclass
@@ -131,28 +114,68 @@ def cyclic_plan(nx: int, world: int, rank: int, nchunks: int = 4, align: int = 4
 
 
 class PipelinedGather:
-    """Compute chunk j+1 while chunk j is being all-gathered.
+    """Compute chunk j+1 while chunk j is being all-gathered (collectives on a side stream).
 
-    ``launch(j, i_begin, i_end, local_plane_offset)`` must enqueue, on the current stream, the build
-    of global planes [i_begin, i_end) into ``local[:, off:off+m]`` of every grid in ``locals_``.
+    Rank-local results live in ``locals_[g]`` of shape ``[nchunks, 8, m, ny, nz]`` (one compact
+    ``[8, m, ny, nz]`` block per chunk).  ``launch(j, i_begin, i_end, blocks)`` must enqueue, on the
+    current stream, the build of global planes [i_begin, i_end) into ``blocks[g] = locals_[g][j]``
+    (channel stride ``m*ny*nz``, ``i_origin = i_begin``).
+
+    Two ways to place a gathered chunk, both with public torch.distributed calls only:
+
+    * ``"staged"`` (default): ONE ``all_gather_into_tensor`` per grid and chunk into a
+      ``[world, 8, m, ny, nz]`` staging buffer, then one strided device copy into the final
+      ``[8, nx, ny, nz]`` array (channel and rank axes swapped);
+    * ``"inplace"``: 8 ``all_gather_into_tensor`` calls per grid and chunk (one per channel)
+      straight into the final array -- no copy, more (smaller) collectives.
     """
 
-    def __init__(self, plan: CyclicPlan, fulls: List[torch.Tensor], locals_: List[torch.Tensor], group=None):
-        self.plan, self.fulls, self.locals, self.group = plan, fulls, locals_, group
+    def __init__(self, plan: CyclicPlan, fulls: List[torch.Tensor], locals_: List[torch.Tensor], group=None,
+                 mode: str = "staged"):
+        assert mode in ("staged", "inplace")
+        self.plan, self.fulls, self.locals, self.group, self.mode = plan, fulls, locals_, group, mode
         dev = fulls[0].device
         self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        for full, loc in zip(fulls, locals_):
+            assert tuple(loc.shape) == (plan.nchunks, full.shape[0], plan.m) + tuple(full.shape[2:]) and loc.is_contiguous()
+        self.staging = None
+        if mode == "staged" and plan.world > 1:
+            shape = (plan.world,) + tuple(locals_[0].shape[1:])
+            self.staging = [[torch.empty(shape, dtype=f.dtype, device=dev) for f in fulls] for _ in range(2)]
 
-    def run(self, launch: Callable[[int, int, int, int], None], on_compute_done: Optional[Callable[[], None]] = None) -> None:
+    def _gather_chunk(self, j: int) -> None:
+        p = self.plan
+        lo, hi = p.block(j)
+        backend = dist.get_backend(self.group)
+        for g, (full, loc) in enumerate(zip(self.fulls, self.locals)):
+            block = loc[j]                                            # [8, m, ny, nz], contiguous
+            if self.mode == "inplace":
+                for c in range(full.shape[0]):
+                    if backend == "gloo":
+                        outs = [full[c, lo + r * p.m: lo + (r + 1) * p.m] for r in range(p.world)]
+                        dist.all_gather(outs, block[c], group=self.group)
+                    else:
+                        dist.all_gather_into_tensor(full[c, lo:hi], block[c], group=self.group)
+                continue
+            stage = self.staging[j % 2][g]                            # [world, 8, m, ny, nz]
+            if backend == "gloo":
+                dist.all_gather(list(stage.unbind(0)), block, group=self.group)
+            else:
+                dist.all_gather_into_tensor(stage, block, group=self.group)
+            # final[c, lo + r*m + t] = stage[r, c, t]
+            full[:, lo:hi].unflatten(1, (p.world, p.m)).copy_(stage.permute(1, 0, 2, 3, 4))
+
+    def run(self, launch: Callable[[int, int, int, List[torch.Tensor]], None],
+            on_compute_done: Optional[Callable[[], None]] = None) -> None:
         p = self.plan
         cur = torch.cuda.current_stream() if self.comm_stream is not None else None
         for j in range(p.nchunks):
             b, e = p.chunk(j)
-            launch(j, b, e, j * p.m)
+            launch(j, b, e, [loc[j] for loc in self.locals])
             if j == p.nchunks - 1 and on_compute_done is not None:
                 on_compute_done()          # e.g. record a timing event after the last kernel
             if p.world == 1:
                 continue
-            lo, hi = p.block(j)
             if self.comm_stream is not None:
                 ev = torch.cuda.Event()
                 ev.record(cur)
@@ -161,7 +184,6 @@ class PipelinedGather:
             else:
                 ctx = contextlib.nullcontext()
             with ctx:
-                for full, local in zip(self.fulls, self.locals):
-                    _gather_block(full, local, lo, hi, j * p.m, p.m, p.world, self.group)
+                self._gather_chunk(j)
         if self.comm_stream is not None and p.world > 1:
             cur.wait_stream(self.comm_stream)

@@ -46,15 +46,16 @@ def _worker(rank, world, port, spacing, outdir):
         from ceg_hip.distributed import PipelinedGather, cyclic_plan
         cyc = cyclic_plan(nx, world, rank, nchunks=4, align=1)
         if cyc is not None:
-            loc = torch.full((8, cyc.n_local, ny, nz), float("nan"), dtype=torch.float32)
-            full2 = torch.full((8, nx, ny, nz), float("nan"), dtype=torch.float32)
+            for mode in ("staged", "inplace"):
+                loc = torch.full((cyc.nchunks, 8, cyc.m, ny, nz), float("nan"), dtype=torch.float32)
+                full2 = torch.full((8, nx, ny, nz), float("nan"), dtype=torch.float32)
 
-            def launch(j, ib, ie, off):
-                gg, _ = O.grid_vdw(w.probe_vdw, w.cset, lam, thr, ib, ie, nthreads=2)
-                loc[:, off:off + (ie - ib)] = torch.from_numpy(gg[:, ib:ie])
+                def launch(j, ib, ie, blocks):
+                    gg, _ = O.grid_vdw(w.probe_vdw, w.cset, lam, thr, ib, ie, nthreads=2)
+                    blocks[0].copy_(torch.from_numpy(gg[:, ib:ie]))
 
-            PipelinedGather(cyc, [full2], [loc]).run(launch)
-            np.save(os.path.join(outdir, f"rank{rank}_cyclic.npy"), full2.numpy())
+                PipelinedGather(cyc, [full2], [loc], mode=mode).run(launch)
+                np.save(os.path.join(outdir, f"rank{rank}_cyclic_{mode}.npy"), full2.numpy())
     finally:
         dist.destroy_process_group()
 
@@ -72,11 +73,12 @@ def test_slab_gather_gloo(tmp_path, world, spacing, oracle):
     for r in range(world):
         got = np.load(tmp_path / f"rank{r}.npy")
         np.testing.assert_array_equal(got, ref)
-        f = tmp_path / f"rank{r}_cyclic.npy"
-        if f.exists():
-            np.testing.assert_array_equal(np.load(f), ref)
-            ncyc += 1
-    assert ncyc in (0, world)
+        for mode in ("staged", "inplace"):
+            f = tmp_path / f"rank{r}_cyclic_{mode}.npy"
+            if f.exists():
+                np.testing.assert_array_equal(np.load(f), ref)
+                ncyc += 1
+    assert ncyc in (0, 2 * world)
 
 
 def test_cyclic_plan_shapes():

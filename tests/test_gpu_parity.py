@@ -326,10 +326,11 @@ def test_slabs_fused_and_layouts(hip_lib, oracle):
 
 
 def test_block_cyclic_chunk_launches(hip_lib):
-    """The launch pattern of bench.py at N > 1 (ceg_hip.distributed.CyclicPlan): every rank's chunks,
-    written into compact rank-local buffers with the (i_begin, i_origin) arithmetic of the bench,
-    then placed like the in-place all-gather would place them, reproduce the single-launch grid
-    bit for bit (chunks start on tile boundaries)."""
+    """The launch pattern of bench.py at N > 1 (ceg_hip.distributed.CyclicPlan / PipelinedGather,
+    "staged" placement): every rank's chunks are built into compact [8, m, ny, nz] blocks
+    (channel stride m*ny*nz, i_origin = i_begin), stacked like all_gather_into_tensor stacks them
+    and put in place with the same strided copy; the result equals the single-launch grid bit for
+    bit (chunks start on tile boundaries)."""
     import torch
     from ceg_hip.distributed import cyclic_plan
     w = W.fixture_workload("CHA_1.4_3b4eeb96", "Ar", 0.5, dims=(63, 61, 57))        # nx = 64
@@ -344,20 +345,21 @@ def test_block_cyclic_chunk_launches(hip_lib):
     for world in (2, 4):
         full_v = torch.full_like(ref_v, float("nan"))
         full_c = torch.full_like(ref_c, float("nan"))
-        for rank in range(world):
-            cyc = cyclic_plan(nx, world, rank, nchunks=4)
-            assert cyc is not None and cyc.m % 4 == 0
-            loc_v = torch.full((8, cyc.n_local, ny, nz), float("nan"), dtype=torch.float32, device=dev)
-            loc_c = torch.full_like(loc_v, float("nan"))
-            for j in range(cyc.nchunks):
+        cycs = [cyclic_plan(nx, world, rank, nchunks=4) for rank in range(world)]
+        assert all(c is not None and c.m % 4 == 0 for c in cycs)
+        m, K = cycs[0].m, cycs[0].nchunks
+        locs_v = [torch.full((K, 8, m, ny, nz), float("nan"), dtype=torch.float32, device=dev) for _ in range(world)]
+        locs_c = [torch.full_like(t, float("nan")) for t in locs_v]
+        for rank, cyc in enumerate(cycs):
+            for j in range(K):
                 b, e = cyc.chunk(j)
-                off = j * cyc.m
-                plan.build_fused(loc_v.data_ptr(), loc_c.data_ptr(), cyc.n_local * plane, b, e, b - off, CULLED, s)
-            torch.cuda.synchronize()
-            for j in range(cyc.nchunks):
-                b, e = cyc.chunk(j)
-                full_v[:, b:e] = loc_v[:, j * cyc.m:(j + 1) * cyc.m]
-                full_c[:, b:e] = loc_c[:, j * cyc.m:(j + 1) * cyc.m]
+                plan.build_fused(locs_v[rank][j].data_ptr(), locs_c[rank][j].data_ptr(), m * plane, b, e, b, CULLED, s)
+        torch.cuda.synchronize()
+        for j in range(K):
+            lo, hi = cycs[0].block(j)
+            for full, locs in ((full_v, locs_v), (full_c, locs_c)):
+                stage = torch.stack([locs[r][j] for r in range(world)])          # what the all-gather produces
+                full[:, lo:hi].unflatten(1, (world, m)).copy_(stage.permute(1, 0, 2, 3, 4))
         assert torch.equal(full_v, ref_v) and torch.equal(full_c, ref_c)
     plan.close()
 
