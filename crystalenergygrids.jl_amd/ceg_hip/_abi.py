@@ -69,6 +69,13 @@ PROTOTYPES = {
     "ceg_interp_points": (C.c_int, [C.c_void_p, c_double_p, C.c_int64, c_double_p]),
     "ceg_interp_points_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "ceg_scale_grid_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_int32, C.c_void_p]),
+    "ceg_recip_create": (C.c_int, [
+        C.POINTER(C.c_void_p), C.c_int32, c_int32_p, c_double_p, c_double_p, c_double_p, C.c_int64,
+        c_int32_p, c_double_p]),
+    "ceg_recip_destroy": (C.c_int, [C.c_void_p]),
+    "ceg_recip_energy": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.c_int32, C.c_int64, C.c_double, C.c_double, c_double_p]),
+    "ceg_recip_energy_device": (C.c_int, [C.c_void_p, C.c_void_p, c_double_p, C.c_int32, C.c_int64, C.c_double, C.c_double,
+                                          C.c_void_p, C.c_void_p]),
 }
 
 ALGO_AUTO, ALGO_BRUTEFORCE, ALGO_CULLED = 0, 1, 2

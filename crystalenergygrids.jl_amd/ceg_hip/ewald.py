@@ -159,13 +159,11 @@ def _periodic_distance(d: np.ndarray, mat, invmat, ortho, safemin2) -> float:
     return math.sqrt(ref2)
 
 
-def compute_ewald(eframework: EwaldFramework, systems: Sequence[Sequence], skipcontribution: int = 0) -> float:
-    """``compute_ewald(eframework, systems)`` = ``compute_ewald(EwaldContext(eframework,
-    systems))`` (ewald.jl:475-577), in K.  ``systems`` is a sequence of kinds, each a
-    sequence of molecules (RASPASystem) of that kind."""
-    if eframework.alpha == 0.0:
-        return 0.0
-    assert skipcontribution == 0
+def ewald_context_constants(eframework: EwaldFramework, systems: Sequence[Sequence]):
+    """The two constants an ``EwaldContext`` carries (ewald.jl:497-544):
+    ``(energy_net_charges, static_contribution)`` in K.  ``systems`` is a sequence of kinds, each a
+    sequence of molecules; the intramolecular exclusion term uses the first molecule of each kind
+    (rigid molecules)."""
     ef = eframework
     allcharges = [np.asarray(kind[0].atomic_charge, dtype=np.float64) for kind in systems]
     numspecies = [len(kind) for kind in systems]
@@ -188,6 +186,23 @@ def compute_ewald(eframework: EwaldFramework, systems: Sequence[Sequence], skipc
         energy_adsorbate_excluded += num * this_energy * COULOMBIC_CONVERSION_FACTOR
     static_contribution = ef.UIon * total_net_charges ** 2 - energy_adsorbate_self - energy_adsorbate_excluded
     energy_net_charges = ef.UIon * ef.net_charges_framework * total_net_charges
+    return energy_net_charges, static_contribution
+
+
+def kindices_array(eframework: EwaldFramework) -> np.ndarray:
+    """``kspace.kindices`` as int32[nkind, 5] rows (j, k, i_first, i_last, rangeidx)."""
+    return np.ascontiguousarray(np.array(eframework.kspace.kindices, dtype=np.int32).reshape(-1, 5))
+
+
+def compute_ewald(eframework: EwaldFramework, systems: Sequence[Sequence], skipcontribution: int = 0) -> float:
+    """``compute_ewald(eframework, systems)`` = ``compute_ewald(EwaldContext(eframework,
+    systems))`` (ewald.jl:475-577), in K.  ``systems`` is a sequence of kinds, each a
+    sequence of molecules (RASPASystem) of that kind."""
+    if eframework.alpha == 0.0:
+        return 0.0
+    assert skipcontribution == 0
+    ef = eframework
+    energy_net_charges, static_contribution = ewald_context_constants(ef, systems)
 
     fr, ch = [], []
     for kind in systems:

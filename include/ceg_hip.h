@@ -231,6 +231,35 @@ CEG_API int ceg_interp_points_device(ceg_interp_t* handle, const double* d_point
  * that was just built by ceg_plan_build_* can be interpolated without leaving the GPU */
 CEG_API int ceg_scale_grid_device(float* d_grid, int64_t nfloats, double scale, int32_t device, void* stream);
 
+/* ---- grid consumer: batched reciprocal-space Ewald energy --------- */
+/*
+ * The `coulomb_reciprocal` term of energy_point (src/grids.jl:319-325): compute_ewald(ctx)
+ * (src/ewald.jl:555-577) for a context holding ONE rigid molecule, evaluated for many placements of
+ * that molecule at once:
+ *   E = 2*(sum_k kf_k Re(conj(S_f(k)) S_a(k)) + energy_net_charges) + sum_k kf_k |S_a(k)|^2
+ *       + static_contribution,      S_a(k) = sum_atoms q exp(2 pi i k.f),  f = invmat * position
+ * With ceg_interp_* this completes energy_point / energy_grid on the device.
+ *
+ *  kvec_ijk  [3*nk] integer k-vectors in the order of kspace.kindices (src/ewald.jl:213-236)
+ *  kfactors  [nk]   (src/ewald.jl:247-259);  sf_re, sf_im [nk] = StoreRigidChargeFramework (:267-271)
+ *  ks        (kx, ky, kz);  invmat: inverse of the SUPERCELL matrix (eframework.invmat), column-major
+ */
+typedef struct ceg_recip ceg_recip_t;
+
+CEG_API int ceg_recip_create(ceg_recip_t** handle, int32_t device, const int32_t* kvec_ijk,
+                             const double* kfactors, const double* sf_re, const double* sf_im, int64_t nk,
+                             const int32_t ks[3], const double invmat[9]);
+CEG_API int ceg_recip_destroy(ceg_recip_t* handle);
+/* positions [n][natoms][3] A, charges [natoms] e, out [n] K -- host memory, synchronous.
+ * energy_net_charges / static_contribution: the two EwaldContext constants (src/ewald.jl:497-544). */
+CEG_API int ceg_recip_energy(ceg_recip_t* handle, const double* positions, const double* charges,
+                             int32_t natoms, int64_t n, double energy_net_charges,
+                             double static_contribution, double* out);
+/* positions / out in device memory (charges on the host), asynchronous on `stream` */
+CEG_API int ceg_recip_energy_device(ceg_recip_t* handle, const double* d_positions, const double* charges,
+                                    int32_t natoms, int64_t n, double energy_net_charges,
+                                    double static_contribution, double* d_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

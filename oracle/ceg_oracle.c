@@ -504,6 +504,92 @@ ORACLE_API void oracle_interpolate_points(const float* grid, const int32_t dims[
         out[p] = oracle_interpolate_grid(grid, dims, size, shift, mat, invmat, is_vdw, coeff, points + 3 * p);
 }
 
+/* ---- reciprocal-space Ewald energy of ONE rigid molecule in the framework (row f2):
+ * compute_ewald(ctx) (src/ewald.jl:555-577) after move_one_system!(ctx, 1, positions) (:352-366)
+ * for a context holding a single molecule, i.e. the `coulomb_reciprocal` term of energy_point
+ * (src/grids.jl:319-325).  Tables as make_line_pos!/make_line_neg! build them (:73-92, powers by
+ * repeated multiplication), sums in the order of ewald_main_loop! (:148-185).
+ *  kind[t] = (j, k, i_first, i_last, rangeidx) rows of kspace.kindices (:213-236)
+ *  invmat  column-major inverse of the supercell matrix (eframework.invmat)
+ *  energy_net_charges, static_contribution: the two context constants (:497-544) */
+#include <complex.h>
+ORACLE_API double oracle_reciprocal_energy(const int32_t* kind, int64_t nkind, const int32_t ks[3],
+                                           const double* kfactors, const double* sf_re, const double* sf_im,
+                                           int64_t num_kvecs, const double invmat[9],
+                                           const double* positions, const double* charges, int32_t natoms,
+                                           double energy_net_charges, double static_contribution)
+{
+    const int kx = ks[0], ky = ks[1], kz = ks[2];
+    const int kxp = kx + 1, tkyp = 2 * ky + 1, tkzp = 2 * kz + 1;
+    double complex* Eikx = malloc(sizeof(double complex) * kxp * natoms);
+    double complex* Eiky = malloc(sizeof(double complex) * tkyp * natoms);
+    double complex* Eikz = malloc(sizeof(double complex) * tkzp * natoms);
+    double complex* sums = calloc(num_kvecs, sizeof(double complex));
+    const double twopi = 6.283185307179586476925286766559;
+    for (int a = 0; a < natoms; ++a) {
+        double f[3];
+        matvec3(f, invmat, positions + 3 * a);                     /* :359 */
+        const double complex ex = cexp(I * (twopi * f[0])), ey = cexp(I * (twopi * f[1])), ez = cexp(I * (twopi * f[2]));
+        double complex* X = Eikx + (size_t)kxp * a;                /* make_line_pos! :73-81 */
+        X[0] = 1.0;
+        if (kxp > 1) X[1] = ex;
+        for (int i = 2; i < kxp; ++i) X[i] = X[i - 1] * ex;
+        double complex* Y = Eiky + (size_t)tkyp * a;               /* make_line_neg! :83-91 */
+        if (ky > 0) {
+            Y[ky - 1] = conj(ey);
+            for (int i = ky - 2; i >= 0; --i) Y[i] = Y[i + 1] * conj(ey);
+        }
+        Y[ky] = 1.0;
+        if (ky > 0) Y[ky + 1] = ey;
+        for (int i = ky + 2; i < tkyp; ++i) Y[i] = Y[i - 1] * ey;
+        double complex* Z = Eikz + (size_t)tkzp * a;
+        if (kz > 0) {
+            Z[kz - 1] = conj(ez);
+            for (int i = kz - 2; i >= 0; --i) Z[i] = Z[i + 1] * conj(ez);
+        }
+        Z[kz] = 1.0;
+        if (kz > 0) Z[kz + 1] = ez;
+        for (int i = kz + 2; i < tkzp; ++i) Z[i] = Z[i - 1] * ez;
+    }
+    for (int a = 0; a < natoms; ++a) {                             /* ewald_main_loop! :158-176 */
+        const double c = charges[a];
+        for (int64_t t = 0; t < nkind; ++t) {
+            const int jy = kind[5 * t], jz = kind[5 * t + 1], i0 = kind[5 * t + 2], i1 = kind[5 * t + 3];
+            const int64_t ridx = kind[5 * t + 4];
+            const double complex eyz = c * Eiky[(size_t)tkyp * a + ky + jy] * Eikz[(size_t)tkzp * a + kz + jz];
+            for (int i = i0; i <= i1; ++i) sums[ridx + (i - i0)] += Eikx[(size_t)kxp * a + i] * eyz;
+        }
+    }
+    double framework_adsorbate = 0.0, adsorbate_adsorbate = 0.0;   /* compute_ewald :563-570 */
+    for (int64_t q = 0; q < num_kvecs; ++q) {
+        const double temp = kfactors[q];
+        const double re_a = creal(sums[q]), im_a = cimag(sums[q]);
+        framework_adsorbate += temp * (sf_re[q] * re_a + sf_im[q] * im_a);
+        adsorbate_adsorbate += temp * (re_a * re_a + im_a * im_a);
+    }
+    free(Eikx); free(Eiky); free(Eikz); free(sums);
+    return 2 * (framework_adsorbate + energy_net_charges) + (adsorbate_adsorbate + static_contribution);
+}
+
+ORACLE_API void oracle_reciprocal_energies(const int32_t* kind, int64_t nkind, const int32_t ks[3],
+                                           const double* kfactors, const double* sf_re, const double* sf_im,
+                                           int64_t num_kvecs, const double invmat[9],
+                                           const double* positions, const double* charges, int32_t natoms, int64_t n,
+                                           double energy_net_charges, double static_contribution, double* out,
+                                           int32_t nthreads)
+{
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < n; ++p)
+        out[p] = oracle_reciprocal_energy(kind, nkind, ks, kfactors, sf_re, sf_im, num_kvecs, invmat,
+                                          positions + 3 * (size_t)natoms * p, charges, natoms,
+                                          energy_net_charges, static_contribution);
+}
+
 ORACLE_API int oracle_max_threads(void)
 {
 #ifdef _OPENMP

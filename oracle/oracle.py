@@ -67,6 +67,9 @@ def lib() -> C.CDLL:
                                             C.c_double, _dp, C.c_int64, _dp, C.c_int32]
         l.oracle_interpolate_points.restype = None
         l.oracle_interpolate_points.argtypes = [_fp, _i32p, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp, C.c_int64, _dp, C.c_int32]
+        l.oracle_reciprocal_energies.restype = None
+        l.oracle_reciprocal_energies.argtypes = [_i32p, C.c_int64, _i32p, _dp, _dp, _dp, C.c_int64, _dp, _dp, _dp, C.c_int32,
+                                                 C.c_int64, C.c_double, C.c_double, _dp, C.c_int32]
         l.oracle_max_threads.restype = C.c_int
         l.oracle_max_threads.argtypes = []
         _lib = l
@@ -214,6 +217,25 @@ def interpolate_points(g, points, nthreads=0) -> np.ndarray:
     lib().oracle_interpolate_points(grid.ctypes.data_as(_fp), dims.ctypes.data_as(_i32p), _d(size), _d(shift),
                                     _d(_cm(cs.cell.mat)), _d(_cm(cs.cell.invmat)),
                                     1 if g.ewald_precision == math.inf else 0, _d(coeff), _d(pts), len(pts), _d(out), nthreads)
+    return out
+
+
+def reciprocal_energies(ef, molecule, positions, nthreads=0) -> np.ndarray:
+    """compute_ewald (ewald.jl:555-577) of one rigid molecule placed at positions[n, natoms, 3]: literal
+    restatement with the reference's power tables and summation order."""
+    from ceg_hip.ewald import ewald_context_constants, kindices_array
+    kind = kindices_array(ef)
+    ks = np.asarray(ef.kspace.ks, dtype=np.int32)
+    kf = np.ascontiguousarray(ef.kfactors, dtype=np.float64)
+    re = np.ascontiguousarray(ef.StoreRigidChargeFramework.real, dtype=np.float64)
+    im = np.ascontiguousarray(ef.StoreRigidChargeFramework.imag, dtype=np.float64)
+    q = np.ascontiguousarray(molecule.atomic_charge, dtype=np.float64)
+    pos = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, len(q), 3)
+    enc, static = ewald_context_constants(ef, ((molecule,),))
+    out = np.empty(len(pos), dtype=np.float64)
+    lib().oracle_reciprocal_energies(kind.ctypes.data_as(_i32p), len(kind), ks.ctypes.data_as(_i32p), _d(kf), _d(re), _d(im),
+                                     len(kf), _d(_cm(ef.invmat)), _d(pos.reshape(-1)), _d(q), len(q), len(pos), enc, static,
+                                     _d(out), nthreads)
     return out
 
 

@@ -72,3 +72,21 @@ def test_oracle_interpolation_equals_host_mirror(oracle):
         m = a != 1e100
         np.testing.assert_allclose(a[m], b[m], rtol=1e-11, atol=1e-9)
         assert (prec == math.inf) == bool((a == 1e100).any())
+
+
+def test_oracle_reciprocal_equals_host_mirror(oracle):
+    """Row f2: the literal restatement of compute_ewald (power tables by repeated multiplication,
+    reference summation order; ewald.jl:109-185, 555-577) against the direct-exponential mirror
+    ``ceg_hip.ewald.compute_ewald`` that test_reference_pins pins to the runtests.jl literals."""
+    import ceg_hip as ceg
+    rng = np.random.default_rng(11)
+    for fwname, sc in (("CHA_1.4_3b4eeb96", (1, 1, 1)), ("CIT-7", None)):
+        fw = ceg.load_framework_RASPA(fwname, "BoulfelfelSholl2021")
+        ef = ceg.initialize_ewald(fw, sc)
+        for molname in ("Na", "CO2"):
+            mol = ceg.load_molecule_RASPA(molname, "TraPPE", "BoulfelfelSholl2021")
+            base = np.asarray(mol.position, dtype=np.float64).reshape(-1, 3)
+            pos = rng.uniform(-30, 50, (12, 1, 3)) + base[None]
+            got = oracle.reciprocal_energies(ef, mol, pos)
+            ref = np.array([ceg.compute_ewald(ef, ((mol.with_positions(p),),)) for p in pos])
+            np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-10 * np.abs(ref).max())
