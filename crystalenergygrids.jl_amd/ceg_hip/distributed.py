@@ -131,15 +131,16 @@ class PipelinedGather:
     """
 
     def __init__(self, plan: CyclicPlan, fulls: List[torch.Tensor], locals_: List[torch.Tensor], group=None,
-                 mode: str = "staged"):
+                 mode: str = "staged", force_collectives: bool = False):
         assert mode in ("staged", "inplace")
         self.plan, self.fulls, self.locals, self.group, self.mode = plan, fulls, locals_, group, mode
+        self.exchange = plan.world > 1 or force_collectives      # world 1: collectives only on request (tests)
         dev = fulls[0].device
         self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         for full, loc in zip(fulls, locals_):
             assert tuple(loc.shape) == (plan.nchunks, full.shape[0], plan.m) + tuple(full.shape[2:]) and loc.is_contiguous()
         self.staging = None
-        if mode == "staged" and plan.world > 1:
+        if mode == "staged" and self.exchange:
             shape = (plan.world,) + tuple(locals_[0].shape[1:])
             self.staging = [[torch.empty(shape, dtype=f.dtype, device=dev) for f in fulls] for _ in range(2)]
 
@@ -174,7 +175,7 @@ class PipelinedGather:
             launch(j, b, e, [loc[j] for loc in self.locals])
             if j == p.nchunks - 1 and on_compute_done is not None:
                 on_compute_done()          # e.g. record a timing event after the last kernel
-            if p.world == 1:
+            if not self.exchange:
                 continue
             if self.comm_stream is not None:
                 ev = torch.cuda.Event()
@@ -185,5 +186,5 @@ class PipelinedGather:
                 ctx = contextlib.nullcontext()
             with ctx:
                 self._gather_chunk(j)
-        if self.comm_stream is not None and p.world > 1:
+        if self.comm_stream is not None and self.exchange:
             cur.wait_stream(self.comm_stream)

@@ -365,6 +365,54 @@ def test_block_cyclic_chunk_launches(hip_lib):
     plan.close()
 
 
+def test_pipelined_gather_over_rccl_single_rank(hip_lib):
+    """bench.py's N > 1 code path with the real backend: an RCCL ("nccl") process group of ONE rank
+    (one GPU per box here; two ranks on one device are refused by RCCL), collectives forced on.
+    Exercises all_gather_into_tensor on the side stream into the staging buffer / into slices of the
+    final array, the event hand-off between the streams and the strided placement copy; the gloo
+    tests cover the world > 1 index arithmetic."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from ceg_hip.distributed import PipelinedGather, allgather_grid, cyclic_plan
+    w = W.fixture_workload("CHA_1.4_3b4eeb96", "Ar", 0.5, dims=(63, 61, 57))        # nx = 64
+    nx, ny, nz = w.cset.npoints
+    plane = ny * nz
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        plan = GridPlan(w.cset, w.probe_vdw, w.probe_coulomb, w.alpha)
+        s = torch.cuda.current_stream().cuda_stream
+        ref_v = torch.empty((8, nx, ny, nz), dtype=torch.float32, device=dev)
+        ref_c = torch.empty_like(ref_v)
+        plan.build_fused(ref_v.data_ptr(), ref_c.data_ptr(), nx * plane, 0, nx, 0, CULLED, s)
+        cyc = cyclic_plan(nx, 1, 0, nchunks=4)
+        assert cyc.nchunks == 4 and cyc.m == 16
+        for mode in ("staged", "inplace"):
+            fulls = [torch.full_like(ref_v, float("nan")), torch.full_like(ref_c, float("nan"))]
+            locs = [torch.full((4, 8, cyc.m, ny, nz), float("nan"), dtype=torch.float32, device=dev) for _ in range(2)]
+            pipe = PipelinedGather(cyc, fulls, locs, mode=mode, force_collectives=True)
+
+            def launch(j, ib, ie, blocks):
+                plan.build_fused(blocks[0].data_ptr(), blocks[1].data_ptr(), cyc.m * plane, ib, ie, ib, CULLED,
+                                 torch.cuda.current_stream().cuda_stream)
+            for _ in range(2):                                        # twice: the staging buffers alternate and are reused
+                pipe.run(launch)
+            torch.cuda.synchronize()
+            assert torch.equal(fulls[0], ref_v) and torch.equal(fulls[1], ref_c), mode
+        # slab fallback (world 1 short-circuits to a copy)
+        out = torch.empty_like(ref_v)
+        allgather_grid(out, ref_v)
+        assert torch.equal(out, ref_v)
+        plan.close()
+    finally:
+        dist.destroy_process_group()
+
+
 # ------------------------------------------------------------------ row f1: batched interpolation
 def test_interpolation_batch_vs_oracle(hip_lib, oracle):
     """GPU interpolate_grid (ceg_interp_*) against the literal COEFF*X oracle: random points far

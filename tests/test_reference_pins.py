@@ -65,6 +65,27 @@ def test_na_in_cha_origin(oracle, forcefield):
     assert direct + recip == pytest.approx(pin["coulomb"], rel=5e-9)
 
 
+def test_na_in_cha_minimum(oracle, forcefield):
+    """runtests.jl:48-50 -- energy_grid value at its only minimum, CartesianIndex(29, 60, 60)."""
+    pin = PINS["na_cha_minimum"]
+    fw = ceg.load_framework_RASPA(pin["framework"], FFNAME)
+    cset = ceg.GridCoordinatesSetup.from_cell(fw.mat, pin["gridstep"])
+    pv = ProbeSystem.build(fw, forcefield, "Na")
+    pc = ProbeSystem.build(fw, forcefield)
+    ew = ceg.initialize_ewald(fw, (1, 1, 1))
+    na = ceg.load_molecule_RASPA("Na", "TraPPE", FFNAME, fw)
+    a, b, c = fw.mat[:, 0], fw.mat[:, 1], fw.mat[:, 2]
+    num = [int(np.floor(np.linalg.norm(v) / pin["energy_grid_step"])) + 1 for v in (a, b, c)]
+    iA, iB, iC = pin["index_1based"]
+    pos = (iA - 1) * a / num[0] + (iB - 1) * b / num[1] + (iC - 1) * c / num[2]
+    val = (interpolate_with_oracle(oracle, cset, pv, pos)
+           + na.atomic_charge[0] * interpolate_with_oracle(oracle, cset, pc, pos, ew.alpha)
+           + ceg.compute_ewald(ew, ((na.with_positions([pos]),),)))
+    assert val == pytest.approx(pin["value"], rel=pin["rtol"])
+    assert val == pytest.approx(pin["value"], rel=1e-4)        # 4.0e-5: see pins.json "ours_note"
+    assert val == pytest.approx(pin["ours"], rel=1e-12)
+
+
 def test_ar_in_cha_na_minimum(oracle, forcefield):
     """runtests.jl:35-38 -- LJ-only (shifted) grids Ar-O / Ar-Na; value of energy_grid at its minimum."""
     pin = PINS["ar_cha_na_minimum"]
