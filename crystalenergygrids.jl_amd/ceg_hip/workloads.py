@@ -90,8 +90,70 @@ def fixture_workload(framework: str, atom: Optional[str], spacing: float, coulom
     return Workload(name or f"{framework}/{atom}/{spacing}", fw, ff, cset, pv, pc, alpha)
 
 
-def roofline_workload(atom: str = "Ar", n: int = 255) -> Workload:
+def roofline_workload(atom: str = "Ar", n: int = 255, truncate: Optional[int] = None) -> Workload:
     """SURVEY §8d run "R": CHA_1.4_3b4eeb96 tiled 2x2x3 (11 664 atoms), (n+1)^3 grid points over
-    the cartesian bounding box of that cell (n = 255 -> 256^3)."""
-    return fixture_workload("CHA_1.4_3b4eeb96", atom, 0.0, coulomb=True, dims=(n, n, n), tile=(2, 2, 3),
-                            name=f"CHA_1.4_3b4eeb96 tiled 2x2x3 (11664 atoms) x {n + 1}^3 grid, {atom} probe LJ + real-space Ewald")
+    the cartesian bounding box of that cell (n = 255 -> 256^3).  ``truncate=10000`` keeps the first
+    10 000 atoms (the "exact 10 k" variant of BASELINE.json config 3)."""
+    w = fixture_workload("CHA_1.4_3b4eeb96", atom, 0.0, coulomb=True, dims=(n, n, n), tile=(2, 2, 3),
+                         name=f"CHA_1.4_3b4eeb96 tiled 2x2x3 (11664 atoms) x {n + 1}^3 grid, {atom} probe LJ + real-space Ewald")
+    if truncate is not None:
+        fw = w.framework
+        fw = RASPASystem(fw.mat, fw.position[:truncate], list(fw.atomic_symbol[:truncate]), fw.atomic_mass[:truncate],
+                         fw.atomic_charge[:truncate], False)
+        w = Workload(w.name.replace("11664 atoms", f"first {truncate} of 11664 atoms"), fw, w.forcefield, w.cset,
+                     ProbeSystem.build(fw, w.forcefield, atom), ProbeSystem.build(fw, w.forcefield), w.alpha)
+    return w
+
+
+def _random_atoms_min_sep(n: int, edge: float, min_sep: float, rng) -> np.ndarray:
+    """n points uniform in [0, edge)^3, periodic minimum separation ``min_sep`` (sequential rejection
+    against a cell hash, so the sequence is fully determined by ``rng``)."""
+    nc = int(edge // min_sep)
+    h = edge / nc
+    cells = {}
+    out = np.empty((n, 3))
+    k = 0
+    while k < n:
+        p = rng.uniform(0.0, edge, 3)
+        c = np.minimum((p / h).astype(int), nc - 1)
+        ok = True
+        for d in np.ndindex(3, 3, 3):
+            key = tuple((c + np.array(d) - 1) % nc)
+            for q in cells.get(key, ()):
+                dd = p - out[q]
+                dd -= edge * np.round(dd / edge)
+                if dd @ dd < min_sep * min_sep:
+                    ok = False
+                    break
+            if not ok:
+                break
+        if ok:
+            out[k] = p
+            cells.setdefault(tuple(c), []).append(k)
+            k += 1
+    return out
+
+
+def synthetic_workload(natoms: int, n: int = 127, edge: float = 40.0, seed: int = 0) -> Workload:
+    """SURVEY §8d fully synthetic sweep variant: orthorhombic ``edge`` A cube, ``natoms`` uniform-random
+    atoms with 1.5 A minimum separation (``numpy.random.default_rng(seed)``), a single LJ kind
+    (eps = 100 K, sigma = 3 A, shifted at the 12 A cutoff), charges +1/-1 alternating; (n+1)^3 grid."""
+    from .interactions import FF, InteractionRule, make_rule
+    rng = np.random.default_rng(seed)
+    pos = _random_atoms_min_sep(natoms, edge, 1.5, rng)
+    mat = np.diag([edge] * 3)
+    lj = InteractionRule(FF.LennardJones, [100.0, 3.0], 0.0, False)
+    lj = InteractionRule(FF.LennardJones, [100.0, 3.0], lj(12.0), False)
+    none = make_rule(FF.NoInteraction)
+    inter = [[none, lj], [lj, none]]
+    sdict = {"X": 1, "P": 2}
+    ff = ForceField(inter, sdict, list(sdict), 12.0, "synthetic")
+    q = np.where(np.arange(natoms) % 2 == 0, 1.0, -1.0)
+    fw = RASPASystem(mat, pos, ["X"] * natoms, np.ones(natoms), q, False)
+    inv = np.linalg.inv(mat)
+    kinds = np.ones(natoms, dtype=np.int64)
+    pv = ProbeSystem(pos, mat, inv, ff, kinds, np.empty(0), 2)
+    pc = ProbeSystem(pos, mat, inv, ff, kinds, q, 0)
+    alpha, _ = ewald_alpha()
+    cset = grid_setup_with_dims(mat, (n, n, n))
+    return Workload(f"synthetic {edge:g} A cube, {natoms} random LJ atoms (+1/-1), {n + 1}^3 grid", fw, ff, cset, pv, pc, alpha)

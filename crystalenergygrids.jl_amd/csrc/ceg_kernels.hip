@@ -486,9 +486,15 @@ __global__ __launch_bounds__(CEG_WG, CEG_WAVES) void k_culled(const PlanConst* _
         const int64_t tt = valid ? pidx : (pts.n - 1);
         px = pts.xyz[3 * tt]; py = pts.xyz[3 * tt + 1]; pz = pts.xyz[3 * tt + 2];
     } else {
-        const int tk = (int)(tile % tiles_k);
         const int tj = (int)((tile / tiles_k) % tiles_j);
         const int ti = (int)(tile / ((int64_t)tiles_k * tiles_j));
+        // Workgroups go to the 8 XCDs round-robin by index: with tiles_k/NW a multiple of 8 every XCD
+        // would own fixed z-slabs of the grid and the launch would last as long as the densest slab
+        // (measured: a framework with a corner missing ran no faster).  Rotating the z-tiles of each
+        // (i, j) column by one workgroup per column makes every XCD sweep all of z, while
+        // consecutive workgroups on one XCD still share their candidate bins in that XCD's L2.
+        const int nq = (tiles_k + NW - 1) / NW;
+        const int tk = (int)((tile % tiles_k + (int64_t)NW * ((ti + (out.i_begin >> 2) + tj) % nq)) % tiles_k);
         i0 = out.i_begin + 4 * ti; j0 = 4 * tj; k0 = 4 * tk;
         i = i0 + (lane >> 4);
         j = j0 + ((lane >> 2) & 3);

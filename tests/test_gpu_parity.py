@@ -623,3 +623,21 @@ def test_reference_energy_grid_flow(hip_lib, tmp_path):
         gs.close()
     finally:
         ceg.setdir_RASPA(GOLDEN / "raspa")
+
+
+# ------------------------------------------------------------------ SURVEY 8d variants of the roofline run
+def test_truncated_and_synthetic_workloads(hip_lib, oracle):
+    """The two other inputs SURVEY §8d names for BASELINE config 3: the exact-10 000-atom truncation of
+    the tiled CHA framework (a framework with a hole: tiles with few/no candidates) and the fully
+    synthetic 40 A cube (orthorhombic fast branch, random positions, alternating charges)."""
+    for w, planes in ((W.roofline_workload("Ar", 63, truncate=10000), (0, 31, 63)), (W.synthetic_workload(3000, 47), (0, 17, 47))):
+        nx, ny, nz = w.cset.npoints
+        gv = G.build_vdw_array(w.probe_vdw, w.cset)
+        gc = G.build_coulomb_array(w.probe_coulomb, w.alpha, w.cset)
+        for i in planes:
+            lam, thr = G.vdw_scaling()
+            ref, _ = oracle.grid_vdw(w.probe_vdw, w.cset, lam, thr, i, i + 1)
+            compare_grids(gv[:, i:i + 1], ref[:, i:i + 1], f"{w.name}/vdw/plane{i}")
+            lam, thr = G.coulomb_scaling()
+            ref, _ = oracle.grid_coulomb(w.probe_coulomb, w.alpha, w.cset, lam, thr, i, i + 1)
+            compare_grids(gc[:, i:i + 1], ref[:, i:i + 1], f"{w.name}/coulomb/plane{i}")
