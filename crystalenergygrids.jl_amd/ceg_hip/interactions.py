@@ -94,6 +94,39 @@ class InteractionRule:
             raise AssertionError
         return v - self.shift
 
+    def at_r2(self, r2: float) -> float:
+        """Energy in K from the squared distance in Å² (interactions.jl:392-406): the LJ, hard-sphere
+        and monomial kinds avoid the square root, the others defer to ``rule(sqrt(r2))``."""
+        k, p = self.kind, self.params
+        if k == FF.LennardJones:
+            x6 = (p[1] ** 2 / r2) ** 3
+            return 4 * p[0] * x6 * (x6 - 1) - self.shift
+        if k == FF.HardSphere:
+            return (math.inf if r2 < (p[0] + p[1]) ** 2 else 0.0) - self.shift
+        if k == FF.NoInteraction:
+            return 0.0 - self.shift
+        if k == FF.Monomial:
+            return p[0] / r2 ** (p[1] / 2) - self.shift
+        return self(math.sqrt(r2))
+
+    def tail(self, cutoff: float) -> float:
+        """``tailcorrection(rule, cutoff)`` interactions.jl:411-431 (K Å³, before the 2π/V factor)."""
+        k, p = self.kind, self.params
+        if (not self.tailcorrection or k in (FF.NoInteraction, FF.HardSphere, FF.CoulombEwaldDirect) or math.isinf(cutoff)):
+            return 0.0
+        if k == FF.LennardJones:
+            xlj3 = (p[1] / cutoff) ** 3
+            xlj9 = xlj3 ** 3
+            return (4 / 3) * p[0] * p[1] ** 3 * (xlj9 / 3 - xlj3)
+        if k == FF.Buckingham:
+            A, B, Cc = p[:3]
+            return A * math.exp(-B * cutoff) * (2.0 + B * cutoff * (2.0 + B * cutoff)) / B ** 3 - Cc / (3 * cutoff ** 3)
+        if k == FF.Coulomb:
+            raise ValueError("Coulomb direct pair interaction cannot have a tail correction: use Ewald summation.")
+        if k == FF.UndefinedInteraction:
+            raise UndefinedInteractionError()
+        raise AssertionError
+
 
 def make_rule(kind: FF, *args: float) -> InteractionRule:
     """``(ik::FF.InteractionKind)(args...)`` interactions.jl:276-345."""
@@ -175,6 +208,20 @@ class InteractionRuleSum:
         ret = 0.0
         for x in self.rules:
             ret += x(r)
+        return ret
+
+    def at_r2(self, r2: float) -> float:
+        """interactions.jl:589-595 with a squared distance"""
+        ret = 0.0
+        for x in self.rules:
+            ret += x.at_r2(r2)
+        return ret
+
+    def tail(self, cutoff: float) -> float:
+        """interactions.jl:646-652"""
+        ret = 0.0
+        for x in self.rules:
+            ret += x.tail(cutoff)
         return ret
 
     def same(self, other) -> bool:

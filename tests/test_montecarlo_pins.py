@@ -1,0 +1,124 @@
+"""Row f3 (guest-guest energies) and the consumers of the grids: the reference's Monte-Carlo
+energy literals of ``test/runtests.jl:186-267`` (CIT-7, 2x3x3 supercell, triclinic), rebuilt with
+the host mirror ``ceg_hip.montecarlo`` on top of grids whose needed corners come from the CPU
+oracle.  Each literal exercises the VdW grids (Ar: LJ; Na: Buckingham + hard sphere; CO2: O/C LJ),
+the Coulomb grid, reciprocal Ewald for several molecules, guest-guest pair terms and the tail
+correction at once; rtol is 1e-3 in the reference, the observed agreement is recorded per assert."""
+import math
+
+import numpy as np
+import pytest
+
+import ceg_hip as ceg
+from ceg_hip import grids as G, montecarlo as M
+from ceg_hip.probes import ProbeSystem
+
+from test_reference_pins import FFNAME, interpolate_with_oracle
+
+
+class OracleGrid(G.EnergyGrid):
+    """An EnergyGrid whose values are produced on demand (8 corners per interpolation) by the oracle."""
+
+
+@pytest.fixture()
+def oracle_grids(oracle, forcefield, monkeypatch):
+    fw = ceg.load_framework_RASPA("CIT-7", FFNAME)
+    cset = ceg.GridCoordinatesSetup.from_cell(fw.mat, 0.15)
+    probes = {}
+
+    def fake_retrieve(grid_path, syst_framework, ff, gridstep, atom_or_ef, mat, new, cutoff, ngpus=1):
+        iscoulomb = isinstance(atom_or_ef, ceg.EwaldFramework)
+        if not iscoulomb and not ff.needsvdwgrid(atom_or_ef):
+            return G.EnergyGrid.trivial(True)
+        g = OracleGrid(cset, (2, 3, 3), 1e-6 if iscoulomb else math.inf, True, None)
+        g.key = ("coulomb", atom_or_ef.alpha) if iscoulomb else ("vdw", atom_or_ef)
+        return g
+
+    def fake_interpolate(g, point):
+        if g.ewald_precision == -math.inf:
+            return 0.0
+        kind, what = g.key
+        if kind == "vdw":
+            if what not in probes:
+                probes[what] = ProbeSystem.build(fw, forcefield, what)
+            return interpolate_with_oracle(oracle, cset, probes[what], point)
+        if "coulomb" not in probes:
+            probes["coulomb"] = ProbeSystem.build(fw, forcefield)
+        return interpolate_with_oracle(oracle, cset, probes["coulomb"], point, what)
+
+    monkeypatch.setattr(M, "retrieve_or_create_grid", fake_retrieve)
+    monkeypatch.setattr(M, "interpolate_grid", fake_interpolate)
+    return fw
+
+
+def _mol(name, positions):
+    m = ceg.load_molecule_RASPA(name, "TraPPE", FFNAME)
+    return m.with_positions(positions)
+
+
+def test_two_argon_in_cit7(oracle_grids):
+    """runtests.jl:192-199"""
+    mc = M.setup_montecarlo("CIT-7", FFNAME, [_mol("Ar", [[-7.7365250811304911, 31.5070011601372251, 1.5285305931479920]]),
+                                               _mol("Ar", [[10.7586599791867421, -2.3259182727570948, 20.5642722996513001]])])
+    base = float(M.baseline_energy(mc))
+    mov1 = float(M.movement_energy(mc, (0, 0)))
+    mov2 = float(M.movement_energy(mc, (0, 1)))
+    assert base == pytest.approx(-1789.77383582, rel=1e-3)
+    assert base - mov1 - mov2 == pytest.approx(0.28797384, rel=1e-3)
+    assert base == pytest.approx(-1789.77383582, rel=1e-7)                 # 2e-8, like the CIT-7 point pin
+    assert base - mov1 - mov2 == pytest.approx(0.28797384, rel=1e-7)
+
+
+def test_sodium_in_cit7(oracle_grids):
+    """runtests.jl:222-241"""
+    solo = [[-4.728415488310421, 32.03533696753957, 2.943765448968882]]
+    nxt = [[-5.036, 31.876, 3.117]]
+    mc = M.setup_montecarlo("CIT-7", FFNAME, [_mol("Na", solo)])
+    assert mc.tailcorrection == pytest.approx(-70.44772635984882, rel=1e-8)          # runtests.jl:224 (isapprox default)
+    base = float(M.baseline_energy(mc))
+    assert base == pytest.approx(-21375.116833457894, rel=1e-3)
+    mc2 = M.setup_montecarlo("CIT-7", FFNAME, [_mol("Na", nxt)])
+    assert mc2.tailcorrection == mc.tailcorrection
+    base2 = float(M.baseline_energy(mc2))
+    assert base2 == pytest.approx(-21795.8765195143, rel=1e-3)
+    diff = float(M.movement_energy(mc, (0, 0), nxt) - M.movement_energy(mc, (0, 0)))
+    assert base2 == pytest.approx(base + diff, rel=1e-8)                               # runtests.jl:234
+    # Observed: 1.2e-4 and 3.0e-4 (2.5 K, 6.6 K).  The Ar literals above are met to 2e-8 and the tail
+    # correction to 1e-8, so the charged-guest literals are taken to be RASPA2-era numbers that the
+    # reference itself only reproduces to its rtol (the difference is position dependent, i.e. it sits in
+    # the interpolated Buckingham / Coulomb terms, not in a constant).  Regression values = this repo.
+    assert base == pytest.approx(-21375.116833457894, rel=2e-4)
+    assert base2 == pytest.approx(-21795.8765195143, rel=4e-4)
+    assert base == pytest.approx(-21372.581099, rel=1e-9)
+    assert base2 == pytest.approx(-21789.326070, rel=1e-9)
+    duo = M.setup_montecarlo("CIT-7", FFNAME, [_mol("Na", [[1.001641978413878, 8.638263743446769, 17.23737576131632]]),
+                                                _mol("Na", [[4.163424680441308, 16.12704796355876, 17.20994387427006]])])
+    bduo = float(M.baseline_energy(duo))
+    assert bduo == pytest.approx(-25957.746610866408, rel=1e-3)
+    assert bduo == pytest.approx(-25957.746610866408, rel=2e-4)            # observed 1.0e-4
+    assert bduo == pytest.approx(-25955.127617, rel=1e-9)
+
+
+def test_sodium_and_two_co2_in_cit7(oracle_grids):
+    """runtests.jl:243-266"""
+    na = [[3.019388765467742, 0.8997706038543032, 26.11901621898599]]
+    co2_1 = [[11.93940309885289, 8.48657378465003, 2.135736631609201], [11.10485516124311, 7.710040763525694, 1.991767166323031],
+             [10.27030722363334, 6.933507742401357, 1.84779770103686]]
+    co2_2 = [[5.491645446274333, 8.057854365959964, 8.669190836544463], [6.335120278303245, 7.462084936052019, 9.172986424179925],
+             [7.178595110332157, 6.866315506144074, 9.676782011815387]]
+    mc = M.setup_montecarlo("CIT-7", FFNAME, [_mol("Na", na), _mol("CO2", co2_1), _mol("CO2", co2_2)])
+    base = float(M.baseline_energy(mc))
+    assert base == pytest.approx(-28329.113561030445, rel=1e-3)
+    newna = [[0.9, 0.1, 1.5]]
+    diff_na = float(M.movement_energy(mc, (0, 0), newna) - M.movement_energy(mc, (0, 0)))
+    assert diff_na == pytest.approx(5440.529635958557, rel=1e-3)
+    mc_na = M.setup_montecarlo("CIT-7", FFNAME, [_mol("Na", newna), _mol("CO2", co2_1), _mol("CO2", co2_2)])
+    assert base + diff_na == pytest.approx(float(M.baseline_energy(mc_na)), rel=1e-8)   # runtests.jl:261
+    newco2 = [[1.3, 2.9, 1.149], [1.3, 2.9, 0.0], [1.3, 2.9, -1.149]]
+    diff_co2 = float(M.movement_energy(mc, (1, 1), newco2) - M.movement_energy(mc, (1, 1)))
+    mc_co2 = M.setup_montecarlo("CIT-7", FFNAME, [_mol("Na", na), _mol("CO2", co2_1), _mol("CO2", newco2)])
+    assert base + diff_co2 == pytest.approx(float(M.baseline_energy(mc_co2)), rel=1e-4)  # runtests.jl:266
+    assert base == pytest.approx(-28329.113561030445, rel=3e-4)            # observed 2.4e-4
+    assert diff_na == pytest.approx(5440.529635958557, rel=2e-5)           # observed 8.8e-6
+    assert base == pytest.approx(-28322.179659, rel=1e-9)
+    assert diff_na == pytest.approx(5440.481803253, rel=1e-9)
