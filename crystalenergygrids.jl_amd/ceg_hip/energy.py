@@ -119,3 +119,122 @@ class GpuEnergySetup:
             self.coulomb.close()
         if self.recip is not None:
             self.recip.close()
+
+
+class PairEnergies:
+    """Device-resident guest atoms + pair table (``ceg_pairs_*``): batched single_contribution_vdw."""
+
+    def __init__(self, ff, mat, invmat, device: int = 0):
+        from .constants import COULOMBIC_CONVERSION_FACTOR
+        self._lib = _abi.load_library()
+        self.ff = ff
+        rules, offsets = ff.pair_table()
+        self._keep = (rules, offsets)
+        h = C.c_void_p()
+        rc = self._lib.ceg_pairs_create(C.byref(h), device, _abi.dptr(_matT(mat)), _abi.dptr(_matT(invmat)), ff.cutoff ** 2,
+                                        rules.ctypes.data, _abi.i32ptr(offsets), ff.nkinds, COULOMBIC_CONVERSION_FACTOR)
+        _abi.check(self._lib, rc)
+        self._h = h
+
+    def set_atoms(self, positions, kinds, molecule) -> None:
+        """positions[N,3]; kinds 1-based ff indices; molecule ids (non-negative)."""
+        pos = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, 3)
+        k = np.ascontiguousarray(np.asarray(kinds, dtype=np.int32) - 1)
+        mol = np.ascontiguousarray(molecule, dtype=np.int32)
+        _abi.check(self._lib, self._lib.ceg_pairs_set_atoms(self._h, _abi.dptr(pos.reshape(-1)), _abi.i32ptr(k), _abi.i32ptr(mol), len(pos)))
+
+    def energies(self, trial, trial_kinds, exclude_molecule: int = -1) -> np.ndarray:
+        tk = np.ascontiguousarray(np.asarray(trial_kinds, dtype=np.int32) - 1)
+        t = np.ascontiguousarray(trial, dtype=np.float64).reshape(-1, len(tk), 3)
+        out = np.empty(len(t), dtype=np.float64)
+        _abi.check(self._lib, self._lib.ceg_pairs_energy(self._h, _abi.dptr(t.reshape(-1)), _abi.i32ptr(tk), len(tk), len(t),
+                                                         exclude_molecule, _abi.dptr(out)))
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.ceg_pairs_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GpuMonteCarloEnergy:
+    """``movement_energy`` (montecarlo.jl:563-579) of a :class:`ceg_hip.montecarlo.MonteCarloSetup` for
+    many trial placements at once: framework terms by batched grid interpolation, guest-guest terms by
+    ``ceg_pairs_*``, reciprocal term by ``ceg_recip_*`` against the structure factor of everything else."""
+
+    def __init__(self, mc, device: int = 0):
+        from . import montecarlo as M
+        self.mc, self._M = mc, M
+        self.interp = [GridInterpolator(g, device) if (g is not None and g.ewald_precision == math.inf) else None for g in mc.grids]
+        self.has_coulomb = mc.coulomb.ewald_precision != -math.inf
+        self.coulomb = GridInterpolator(mc.coulomb, device) if self.has_coulomb else None
+        self.recip = ReciprocalEwald(mc.ewald, device) if mc.ewald.alpha != 0.0 else None
+        self.pairs = PairEnergies(mc.ff, mc.mat, mc.invmat, device)
+        self.refresh()
+
+    def refresh(self) -> None:
+        """Upload the current guest atoms (call after the host-side state changed)."""
+        mc = self.mc
+        pos, kinds, mol = [], [], []
+        for m, (i, j, ids, p) in enumerate(mc.molecules()):
+            pos.append(p)
+            kinds += list(ids)
+            mol += [m] * len(ids)
+        self.pairs.set_atoms(np.concatenate(pos) if pos else np.empty((0, 3)), kinds, mol)
+
+    def movement_energies(self, idx, positions) -> np.ndarray:
+        """-> float64[n, 4]: (framework vdw, framework direct, inter, reciprocal) of molecule ``idx``
+        (0-based (kind, molecule)) at each of ``positions[n, natoms, 3]``."""
+        mc, M = self.mc, self._M
+        i, j = idx
+        ids = mc.ffidx[i]
+        pos = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, len(ids), 3)
+        out = np.zeros((len(pos), 4))
+        if mc.grids:
+            for a, ix in enumerate(ids):
+                it = self.interp[ix - 1]
+                if it is not None:
+                    out[:, 0] += it(pos[:, a])
+                if self.has_coulomb:
+                    c = self.coulomb(pos[:, a])
+                    out[:, 1] += np.where(c == 1e100, c, float(mc.charges[ix]) * c)
+        out[:, 2] = self.pairs.energies(pos, ids, exclude_molecule=mc.flat_index(i, j))
+        if self.recip is not None:
+            rest = M.ewald_rest(mc, idx)
+            lib = self.recip._lib
+            _abi.check(lib, lib.ceg_recip_set_structure_factor(self.recip._h, _abi.dptr(np.ascontiguousarray(rest.real)),
+                                                               _abi.dptr(np.ascontiguousarray(rest.imag))))
+            q = np.ascontiguousarray([mc.charges[ix] for ix in ids], dtype=np.float64)
+            rec = np.empty(len(pos))
+            _abi.check(lib, lib.ceg_recip_energy(self.recip._h, _abi.dptr(pos.reshape(-1)), _abi.dptr(q), len(q), len(pos), 0.0, 0.0,
+                                                 _abi.dptr(rec)))
+            out[:, 3] = rec
+        return out
+
+    def baseline_energy(self):
+        """baseline_energy (montecarlo.jl:530-542) with the framework and guest-guest sums on the GPU
+        (each pair is seen from both molecules, hence the 1/2) and the many-molecule reciprocal sum on
+        the host."""
+        mc, M = self.mc, self._M
+        reciprocal = M.compute_ewald_mc(mc)
+        fv = fd = inter = 0.0
+        for i, j, ids, p in mc.molecules():
+            e = self.movement_energies((i, j), p[None])[0]
+            fv += e[0]; fd += e[1]; inter += e[2]
+        return M.BaselineEnergyReport(fv, fd, 0.5 * inter, reciprocal, mc.tailcorrection)
+
+    def close(self) -> None:
+        for it in self.interp:
+            if it is not None:
+                it.close()
+        if self.coulomb is not None:
+            self.coulomb.close()
+        if self.recip is not None:
+            self.recip.close()
+        self.pairs.close()

@@ -186,6 +186,24 @@ class ForceField:
             table[t]['shift'] = r.shift
         return table, np.asarray(offsets, dtype=np.int32)
 
+    def pair_table(self):
+        """Every pair rule flattened for ``ceg_pairs_create``: ``rules`` structured array and
+        ``rule_offset`` (nkinds*nkinds + 1 int32), pair (a, b) 0-based at index ``a*nkinds + b``."""
+        from ._abi import RULE_DTYPE
+        flat: List[InteractionRule] = []
+        offsets = [0]
+        for a in range(self.nkinds):
+            for b in range(self.nkinds):
+                flat.extend(rules_of(self.interactions[a][b]))
+                offsets.append(len(flat))
+        table = np.zeros(len(flat), dtype=RULE_DTYPE)
+        for t, r in enumerate(flat):
+            table[t]['kind'] = int(r.kind)
+            for q, v in enumerate(r.params[:3]):
+                table[t]['p'][q] = v
+            table[t]['shift'] = r.shift
+        return table, np.asarray(offsets, dtype=np.int32)
+
     def check_vdw_grid(self, probe: int, kinds_present: Iterable[int]) -> None:
         """Mirror the lazy Julia errors: only kinds actually met in the framework raise."""
         for k in sorted(set(int(x) for x in kinds_present)):

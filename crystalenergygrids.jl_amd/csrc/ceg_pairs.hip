@@ -1,0 +1,276 @@
+// ceg_pairs.hip -- guest-guest pair energy of a rigid molecule for many trial placements
+// (SURVEY 8f row f3): single_contribution_vdw_noneighbour, src/energy.jl:407-427, with
+// unsafe_periodic_distance2! (src/utils.jl:294-302) and the rule energies of
+// src/interactions.jl:367-406 / :589-595.
+//
+// One wave64 per placement: lanes stride over the guest atoms of the system (coalesced 32-B reads),
+// each lane loops over the <= 16 atoms of the molecule, wave reduction at the end.  The pair table
+// is small (kinds^2 rule runs) and read through the scalar/L1 path.  FP64 throughout, libm-grade
+// exp/erfc (ocml): this is a consumer kernel of a few thousand atoms, not the grid build.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "../../include/ceg_hip.h"
+#include "ceg_internal.h"
+
+using ceg::DevRule;
+
+extern "C" void ceg_set_last_error_(const char* msg);
+
+namespace {
+
+constexpr int PAIRS_MAX_ATOMS = 16;
+constexpr int PAIRS_WAVES = 4;
+
+struct PairsGeom {
+    double mat[9], invmat[9];
+    double cutoff2, coulombic;
+    int32_t nkinds, m, exclude;
+    int32_t kinds[PAIRS_MAX_ATOMS];
+};
+
+// (rule::InteractionRule)(r2) -- src/interactions.jl:392-406 (r2 forms) and :367-390 (r forms)
+__device__ __forceinline__ double rule_energy(const DevRule& R, double r2, double coulombic)
+{
+#pragma clang fp contract(off)
+    double v;
+    switch (R.kind) {
+    case CEG_LENNARDJONES: {
+        const double s2 = R.p1 * R.p1;
+        const double q = s2 / r2;
+        const double x6 = q * q * q;
+        v = 4.0 * R.p0 * x6 * (x6 - 1.0);
+        break;
+    }
+    case CEG_HARDSPHERE: {
+        const double s = R.p0 + R.p1;
+        v = (r2 < s * s) ? __builtin_huge_val() : 0.0;
+        break;
+    }
+    case CEG_NOINTERACTION: v = 0.0; break;
+    case CEG_MONOMIAL: v = R.p0 / pow(r2, R.p1 / 2.0); break;
+    case CEG_COULOMB_EWALD_DIRECT: {
+        const double r = sqrt(r2);
+        v = coulombic * R.p1 * R.p2 * erfc(R.p0 * r) / r;
+        break;
+    }
+    case CEG_COULOMB: v = coulombic * R.p0 * R.p1 / sqrt(r2); break;
+    case CEG_BUCKINGHAM: {
+        const double r = sqrt(r2);
+        const double r3 = r * r * r;
+        v = R.p0 * exp(-R.p1 * r) - R.p2 / (r3 * r3);
+        break;
+    }
+    case CEG_EXPONENTIAL: v = R.p0 * exp(-R.p1 * sqrt(r2)); break;
+    default: v = __builtin_nan(""); break;          // UndefinedInteraction is refused at create time
+    }
+    return v - R.shift;
+}
+
+__global__ __launch_bounds__(64 * PAIRS_WAVES) void k_pairs(PairsGeom g, const DevRule* __restrict__ rules,
+                                                             const int32_t* __restrict__ offset,
+                                                             const double4* __restrict__ atoms,      // x, y, z, (kind | molecule) bits
+                                                             int64_t natoms, const double* __restrict__ trial, int64_t n,
+                                                             double* __restrict__ out)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * PAIRS_WAVES + wave;
+    if (p >= n) return;
+    __shared__ double s_trial[PAIRS_WAVES][PAIRS_MAX_ATOMS * 3];
+    double* t3 = s_trial[wave];
+    if (lane < 3 * g.m) t3[lane] = trial[(size_t)p * g.m * 3 + lane];
+    __builtin_amdgcn_wave_barrier();
+    const double* M = g.mat;
+    const double* I = g.invmat;
+    double e = 0.0;
+    for (int64_t l = lane; l < natoms; l += 64) {
+        const double4 A = atoms[l];
+        const long long bits = __double_as_longlong(A.w);
+        const int kind1 = (int)(bits & 0xffffffffll), mol = (int)(bits >> 32);
+        if (mol == g.exclude) continue;
+        for (int a = 0; a < g.m; ++a) {
+            double r2;
+            {
+#pragma clang fp contract(off)
+                // buffer = pos2 - pos1 (energy.jl:420); invmat * buffer; wrap; mat * frac; norm2
+                const double dx = t3[3 * a] - A.x, dy = t3[3 * a + 1] - A.y, dz = t3[3 * a + 2] - A.z;
+                double f0 = I[0] * dx + I[3] * dy + I[6] * dz;
+                double f1 = I[1] * dx + I[4] * dy + I[7] * dz;
+                double f2 = I[2] * dx + I[5] * dy + I[8] * dz;
+                f0 = ((f0 + 0.5) - floor(f0 + 0.5)) - 0.5;
+                f1 = ((f1 + 0.5) - floor(f1 + 0.5)) - 0.5;
+                f2 = ((f2 + 0.5) - floor(f2 + 0.5)) - 0.5;
+                const double vx = M[0] * f0 + M[3] * f1 + M[6] * f2;
+                const double vy = M[1] * f0 + M[4] * f1 + M[7] * f2;
+                const double vz = M[2] * f0 + M[5] * f1 + M[8] * f2;
+                r2 = vx * vx + vy * vy + vz * vz;
+            }
+            if (r2 < g.cutoff2) {
+                const int t = kind1 * g.nkinds + g.kinds[a];
+                for (int q = offset[t]; q < offset[t + 1]; ++q) e += rule_energy(rules[q], r2, g.coulombic);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
+    if (lane == 0) out[p] = e;
+}
+
+int perr(int code, const char* msg)
+{
+    ceg_set_last_error_(msg);
+    return code;
+}
+
+}  // namespace
+
+struct ceg_pairs {
+    int device = 0;
+    double mat[9], invmat[9];
+    double cutoff2 = 0.0, coulombic = 0.0;
+    int32_t nkinds = 0;
+    DevRule* d_rules = nullptr;
+    int32_t* d_offset = nullptr;
+    double4* d_atoms = nullptr;
+    int64_t natoms = 0, cap = 0;
+};
+
+extern "C" int ceg_pairs_create(ceg_pairs_t** handle, int32_t device, const double mat[9], const double invmat[9], double cutoff2,
+                                const ceg_rule_t* rules, const int32_t* rule_offset, int32_t nkinds, double coulombic)
+{
+    if (!handle || !mat || !invmat || !rule_offset || nkinds < 1 || nkinds > 4096 || !(cutoff2 > 0.0))
+        return perr(CEG_ERR_INVALID, "bad argument");
+    *handle = nullptr;
+    const int64_t nt = (int64_t)nkinds * nkinds;
+    if (rule_offset[0] != 0) return perr(CEG_ERR_INVALID, "rule_offset[0] must be 0");
+    for (int64_t t = 0; t < nt; ++t)
+        if (rule_offset[t + 1] < rule_offset[t]) return perr(CEG_ERR_INVALID, "rule_offset must be non-decreasing");
+    const int32_t nr = rule_offset[nt];
+    if (nr > 0 && !rules) return perr(CEG_ERR_INVALID, "rules missing");
+    std::vector<DevRule> dr((size_t)(nr > 0 ? nr : 1));
+    for (int32_t q = 0; q < nr; ++q) {
+        const ceg_rule_t& r = rules[q];
+        if (r.kind < CEG_HARDSPHERE || r.kind > CEG_NOINTERACTION) return perr(CEG_ERR_INVALID, "unknown rule kind");
+        if (r.kind == CEG_UNDEFINED_INTERACTION) return perr(CEG_ERR_RULE, "Undefined interaction");     // interactions.jl:386-387
+        dr[q].kind = r.kind; dr[q]._pad = 0;
+        dr[q].p0 = r.p[0]; dr[q].p1 = r.p[1]; dr[q].p2 = r.p[2]; dr[q].shift = r.shift;
+    }
+    if (ceg_device_count() <= 0) return perr(CEG_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= ceg_device_count()) return perr(CEG_ERR_NO_DEVICE, "device not present");
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (hipSetDevice(device) != hipSuccess) return perr(CEG_ERR_HIP, "hipSetDevice failed");
+    ceg_pairs* h = new ceg_pairs();
+    h->device = device;
+    for (int a = 0; a < 9; ++a) { h->mat[a] = mat[a]; h->invmat[a] = invmat[a]; }
+    h->cutoff2 = cutoff2; h->coulombic = coulombic; h->nkinds = nkinds;
+    bool ok = hipMalloc((void**)&h->d_rules, dr.size() * sizeof(DevRule)) == hipSuccess &&
+              hipMalloc((void**)&h->d_offset, (size_t)(nt + 1) * sizeof(int32_t)) == hipSuccess;
+    ok = ok && hipMemcpy(h->d_rules, dr.data(), dr.size() * sizeof(DevRule), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(h->d_offset, rule_offset, (size_t)(nt + 1) * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
+    if (prev >= 0) (void)hipSetDevice(prev);
+    if (!ok) {
+        ceg_pairs_destroy(h);
+        return perr(CEG_ERR_HIP, "could not upload the pair table");
+    }
+    *handle = h;
+    return CEG_OK;
+}
+
+extern "C" int ceg_pairs_destroy(ceg_pairs_t* h)
+{
+    if (!h) return CEG_OK;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (hipSetDevice(h->device) == hipSuccess) {
+        (void)hipFree(h->d_rules);
+        (void)hipFree(h->d_offset);
+        (void)hipFree(h->d_atoms);
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    delete h;
+    return CEG_OK;
+}
+
+extern "C" int ceg_pairs_set_atoms(ceg_pairs_t* h, const double* positions, const int32_t* kinds, const int32_t* molecule,
+                                   int64_t natoms)
+{
+    if (!h || natoms < 0 || (natoms > 0 && (!positions || !kinds || !molecule))) return perr(CEG_ERR_INVALID, "bad argument");
+    std::vector<double4> host((size_t)(natoms > 0 ? natoms : 1));
+    for (int64_t l = 0; l < natoms; ++l) {
+        if (kinds[l] < 0 || kinds[l] >= h->nkinds) return perr(CEG_ERR_INVALID, "atom kind outside the pair table");
+        if (molecule[l] < 0) return perr(CEG_ERR_INVALID, "molecule ids must be non-negative");
+        const long long bits = ((long long)molecule[l] << 32) | (long long)(uint32_t)kinds[l];
+        double w;
+        memcpy(&w, &bits, sizeof(w));
+        host[l] = make_double4(positions[3 * l], positions[3 * l + 1], positions[3 * l + 2], w);
+    }
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (hipSetDevice(h->device) != hipSuccess) return perr(CEG_ERR_HIP, "hipSetDevice failed");
+    bool ok = true;
+    if (natoms > h->cap) {
+        (void)hipFree(h->d_atoms);
+        h->d_atoms = nullptr;
+        h->cap = natoms + natoms / 2 + 64;
+        ok = hipMalloc((void**)&h->d_atoms, (size_t)h->cap * sizeof(double4)) == hipSuccess;
+        if (!ok) h->cap = 0;
+    }
+    if (ok && natoms > 0) ok = hipMemcpy(h->d_atoms, host.data(), (size_t)natoms * sizeof(double4), hipMemcpyHostToDevice) == hipSuccess;
+    if (prev >= 0) (void)hipSetDevice(prev);
+    if (!ok) return perr(CEG_ERR_HIP, "could not upload the guest atoms");
+    h->natoms = natoms;
+    return CEG_OK;
+}
+
+extern "C" int ceg_pairs_energy_device(ceg_pairs_t* h, const double* d_trial, const int32_t* trial_kinds, int32_t m, int64_t n,
+                                       int32_t exclude_molecule, double* d_out, void* stream)
+{
+    if (!h || n < 0 || m < 1 || !trial_kinds || (n > 0 && (!d_trial || !d_out))) return perr(CEG_ERR_INVALID, "bad argument");
+    if (m > PAIRS_MAX_ATOMS) return perr(CEG_ERR_UNSUPPORTED, "molecule has more atoms than the kernel holds in registers (16)");
+    if (n == 0) return CEG_OK;
+    PairsGeom g{};
+    for (int a = 0; a < 9; ++a) { g.mat[a] = h->mat[a]; g.invmat[a] = h->invmat[a]; }
+    g.cutoff2 = h->cutoff2; g.coulombic = h->coulombic; g.nkinds = h->nkinds; g.m = m; g.exclude = exclude_molecule;
+    for (int a = 0; a < m; ++a) {
+        if (trial_kinds[a] < 0 || trial_kinds[a] >= h->nkinds) return perr(CEG_ERR_INVALID, "trial atom kind outside the pair table");
+        g.kinds[a] = trial_kinds[a];
+    }
+    const int64_t nblocks = (n + PAIRS_WAVES - 1) / PAIRS_WAVES;
+    if (nblocks > 0x7fffffffLL) return perr(CEG_ERR_INVALID, "too many placements");
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (hipSetDevice(h->device) != hipSuccess) return perr(CEG_ERR_HIP, "hipSetDevice failed");
+    hipLaunchKernelGGL(k_pairs, dim3((unsigned)nblocks), dim3(64 * PAIRS_WAVES), 0, (hipStream_t)stream, g, h->d_rules, h->d_offset,
+                       h->d_atoms, h->natoms, d_trial, n, d_out);
+    const hipError_t e = hipGetLastError();
+    if (prev >= 0) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return perr(CEG_ERR_HIP, hipGetErrorString(e));
+    return CEG_OK;
+}
+
+extern "C" int ceg_pairs_energy(ceg_pairs_t* h, const double* trial, const int32_t* trial_kinds, int32_t m, int64_t n,
+                                int32_t exclude_molecule, double* out)
+{
+    if (!h || n < 0 || m < 1 || m > PAIRS_MAX_ATOMS || !trial_kinds || (n > 0 && (!trial || !out)))
+        return perr(m > PAIRS_MAX_ATOMS ? CEG_ERR_UNSUPPORTED : CEG_ERR_INVALID, "bad argument");
+    if (n == 0) return CEG_OK;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (hipSetDevice(h->device) != hipSuccess) return perr(CEG_ERR_HIP, "hipSetDevice failed");
+    double *d_p = nullptr, *d_o = nullptr;
+    const size_t np = (size_t)n * m * 3;
+    int rc = CEG_OK;
+    if (hipMalloc((void**)&d_p, sizeof(double) * np) != hipSuccess || hipMalloc((void**)&d_o, sizeof(double) * n) != hipSuccess)
+        rc = perr(CEG_ERR_HIP, "hipMalloc failed");
+    if (!rc && hipMemcpy(d_p, trial, sizeof(double) * np, hipMemcpyHostToDevice) != hipSuccess) rc = perr(CEG_ERR_HIP, "H2D failed");
+    if (!rc) rc = ceg_pairs_energy_device(h, d_p, trial_kinds, m, n, exclude_molecule, d_o, nullptr);
+    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = perr(CEG_ERR_HIP, "kernel execution failed");
+    if (!rc && hipMemcpy(out, d_o, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess) rc = perr(CEG_ERR_HIP, "D2H failed");
+    if (d_p) (void)hipFree(d_p);
+    if (d_o) (void)hipFree(d_o);
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return rc;
+}

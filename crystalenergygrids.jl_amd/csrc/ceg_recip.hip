@@ -149,6 +149,21 @@ extern "C" int ceg_recip_create(ceg_recip_t** handle, int32_t device, const int3
     return CEG_OK;
 }
 
+extern "C" int ceg_recip_set_structure_factor(ceg_recip_t* h, const double* sf_re, const double* sf_im)
+{
+    if (!h || (h->nk > 0 && (!sf_re || !sf_im))) return rerr(CEG_ERR_INVALID, "bad argument");
+    if (h->nk == 0) return CEG_OK;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (hipSetDevice(h->device) != hipSuccess) return rerr(CEG_ERR_HIP, "hipSetDevice failed");
+    // hipMemcpy from pageable memory is synchronous with respect to earlier work on the null stream;
+    // launches on other streams must be ordered by the caller (documented in INTEGRATION.md)
+    const bool ok = hipMemcpy(h->d_re, sf_re, h->nk * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+                    hipMemcpy(h->d_im, sf_im, h->nk * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return ok ? CEG_OK : rerr(CEG_ERR_HIP, "could not upload the structure factor");
+}
+
 extern "C" int ceg_recip_destroy(ceg_recip_t* h)
 {
     if (!h) return CEG_OK;

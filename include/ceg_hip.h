@@ -260,6 +260,46 @@ CEG_API int ceg_recip_energy_device(ceg_recip_t* handle, const double* d_positio
                                     int32_t natoms, int64_t n, double energy_net_charges,
                                     double static_contribution, double* d_out, void* stream);
 
+/* replace the structure factor the placements are summed against (same nk).  With
+ * sf = framework + all other guests ("rest" of single_contribution_ewald, src/ewald.jl:718-737) and
+ * energy_net_charges = static_contribution = 0, ceg_recip_energy* returns single_contribution_ewald
+ * of the moved molecule for every trial placement. */
+CEG_API int ceg_recip_set_structure_factor(ceg_recip_t* handle, const double* sf_re, const double* sf_im);
+
+/* ---- guest-guest pair energies for trial placements ---------------- */
+/*
+ * single_contribution_vdw (src/energy.jl:397-427, the exhaustive variant :407-427) of a rigid
+ * molecule against all other guest atoms of the system, for many trial placements at once:
+ *   E = sum_{atom k2 of the molecule} sum_{guest atom l1 not of the excluded molecule, d2 < cutoff2}
+ *           ff[kind(l1), kind(k2)](d2)
+ * d2 by unsafe_periodic_distance2! (src/utils.jl:294-302: wrap to the nearest image of the MC cell, no
+ * image search); rule energies as src/interactions.jl:367-406 (sum rules: :589-595), which includes the
+ * CoulombEwaldDirect pair term q_i q_j erfc(alpha r)/r that carries the real-space guest-guest Ewald sum.
+ *
+ *  mat, invmat   MC cell (= supercell) matrix and inverse, column-major
+ *  rules, rule_offset[nkinds*nkinds + 1]   rule run of the pair (a, b), 0-based kinds, at index
+ *                a*nkinds + b (the table is symmetric); kinds rejected as for the grids -> CEG_ERR_RULE
+ *                only for UndefinedInteraction (every other kind has an energy form)
+ *  coulombic     COULOMBIC_CONVERSION_FACTOR in K A / e^2 (src/constants.jl), an argument like lambda
+ */
+typedef struct ceg_pairs ceg_pairs_t;
+
+CEG_API int ceg_pairs_create(ceg_pairs_t** handle, int32_t device, const double mat[9], const double invmat[9],
+                             double cutoff2, const ceg_rule_t* rules, const int32_t* rule_offset,
+                             int32_t nkinds, double coulombic);
+CEG_API int ceg_pairs_destroy(ceg_pairs_t* handle);
+/* the guest atoms currently in the system: positions [3*natoms] A, kinds [natoms] 0-based ff index,
+ * molecule [natoms] id of the molecule each atom belongs to (any non-negative labelling) */
+CEG_API int ceg_pairs_set_atoms(ceg_pairs_t* handle, const double* positions, const int32_t* kinds,
+                                const int32_t* molecule, int64_t natoms);
+/* trial [n][m][3] A, trial_kinds [m]; atoms with molecule id == exclude_molecule are skipped (-1: none);
+ * out [n] K.  Host memory, synchronous. */
+CEG_API int ceg_pairs_energy(ceg_pairs_t* handle, const double* trial, const int32_t* trial_kinds, int32_t m,
+                             int64_t n, int32_t exclude_molecule, double* out);
+/* trial / out in device memory, asynchronous on `stream` */
+CEG_API int ceg_pairs_energy_device(ceg_pairs_t* handle, const double* d_trial, const int32_t* trial_kinds,
+                                    int32_t m, int64_t n, int32_t exclude_molecule, double* d_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

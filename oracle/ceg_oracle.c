@@ -598,3 +598,74 @@ ORACLE_API int oracle_max_threads(void)
     return 1;
 #endif
 }
+
+/* ======================================================================================
+ * Row f3: guest-guest pair energy of a rigid molecule at a trial placement.
+ * src/energy.jl:407-427 single_contribution_vdw_noneighbour (rigid molecule: no intra term),
+ * src/utils.jl:294-302 unsafe_periodic_distance2!, src/interactions.jl:367-406 rule energies
+ * (r2 forms :392-406 for LJ / HardSphere / NoInteraction / Monomial, r forms otherwise),
+ * :589-595 for rule sums.
+ * ====================================================================================== */
+static double rule_energy_r(const ceg_rule_t* R, double r, double coulombic)
+{   /* interactions.jl:367-390 */
+    double v;
+    switch (R->kind) {
+    case CEG_LENNARDJONES: { double x6 = pow(R->p[1] / r, 6); v = 4 * R->p[0] * x6 * (x6 - 1); break; }
+    case CEG_COULOMB_EWALD_DIRECT: v = coulombic * R->p[1] * R->p[2] * erfc(R->p[0] * r) / r; break;
+    case CEG_COULOMB: v = coulombic * R->p[0] * R->p[1] / r; break;
+    case CEG_HARDSPHERE: v = (r < R->p[0] + R->p[1]) ? INFINITY : 0.0; break;
+    case CEG_BUCKINGHAM: v = R->p[0] * exp(-R->p[1] * r) - R->p[2] / pow(r, 6); break;
+    case CEG_NOINTERACTION: v = 0.0; break;
+    case CEG_MONOMIAL: v = R->p[0] / pow(r, R->p[1]); break;
+    case CEG_EXPONENTIAL: v = R->p[0] * exp(-R->p[1] * r); break;
+    default: v = NAN; break;
+    }
+    return v - R->shift;
+}
+
+static double rule_energy_r2(const ceg_rule_t* R, double r2, double coulombic)
+{   /* interactions.jl:392-406 */
+    switch (R->kind) {
+    case CEG_LENNARDJONES: { double s2 = R->p[1] * R->p[1]; double q = s2 / r2; double x6 = q * q * q;
+                             return 4 * R->p[0] * x6 * (x6 - 1) - R->shift; }
+    case CEG_HARDSPHERE: { double s = R->p[0] + R->p[1]; return ((r2 < s * s) ? INFINITY : 0.0) - R->shift; }
+    case CEG_NOINTERACTION: return 0.0 - R->shift;
+    case CEG_MONOMIAL: return R->p[0] / pow(r2, R->p[1] / 2) - R->shift;
+    default: return rule_energy_r(R, sqrt(r2), coulombic);
+    }
+}
+
+ORACLE_API void oracle_single_contribution_vdw(const double mat[9], const double invmat[9], double cutoff2,
+                                               const ceg_rule_t* rules, const int32_t* rule_offset, int32_t nkinds,
+                                               double coulombic, const double* positions, const int32_t* kinds,
+                                               const int32_t* molecule, int64_t natoms, const double* trial,
+                                               const int32_t* trial_kinds, int32_t m, int64_t n, int32_t exclude,
+                                               double* out, int32_t nthreads)
+{
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t p = 0; p < n; ++p) {
+        double energy = 0.0;
+        for (int32_t k2 = 0; k2 < m; ++k2) {                     /* energy.jl:415 */
+            const double* pos2 = trial + ((size_t)p * m + k2) * 3;
+            for (int64_t l1 = 0; l1 < natoms; ++l1) {             /* :417 */
+                if (molecule[l1] == exclude) continue;            /* :419 */
+                double buffer[3] = {pos2[0] - positions[3 * l1], pos2[1] - positions[3 * l1 + 1], pos2[2] - positions[3 * l1 + 2]};
+                double f[3];
+                matvec3(f, invmat, buffer);                       /* utils.jl:295 */
+                for (int i = 0; i < 3; ++i) { double diff = f[i] + 0.5; f[i] = diff - floor(diff) - 0.5; }
+                matvec3(buffer, mat, f);
+                const double d2 = norm2_3(buffer);
+                if (d2 < cutoff2) {                               /* energy.jl:422 */
+                    const int32_t t = kinds[l1] * nkinds + trial_kinds[k2];
+                    double e = 0.0;                               /* rule sum: interactions.jl:589-595 */
+                    for (int32_t q = rule_offset[t]; q < rule_offset[t + 1]; ++q) e += rule_energy_r2(&rules[q], d2, coulombic);
+                    energy += e;
+                }
+            }
+        }
+        out[p] = energy;
+    }
+}

@@ -70,6 +70,9 @@ def lib() -> C.CDLL:
         l.oracle_reciprocal_energies.restype = None
         l.oracle_reciprocal_energies.argtypes = [_i32p, C.c_int64, _i32p, _dp, _dp, _dp, C.c_int64, _dp, _dp, _dp, C.c_int32,
                                                  C.c_int64, C.c_double, C.c_double, _dp, C.c_int32]
+        l.oracle_single_contribution_vdw.restype = None
+        l.oracle_single_contribution_vdw.argtypes = [_dp, _dp, C.c_double, C.c_void_p, _i32p, C.c_int32, C.c_double, _dp, _i32p, _i32p,
+                                                     C.c_int64, _dp, _i32p, C.c_int32, C.c_int64, C.c_int32, _dp, C.c_int32]
         l.oracle_max_threads.restype = C.c_int
         l.oracle_max_threads.argtypes = []
         _lib = l
@@ -236,6 +239,29 @@ def reciprocal_energies(ef, molecule, positions, nthreads=0) -> np.ndarray:
     lib().oracle_reciprocal_energies(kind.ctypes.data_as(_i32p), len(kind), ks.ctypes.data_as(_i32p), _d(kf), _d(re), _d(im),
                                      len(kf), _d(_cm(ef.invmat)), _d(pos.reshape(-1)), _d(q), len(q), len(pos), enc, static,
                                      _d(out), nthreads)
+    return out
+
+
+def single_contribution_vdw(mc, idx, trial, nthreads=0) -> np.ndarray:
+    """single_contribution_vdw_noneighbour (energy.jl:407-427) of molecule ``idx`` = (kind, molecule),
+    0-based, of a ceg_hip.montecarlo.MonteCarloSetup at trial[n, natoms, 3]."""
+    from ceg_hip.constants import COULOMBIC_CONVERSION_FACTOR
+    rules, offsets = mc.ff.pair_table()
+    pos, kinds, mol = [], [], []
+    for m, (i, j, ids, p) in enumerate(mc.molecules()):
+        pos.append(p)
+        kinds += [k - 1 for k in ids]
+        mol += [m] * len(ids)
+    pos = np.ascontiguousarray(np.concatenate(pos) if pos else np.empty((0, 3)), dtype=np.float64)
+    kinds = np.ascontiguousarray(kinds, dtype=np.int32)
+    mol = np.ascontiguousarray(mol, dtype=np.int32)
+    tk = np.ascontiguousarray([k - 1 for k in mc.ffidx[idx[0]]], dtype=np.int32)
+    t = np.ascontiguousarray(trial, dtype=np.float64).reshape(-1, len(tk), 3)
+    out = np.empty(len(t), dtype=np.float64)
+    lib().oracle_single_contribution_vdw(_d(_cm(mc.mat)), _d(_cm(mc.invmat)), mc.ff.cutoff ** 2, rules.ctypes.data,
+                                         offsets.ctypes.data_as(_i32p), mc.ff.nkinds, COULOMBIC_CONVERSION_FACTOR, _d(pos.reshape(-1)),
+                                         kinds.ctypes.data_as(_i32p), mol.ctypes.data_as(_i32p), len(pos), _d(t.reshape(-1)),
+                                         tk.ctypes.data_as(_i32p), len(tk), len(t), mc.flat_index(*idx), _d(out), nthreads)
     return out
 
 

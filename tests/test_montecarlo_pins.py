@@ -122,3 +122,85 @@ def test_sodium_and_two_co2_in_cit7(oracle_grids):
     assert diff_na == pytest.approx(5440.529635958557, rel=2e-5)           # observed 8.8e-6
     assert base == pytest.approx(-28322.179659, rel=1e-9)
     assert diff_na == pytest.approx(5440.481803253, rel=1e-9)
+
+
+def _trio(M_):
+    na = [[3.019388765467742, 0.8997706038543032, 26.11901621898599]]
+    co2_1 = [[11.93940309885289, 8.48657378465003, 2.135736631609201], [11.10485516124311, 7.710040763525694, 1.991767166323031],
+             [10.27030722363334, 6.933507742401357, 1.84779770103686]]
+    co2_2 = [[5.491645446274333, 8.057854365959964, 8.669190836544463], [6.335120278303245, 7.462084936052019, 9.172986424179925],
+             [7.178595110332157, 6.866315506144074, 9.676782011815387]]
+    return M_.setup_montecarlo("CIT-7", FFNAME, [_mol("Na", na), _mol("CO2", co2_1), _mol("CO2", co2_2)])
+
+
+def test_oracle_pair_energy_equals_host_mirror(oracle, monkeypatch):
+    """Row f3 oracle (C restatement of single_contribution_vdw_noneighbour) against the Python mirror
+    that the literals above pin; includes trial positions that wrap around the MC cell and a close
+    contact."""
+    monkeypatch.setattr(M, "retrieve_or_create_grid", lambda *a, **k: G.EnergyGrid.trivial(True))
+    mc = _trio(M)
+    rng = np.random.default_rng(3)
+    for idx in ((0, 0), (1, 0), (1, 1)):
+        base = mc.positions[idx[0]][idx[1]]
+        trial = base[None] + np.concatenate([rng.uniform(-4, 4, (6, 1, 3)), rng.uniform(-80, 80, (6, 1, 3))])
+        got = oracle.single_contribution_vdw(mc, idx, trial)
+        ref = np.array([M.single_contribution_vdw(mc, idx, t) for t in trial])
+        np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-10)          # numpy matvec vs scalar sums: last-digit differences
+    # Na dropped 0.5 A from an oxygen of the first CO2: steep repulsive wall (6.5e10 K)
+    contact = mc.positions[1][0][0][None, None, :] + 0.3
+    assert oracle.single_contribution_vdw(mc, (0, 0), contact)[0] == pytest.approx(M.single_contribution_vdw(mc, (0, 0), contact[0]), rel=1e-10)
+
+
+@pytest.mark.gpu
+def test_gpu_montecarlo_energies(hip_lib, oracle, tmp_path):
+    """The same literals through the product path: CIT-7 grids (Ar, Na, O_co2, C_co2 VdW + Coulomb, 0.15 A,
+    2x3x3 supercell) built by the HIP kernels via setup_montecarlo, then movement energies of many trial
+    placements from the GPU consumers (interpolation, pair kernel, reciprocal kernel) against the host
+    mirror / oracle, and the runtests.jl literals from GPU-evaluated baselines."""
+    import os
+    from pathlib import Path
+    from ceg_hip.energy import GpuMonteCarloEnergy
+    golden = Path(__file__).parent / "golden" / "raspa"
+    raspa = tmp_path / "raspa"
+    raspa.mkdir()
+    for sub in ("forcefield", "molecules", "structures"):
+        os.symlink(golden / sub, raspa / sub)
+    ceg.setdir_RASPA(raspa)
+    try:
+        mc = _trio(M)
+        gm = GpuMonteCarloEnergy(mc)
+        base = M.baseline_energy(mc)                       # host: sets mc.sums
+        gbase = gm.baseline_energy()
+        assert float(gbase) == pytest.approx(float(base), rel=1e-10)
+        assert float(gbase) == pytest.approx(-28329.113561030445, rel=1e-3)           # runtests.jl:258
+        assert float(gbase) == pytest.approx(-28322.179659, rel=1e-7)                 # the CPU-oracle value of this repo
+        rng = np.random.default_rng(9)
+        for idx in ((0, 0), (1, 0), (1, 1)):
+            cur = mc.positions[idx[0]][idx[1]]
+            trial = cur[None] + np.concatenate([np.zeros((1, 1, 3)), rng.uniform(-2, 2, (40, 1, 3)), rng.uniform(-60, 60, (23, 1, 3))])
+            got = gm.movement_energies(idx, trial)
+            pair_ref = oracle.single_contribution_vdw(mc, idx, trial)
+            fin = np.isfinite(pair_ref)
+            assert np.array_equal(np.isfinite(got[:, 2]), fin)
+            assert np.all(np.abs(got[fin, 2] - pair_ref[fin]) <= 1e-10 * np.abs(pair_ref[fin]) + 1e-9)
+            for t in (0, 1, 41):
+                ref = M.movement_energy(mc, idx, trial[t])
+                r = np.array([ref.framework_vdw, ref.framework_direct, ref.inter, ref.reciprocal])
+                ok = np.isfinite(r)
+                assert np.all(np.abs(got[t][ok] - r[ok]) <= 1e-9 * np.abs(r[ok]) + 1e-7), (idx, t, got[t], r)
+        # runtests.jl:259-261: moving the Na
+        d = gm.movement_energies((0, 0), np.array([[[0.9, 0.1, 1.5]], mc.positions[0][0]]))
+        diff_na = d[0].sum() - d[1].sum()
+        assert diff_na == pytest.approx(5440.529635958557, rel=1e-3)
+        assert diff_na == pytest.approx(5440.481803253, rel=1e-7)
+        gm.close()
+        # two argon atoms (runtests.jl:192-199)
+        mc2 = M.setup_montecarlo("CIT-7", FFNAME, [_mol("Ar", [[-7.7365250811304911, 31.5070011601372251, 1.5285305931479920]]),
+                                                    _mol("Ar", [[10.7586599791867421, -2.3259182727570948, 20.5642722996513001]])])
+        gm2 = GpuMonteCarloEnergy(mc2)
+        M.baseline_energy(mc2)
+        b2 = float(gm2.baseline_energy())
+        assert b2 == pytest.approx(-1789.77383582, rel=1e-7)
+        gm2.close()
+    finally:
+        ceg.setdir_RASPA(golden)
