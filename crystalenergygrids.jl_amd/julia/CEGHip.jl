@@ -175,4 +175,66 @@ function install!()
     nothing
 end
 
+# ------------------------------------------------------------------ consumers of the grids (SURVEY 8f rows f1-f3)
+# Batched versions of interpolate_grid (src/grids.jl:212-273), compute_ewald(ctx) for one rigid molecule
+# (src/ewald.jl:555-577) and single_contribution_vdw (src/energy.jl:397-427).  Handles are opaque pointers.
+
+_pts(positions) = Float64[NoUnits(x/u"Å") for p in positions for x in p]
+
+"`ceg_interp_create` from a parsed `EnergyGrid` (the array is already in K, src/grids.jl:78)."
+function interp_handle(g::CEG.EnergyGrid; device=0)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    dims, size, shift, _ = _geometry(g.csetup)
+    mat = Vector{Float64}(vec(NoUnits.(g.csetup.cell.mat ./ u"Å")))
+    invmat = Vector{Float64}(vec(NoUnits.(g.csetup.cell.invmat .* u"Å")))
+    GC.@preserve g dims size shift mat invmat _check(ccall((:ceg_interp_create, LIB[]), Cint,
+        (Ref{Ptr{Cvoid}}, Int32, Ptr{Cfloat}, Int32, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32),
+        h, device, g.grid, 0, dims, size, shift, mat, invmat, g.ewald_precision == Inf))
+    h[]
+end
+
+"interpolate_grid(g, p) for every p of `positions` -> Vector{Float64} (K)"
+function interp_points(h::Ptr{Cvoid}, positions)
+    pts = _pts(positions); out = Vector{Float64}(undef, length(positions))
+    GC.@preserve pts out _check(ccall((:ceg_interp_points, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}),
+                                      h, pts, length(out), out))
+    out
+end
+
+"`ceg_recip_create` from an `EwaldFramework` (k-vectors in the order of kspace.kindices, src/ewald.jl:213-236)."
+function recip_handle(ef::EwaldFramework; device=0)
+    ijk = Int32[]
+    for (jy, jz, jxrange, _) in ef.kspace.kindices, jx in jxrange
+        push!(ijk, jx, jy, jz)
+    end
+    sf = ef.StoreRigidChargeFramework
+    re, im_ = Vector{Float64}(real.(sf)), Vector{Float64}(imag.(sf))
+    ks = Int32[ef.kspace.ks...]; invmat = Vector{Float64}(vec(ef.invmat))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve ijk re im_ ks invmat _check(ccall((:ceg_recip_create, LIB[]), Cint,
+        (Ref{Ptr{Cvoid}}, Int32, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Int32}, Ptr{Float64}),
+        h, device, ijk, ef.kfactors, re, im_, length(ef.kfactors), ks, invmat))
+    h[]
+end
+
+"compute_ewald for `placements` (each a vector of atom positions) of a molecule with `charges`; `enc`, `static` = ctx.energy_net_charges, ctx.static_contribution[] in K"
+function recip_energy(h::Ptr{Cvoid}, placements, charges::Vector{Float64}, enc::Float64, static::Float64)
+    pts = Float64[NoUnits(x/u"Å") for mol in placements for p in mol for x in p]
+    out = Vector{Float64}(undef, length(placements))
+    GC.@preserve pts charges out _check(ccall((:ceg_recip_energy, LIB[]), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int32, Int64, Float64, Float64, Ptr{Float64}),
+        h, pts, charges, length(charges), length(out), enc, static, out))
+    out
+end
+
+"single_contribution_vdw of a molecule with ff indices `idx2` at every trial placement; `h` from ceg_pairs_create / ceg_pairs_set_atoms"
+function pairs_energy(h::Ptr{Cvoid}, placements, idx2::Vector{Int}, exclude_molecule::Int)
+    pts = Float64[NoUnits(x/u"Å") for mol in placements for p in mol for x in p]
+    kinds = Int32.(idx2 .- 1); out = Vector{Float64}(undef, length(placements))
+    GC.@preserve pts kinds out _check(ccall((:ceg_pairs_energy, LIB[]), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int32}, Int32, Int64, Int32, Ptr{Float64}),
+        h, pts, kinds, length(kinds), length(out), exclude_molecule, out))
+    out
+end
+
 end # module
