@@ -41,6 +41,7 @@ PROTOTYPES = {
         C.c_int32, C.c_double, C.c_double, C.c_double,
         c_int32_p, c_double_p, c_double_p, c_double_p,
         C.c_double, C.c_double, c_float_p, C.c_int32]),
+    "ceg_release_cached_buffers": (C.c_int, []),
     "ceg_plan_create": (C.c_int, [
         C.POINTER(C.c_void_p), C.c_int32,
         c_double_p, c_int64_p, c_double_p, C.c_int64,

@@ -7,11 +7,17 @@
 #include "ceg_internal.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <unordered_map>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace ceg;
@@ -209,12 +215,77 @@ int convert_rules(ceg_plan* p, const ceg_rule_t* rules, const int32_t* rule_offs
     return CEG_OK;
 }
 
+// ---- small-block cache for the plan tables.  A plan is a dozen small device arrays; hipMalloc +
+// hipFree of those cost ~3 ms per plan, a third of the one-shot VdW build.  Blocks are kept by
+// (device, power-of-two size class) and handed back by ceg_plan_destroy after a device
+// synchronisation (hipFree's implicit one), so a cached block is never still in use by a kernel.
+struct BlockCache {
+    std::mutex m;
+    std::map<std::pair<int, size_t>, std::vector<void*>> idle;
+    std::unordered_map<void*, std::pair<int, size_t>> owner;
+    size_t idle_bytes = 0;
+};
+BlockCache g_blocks;
+constexpr size_t BLOCK_CACHE_LIMIT = 256ull << 20;
+
+hipError_t cached_malloc(void** out, size_t bytes)
+{
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    size_t cls = 512;
+    while (cls < bytes) cls <<= 1;
+    std::lock_guard<std::mutex> lock(g_blocks.m);
+    auto& list = g_blocks.idle[{dev, cls}];
+    if (!list.empty()) {
+        *out = list.back();
+        list.pop_back();
+        g_blocks.idle_bytes -= cls;
+        return hipSuccess;
+    }
+    if (hipError_t e = hipMalloc(out, cls); e != hipSuccess) return e;
+    g_blocks.owner[*out] = {dev, cls};
+    return hipSuccess;
+}
+
+void cached_free(void* ptr)         // caller has synchronised the device
+{
+    if (!ptr) return;
+    std::lock_guard<std::mutex> lock(g_blocks.m);
+    auto it = g_blocks.owner.find(ptr);
+    if (it == g_blocks.owner.end()) { (void)hipFree(ptr); return; }
+    const size_t cls = it->second.second;
+    if (g_blocks.idle_bytes + cls > BLOCK_CACHE_LIMIT) {
+        g_blocks.owner.erase(it);
+        (void)hipFree(ptr);
+        return;
+    }
+    g_blocks.idle[it->second].push_back(ptr);
+    g_blocks.idle_bytes += cls;
+}
+
+void block_cache_release()
+{
+    std::lock_guard<std::mutex> lock(g_blocks.m);
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    for (auto& kv : g_blocks.idle) {
+        if (hipSetDevice(kv.first.first) != hipSuccess) continue;
+        for (void* ptr : kv.second) {
+            g_blocks.owner.erase(ptr);
+            (void)hipFree(ptr);
+        }
+        kv.second.clear();
+    }
+    g_blocks.idle_bytes = 0;
+    if (prev >= 0) (void)hipSetDevice(prev);
+}
+
 template <class T>
 int upload(T** dst, const T* src, size_t n)
 {
     *dst = nullptr;
     if (n == 0) n = 1;  // keep pointers valid
-    HIP_TRY(hipMalloc((void**)dst, n * sizeof(T)));
+    HIP_TRY(cached_malloc((void**)dst, n * sizeof(T)));
     if (src) HIP_TRY(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
     return CEG_OK;
 }
@@ -258,9 +329,11 @@ int build_images(ceg_plan* p)
             }
         }
         int n0[3], n1[3];
+        // an image pa + M n lies in the box only if n = I (P - pa) is inside the fractional hull of
+        // the box corners, i.e. fmin <= n <= fmax componentwise (1e-9 guards the rounding of I*d)
         for (int q = 0; q < 3; ++q) {
-            n0[q] = (int)std::floor(fmin[q]) - 1;
-            n1[q] = (int)std::ceil(fmax[q]) + 1;
+            n0[q] = (int)std::ceil(fmin[q] - 1e-9);
+            n1[q] = (int)std::floor(fmax[q] + 1e-9);
         }
         for (int nx = n0[0]; nx <= n1[0]; ++nx)
             for (int ny = n0[1]; ny <= n1[1]; ++ny)
@@ -325,8 +398,28 @@ int build_images(ceg_plan* p)
 // [alpha*R_EXACT, alpha*cutoff] as ERFCX_TAB_N degree-5 pieces (Chebyshev-node interpolation in
 // long double), and 2^(j/64).  Returns false (fast path disabled, libm-grade erfc used instead)
 // if the fit does not reach 1e-14.
+bool build_ewald_tables_uncached(double alpha, double cutoff2, std::vector<double>& tab, std::vector<double>& exp2_tab,
+                                 double* inv_h_out, double* mx0_inv_h_out);
+
+// the long-double fit takes ~2 ms; every Coulomb grid of a run uses the same (alpha, cutoff)
 bool build_ewald_tables(double alpha, double cutoff2, std::vector<double>& tab, std::vector<double>& exp2_tab,
                         double* inv_h_out, double* mx0_inv_h_out)
+{
+    struct Memo { bool valid = false, ok = false; double alpha = 0, cutoff2 = 0, inv_h = 0, mx0 = 0; std::vector<double> tab, e2; };
+    static std::mutex m;
+    static Memo memo;
+    std::lock_guard<std::mutex> lock(m);
+    if (!(memo.valid && memo.alpha == alpha && memo.cutoff2 == cutoff2)) {
+        memo.tab.clear(); memo.e2.clear();
+        memo.ok = build_ewald_tables_uncached(alpha, cutoff2, memo.tab, memo.e2, &memo.inv_h, &memo.mx0);
+        memo.alpha = alpha; memo.cutoff2 = cutoff2; memo.valid = true;
+    }
+    tab = memo.tab; exp2_tab = memo.e2; *inv_h_out = memo.inv_h; *mx0_inv_h_out = memo.mx0;
+    return memo.ok;
+}
+
+bool build_ewald_tables_uncached(double alpha, double cutoff2, std::vector<double>& tab, std::vector<double>& exp2_tab,
+                                 double* inv_h_out, double* mx0_inv_h_out)
 {
     const int N = CEG_ERFCX_TAB_N;
     const long double x0 = (long double)alpha * std::sqrt((long double)CEG_R_EXACT2) * (1.0L - 1e-6L);
@@ -402,6 +495,13 @@ extern "C" int ceg_plan_create(ceg_plan_t** plan, int32_t device,
     if (!plan) return fail(CEG_ERR_INVALID, "plan is NULL");
     *plan = nullptr;
     if (int rc = check_common(pos, natoms, mat, invmat, dims, size, shift, delta)) return rc;
+    const bool trace = std::getenv("CEG_HIP_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto stamp = [&](const char* what) {
+        if (trace)
+            fprintf(stderr, "[ceg plan] %-28s %8.3f ms\n", what,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    };
     const int ndev = ceg_device_count();
     if (ndev <= 0) return fail(CEG_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
     if (device < 0 || device >= ndev) return fail(CEG_ERR_NO_DEVICE, "device %d not present (%d devices)", device, ndev);
@@ -453,6 +553,7 @@ extern "C" int ceg_plan_create(ceg_plan_t** plan, int32_t device,
     p->can_cull = std::isfinite(cutoff2) && cutoff2 > 0 &&
                   std::min(w[0], std::min(w[1], w[2])) >= 2.0 * cutoff * (1.0 - 1e-12);
 
+    stamp("host: rules, geometry");
     DeviceGuard guard(device);
     if (!guard.ok) {
         delete p;
@@ -468,7 +569,9 @@ extern "C" int ceg_plan_create(ceg_plan_t** plan, int32_t device,
         if (p->h_offset.empty()) p->h_offset.assign(1, 0);
         rc = upload(&p->d_offset, p->h_offset.data(), p->h_offset.size());
     }
+    stamp("atom / rule tables uploaded");
     if (!rc && p->can_cull) rc = build_images(p);
+    stamp("images built + uploaded");
     if (!rc && p->can_cull) {
         PlanConst hc{};
         hc.g = p->g;
@@ -498,6 +601,7 @@ extern "C" int ceg_plan_create(ceg_plan_t** plan, int32_t device,
         }
         if (!rc) rc = upload(&p->d_pc, &hc, 1);
     }
+    stamp("function tables, constants");
     if (rc) {
         ceg_plan_destroy(p);
         return rc;
@@ -510,18 +614,11 @@ extern "C" int ceg_plan_destroy(ceg_plan_t* p)
 {
     if (!p) return CEG_OK;
     DeviceGuard guard(p->device);
-    (void)hipFree(p->d_atoms);
-    (void)hipFree(p->d_kind);
-    (void)hipFree(p->d_rules);
-    (void)hipFree(p->d_offset);
-    (void)hipFree(p->d_images);
-    (void)hipFree(p->d_imgkind);
-    (void)hipFree(p->d_imgatom);
-    (void)hipFree(p->d_binstart);
-    (void)hipFree(p->d_pc);
-    (void)hipFree(p->d_erfcx);
-    (void)hipFree(p->d_exp2);
-    (void)hipFree(p->d_fast);
+    (void)hipDeviceSynchronize();          // what hipFree would do: no kernel of this plan is still running
+    for (void* ptr : {(void*)p->d_atoms, (void*)p->d_kind, (void*)p->d_rules, (void*)p->d_offset, (void*)p->d_images,
+                      (void*)p->d_imgkind, (void*)p->d_imgatom, (void*)p->d_binstart, (void*)p->d_pc, (void*)p->d_erfcx,
+                      (void*)p->d_exp2, (void*)p->d_fast})
+        cached_free(ptr);
     delete p;
     return CEG_OK;
 }
@@ -679,6 +776,225 @@ inline void slab(int nx, int n, int d, int* begin, int* end)
     *end = *begin + base + (d < rem ? 1 : 0);
 }
 
+// ---- pinned staging buffers, kept across calls (page-locking costs more than the copy it serves)
+struct PinnedBuf { void* ptr; size_t bytes; bool busy; };
+std::mutex g_pinned_mutex;
+std::vector<PinnedBuf> g_pinned;
+
+// ---- device output slabs, kept across calls as well (hipMalloc + hipFree of 0.5 GB cost ~8 ms, as
+// much as the VdW kernel itself); one idle buffer per device is retained, see ceg_release_cached_buffers
+struct DeviceBuf { int device; void* ptr; size_t bytes; bool busy; };
+std::vector<DeviceBuf> g_devbufs;      // guarded by g_pinned_mutex
+
+// streams are expensive to create on ROCm (an HSA queue each, ~2 ms): keep a pair per device
+struct StreamPair { int device; hipStream_t comp, copy; bool busy; };
+std::vector<StreamPair> g_streams;     // guarded by g_pinned_mutex
+
+bool streams_acquire(int device, hipStream_t* comp, hipStream_t* copy)
+{
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    for (auto& p : g_streams)
+        if (p.device == device && !p.busy) { p.busy = true; *comp = p.comp; *copy = p.copy; return true; }
+    StreamPair sp{device, nullptr, nullptr, true};
+    if (hipStreamCreateWithFlags(&sp.comp, hipStreamNonBlocking) != hipSuccess) return false;
+    if (hipStreamCreateWithFlags(&sp.copy, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(sp.comp); return false; }
+    g_streams.push_back(sp);
+    *comp = sp.comp; *copy = sp.copy;
+    return true;
+}
+
+void streams_release(hipStream_t comp)
+{
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    for (auto& p : g_streams)
+        if (p.comp == comp) p.busy = false;
+}
+
+void* device_acquire(int device, size_t bytes)     // current device must be `device`
+{
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    for (auto& p : g_devbufs)
+        if (p.device == device && !p.busy && p.bytes >= bytes) { p.busy = true; return p.ptr; }
+    for (size_t t = 0; t < g_devbufs.size(); ++t)
+        if (g_devbufs[t].device == device && !g_devbufs[t].busy) {
+            (void)hipFree(g_devbufs[t].ptr);
+            g_devbufs.erase(g_devbufs.begin() + t);
+            break;
+        }
+    void* ptr = nullptr;
+    if (hipMalloc(&ptr, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    g_devbufs.push_back({device, ptr, bytes, true});
+    return ptr;
+}
+
+void device_release(void* ptr)
+{
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    for (auto& p : g_devbufs)
+        if (p.ptr == ptr) p.busy = false;
+}
+
+void* pinned_acquire(size_t bytes)
+{
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    for (auto& p : g_pinned)
+        if (!p.busy && p.bytes >= bytes) { p.busy = true; return p.ptr; }
+    for (size_t t = 0; t < g_pinned.size(); ++t)          // replace an idle, too small buffer
+        if (!g_pinned[t].busy) {
+            (void)hipHostFree(g_pinned[t].ptr);
+            g_pinned.erase(g_pinned.begin() + t);
+            break;
+        }
+    void* ptr = nullptr;
+    if (hipHostMalloc(&ptr, bytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    g_pinned.push_back({ptr, bytes, true});
+    return ptr;
+}
+
+void pinned_release(void* ptr)
+{
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    for (auto& p : g_pinned)
+        if (p.ptr == ptr) p.busy = false;
+}
+
+// copy `nseg` segments in parallel; first touch of a fresh destination is page-fault bound, and the
+// faults of different threads proceed in parallel
+struct Segment { float* dst; const float* src; size_t n; };
+void parallel_copy(const std::vector<Segment>& segs, int nthreads)
+{
+    // cut every segment into pieces of <= 1 MiB so that all threads have work
+    std::vector<Segment> pieces;
+    const size_t piece = 256 * 1024;
+    for (const auto& sg : segs)
+        for (size_t o = 0; o < sg.n; o += piece) pieces.push_back({sg.dst + o, sg.src + o, std::min(piece, sg.n - o)});
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const size_t t = next.fetch_add(1);
+            if (t >= pieces.size()) return;
+            std::memcpy(pieces[t].dst, pieces[t].src, pieces[t].n * sizeof(float));
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; ++t) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+}
+
+// One device's share of a one-shot build: x-planes [b, e) of the grid, computed in chunks of `cx`
+// planes; chunk j is copied D2H into a pinned ring slot (copy stream) and from there into the
+// caller's array (host threads) while chunk j+1.. are being computed.
+int device_pipeline(int mode, int d, int b, int e, int nx, int64_t plane, const double* pos, const int64_t* atomkind,
+                    const double* charge, int64_t natoms, const double* mat, const double* invmat, int32_t ortho,
+                    double safemin2, double cutoff2, const ceg_rule_t* rules, const int32_t* rule_offset, int32_t nkinds,
+                    double alpha, const int32_t* dims, const double* size, const double* shift, const double* delta,
+                    double lambda, double threshold, float* grid, int copy_threads, std::string* err)
+{
+    auto bad = [&](int code, const char* what) {
+        *err = std::string(what) + " (device " + std::to_string(d) + "): " + hipGetErrorString(hipGetLastError());
+        return code;
+    };
+    const int64_t npts = plane * nx;
+    const int64_t slab_pts = (int64_t)(e - b) * plane;
+    if (slab_pts <= 0) return CEG_OK;
+    const bool trace = std::getenv("CEG_HIP_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto stamp = [&](const char* what) {
+        if (trace)
+            fprintf(stderr, "[ceg one-shot dev %d] %-28s %8.3f ms\n", d, what,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    };
+    if (hipSetDevice(d) != hipSuccess) return bad(CEG_ERR_HIP, "hipSetDevice failed");
+    ceg_plan* plan = nullptr;
+    int rc = ceg_plan_create(&plan, d, pos, atomkind, charge, natoms, mat, invmat, ortho, safemin2, cutoff2, rules, rule_offset,
+                             nkinds, alpha, dims, size, shift, delta);
+    if (rc) { *err = g_err; return rc; }
+    stamp("plan created");
+    // chunk = a multiple of 4 planes (the kernel's tile edge) of about 32 MB over the 8 channels
+    int cx = (int)std::max<int64_t>(4, ((32ll << 20) / (plane * 8 * (int64_t)sizeof(float))) / 4 * 4);
+    cx = std::min(cx, (e - b + 3) / 4 * 4);
+    const int nchunks = (e - b + cx - 1) / cx;
+    const int R = std::min(3, nchunks);
+    const size_t slot_floats = (size_t)8 * cx * plane;
+    float* d_out = nullptr;
+    float* h_ring = nullptr;
+    hipStream_t s_comp = nullptr, s_copy = nullptr;
+    std::vector<hipEvent_t> ev_comp(nchunks, nullptr), ev_copy(nchunks, nullptr);
+    std::thread drain;
+    std::atomic<int> drained{0};
+    std::atomic<int> drain_rc{CEG_OK};
+    bool ok = streams_acquire(d, &s_comp, &s_copy) &&
+              (d_out = static_cast<float*>(device_acquire(d, sizeof(float) * 8 * slab_pts))) != nullptr;
+    for (int j = 0; j < nchunks && ok; ++j)
+        ok = hipEventCreateWithFlags(&ev_comp[j], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&ev_copy[j], hipEventDisableTiming) == hipSuccess;
+    if (ok) {
+        h_ring = static_cast<float*>(pinned_acquire(sizeof(float) * slot_floats * R));
+        ok = h_ring != nullptr;
+    }
+    if (!ok) rc = bad(CEG_ERR_HIP, "allocation of streams / buffers failed");
+    stamp("streams, buffers, pinned ring");
+    // all kernels up front: the compute stream runs them back to back
+    for (int j = 0; j < nchunks && !rc; ++j) {
+        const int cb = b + j * cx, ce = std::min(e, cb + cx);
+        rc = (mode == MODE_VDW) ? ceg_plan_build_vdw(plan, lambda, threshold, cb, ce, d_out, slab_pts, b, CEG_ALGO_AUTO, s_comp)
+                                : ceg_plan_build_coulomb(plan, lambda, threshold, cb, ce, d_out, slab_pts, b, CEG_ALGO_AUTO, s_comp);
+        if (rc) { *err = g_err; break; }
+        if (hipEventRecord(ev_comp[j], s_comp) != hipSuccess) rc = bad(CEG_ERR_HIP, "hipEventRecord failed");
+    }
+    std::atomic<int> enqueued{0};
+    stamp("kernels enqueued");
+    if (!rc) {
+        drain = std::thread([&]() {
+            (void)hipSetDevice(d);
+            for (int j = 0; j < nchunks; ++j) {
+                while (j >= enqueued.load()) std::this_thread::yield();
+                if (drain_rc.load() != CEG_OK) { drained.store(j + 1); continue; }
+                if (hipEventSynchronize(ev_copy[j]) != hipSuccess) { drain_rc.store(CEG_ERR_HIP); drained.store(j + 1); continue; }
+                const int cb = b + j * cx, ce = std::min(e, cb + cx);
+                const size_t cpts = (size_t)(ce - cb) * plane;
+                const float* slot = h_ring + (size_t)(j % R) * slot_floats;
+                std::vector<Segment> segs;
+                for (int c = 0; c < 8; ++c) segs.push_back({grid + (size_t)c * npts + (size_t)cb * plane, slot + (size_t)c * cpts, cpts});
+                parallel_copy(segs, copy_threads);
+                drained.store(j + 1);
+            }
+        });
+        for (int j = 0; j < nchunks && !rc; ++j) {
+            while (j - drained.load() >= R) std::this_thread::yield();        // ring slot still being emptied
+            const int cb = b + j * cx, ce = std::min(e, cb + cx);
+            const size_t cpts = (size_t)(ce - cb) * plane;
+            float* slot = h_ring + (size_t)(j % R) * slot_floats;
+            if (hipStreamWaitEvent(s_copy, ev_comp[j], 0) != hipSuccess) rc = bad(CEG_ERR_HIP, "hipStreamWaitEvent failed");
+            for (int c = 0; c < 8 && !rc; ++c)
+                if (hipMemcpyAsync(slot + (size_t)c * cpts, d_out + (size_t)c * slab_pts + (size_t)(cb - b) * plane, sizeof(float) * cpts,
+                                   hipMemcpyDeviceToHost, s_copy) != hipSuccess)
+                    rc = bad(CEG_ERR_HIP, "hipMemcpyAsync D2H failed");
+            if (!rc && hipEventRecord(ev_copy[j], s_copy) != hipSuccess) rc = bad(CEG_ERR_HIP, "hipEventRecord failed");
+            if (rc) drain_rc.store(rc);
+            enqueued.store(j + 1);
+        }
+        if (rc) enqueued.store(nchunks);       // let the drain thread run to its end
+        stamp("copies enqueued");
+        drain.join();
+        stamp("drained into caller array");
+        if (!rc && drain_rc.load() != CEG_OK) rc = bad(CEG_ERR_HIP, "kernel execution or D2H copy failed");
+    }
+    (void)hipStreamSynchronize(s_comp);
+    (void)hipStreamSynchronize(s_copy);
+    for (int j = 0; j < nchunks; ++j) {
+        if (ev_comp[j]) (void)hipEventDestroy(ev_comp[j]);
+        if (ev_copy[j]) (void)hipEventDestroy(ev_copy[j]);
+    }
+    if (h_ring) pinned_release(h_ring);
+    if (d_out) device_release(d_out);
+    if (s_comp) streams_release(s_comp);
+    ceg_plan_destroy(plan);
+    stamp("cleaned up");
+    return rc;
+}
+
 int oneshot(int mode, const double* pos, const int64_t* atomkind, const double* charge, int64_t natoms,
             const double* mat, const double* invmat, int32_t ortho, double safemin2, double cutoff2,
             const ceg_rule_t* rules, const int32_t* rule_offset, int32_t nkinds, double alpha,
@@ -692,57 +1008,63 @@ int oneshot(int mode, const double* pos, const int64_t* atomkind, const double* 
     if (ngpus < 1 || ngpus > ndev) return fail(CEG_ERR_NO_DEVICE, "ngpus = %d but %d HIP devices are present", ngpus, ndev);
     const int nx = dims[0] + 1;
     const int64_t plane = (int64_t)(dims[1] + 1) * (dims[2] + 1);
-    const int64_t npts = plane * nx;
     ngpus = std::min(ngpus, nx);
-
-    std::vector<ceg_plan*> plans(ngpus, nullptr);
-    std::vector<float*> d_out(ngpus, nullptr);
-    std::vector<hipStream_t> streams(ngpus, nullptr);
-    int rc = CEG_OK;
     int prev = -1;
     (void)hipGetDevice(&prev);
-    for (int d = 0; d < ngpus && !rc; ++d) {
-        rc = ceg_plan_create(&plans[d], d, pos, atomkind, charge, natoms, mat, invmat, ortho, safemin2, cutoff2,
-                             rules, rule_offset, nkinds, alpha, dims, size, shift, delta);
-        if (rc) break;
+    // host threads that move finished chunks from the pinned ring into the caller's array
+    int copy_threads = 8;
+    if (const char* env = std::getenv("CEG_HIP_COPY_THREADS")) copy_threads = std::max(1, atoi(env));
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw > 0) copy_threads = std::min<int>(copy_threads, (int)hw);
+    copy_threads = std::max(1, copy_threads / ngpus);
+
+    std::vector<int> rcs(ngpus, CEG_OK);
+    std::vector<std::string> errs(ngpus);
+    auto run = [&](int d) {
         int b, e;
         slab(nx, ngpus, d, &b, &e);
-        if (hipSetDevice(d) != hipSuccess) { rc = fail(CEG_ERR_HIP, "hipSetDevice(%d) failed", d); break; }
-        if (hipStreamCreateWithFlags(&streams[d], hipStreamNonBlocking) != hipSuccess) { rc = fail(CEG_ERR_HIP, "hipStreamCreate failed"); break; }
-        const int64_t slab_pts = (int64_t)(e - b) * plane;
-        if (hipMalloc((void**)&d_out[d], sizeof(float) * 8 * std::max<int64_t>(slab_pts, 1)) != hipSuccess) {
-            rc = fail(CEG_ERR_HIP, "hipMalloc of %lld bytes failed on device %d", (long long)(sizeof(float) * 8 * slab_pts), d);
-            break;
-        }
-        if (mode == MODE_VDW)
-            rc = ceg_plan_build_vdw(plans[d], lambda, threshold, b, e, d_out[d], slab_pts, b, CEG_ALGO_AUTO, streams[d]);
-        else
-            rc = ceg_plan_build_coulomb(plans[d], lambda, threshold, b, e, d_out[d], slab_pts, b, CEG_ALGO_AUTO, streams[d]);
-    }
-    // gather: each device's slab goes straight into its place in the host array (one copy per channel)
-    for (int d = 0; d < ngpus && !rc; ++d) {
-        int b, e;
-        slab(nx, ngpus, d, &b, &e);
-        const int64_t slab_pts = (int64_t)(e - b) * plane;
-        if (hipSetDevice(d) != hipSuccess) { rc = fail(CEG_ERR_HIP, "hipSetDevice(%d) failed", d); break; }
-        if (hipStreamSynchronize(streams[d]) != hipSuccess) { rc = fail(CEG_ERR_HIP, "kernel execution failed on device %d: %s", d, hipGetErrorString(hipGetLastError())); break; }
-        for (int c = 0; c < 8 && !rc; ++c)
-            if (slab_pts > 0 && hipMemcpy(grid + c * npts + (int64_t)b * plane, d_out[d] + c * slab_pts, sizeof(float) * slab_pts,
-                                          hipMemcpyDeviceToHost) != hipSuccess)
-                rc = fail(CEG_ERR_HIP, "hipMemcpy D2H failed on device %d", d);
-    }
-    for (int d = 0; d < ngpus; ++d) {
-        if (hipSetDevice(d) == hipSuccess) {
-            if (d_out[d]) (void)hipFree(d_out[d]);
-            if (streams[d]) (void)hipStreamDestroy(streams[d]);
-        }
-        if (plans[d]) ceg_plan_destroy(plans[d]);
-    }
+        rcs[d] = device_pipeline(mode, d, b, e, nx, plane, pos, atomkind, charge, natoms, mat, invmat, ortho, safemin2, cutoff2, rules,
+                                 rule_offset, nkinds, alpha, dims, size, shift, delta, lambda, threshold, grid, copy_threads, &errs[d]);
+    };
+    std::vector<std::thread> workers;
+    for (int d = 1; d < ngpus; ++d) workers.emplace_back(run, d);      // one host thread per extra device
+    run(0);
+    for (auto& w : workers) w.join();
     if (prev >= 0) (void)hipSetDevice(prev);
-    return rc;
+    for (int d = 0; d < ngpus; ++d)
+        if (rcs[d]) return fail(rcs[d], "%s", errs[d].c_str());
+    return CEG_OK;
 }
 
 }  // namespace
+
+extern "C" int ceg_release_cached_buffers(void)
+{
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    for (size_t t = g_devbufs.size(); t-- > 0;)
+        if (!g_devbufs[t].busy) {
+            if (hipSetDevice(g_devbufs[t].device) == hipSuccess) (void)hipFree(g_devbufs[t].ptr);
+            g_devbufs.erase(g_devbufs.begin() + t);
+        }
+    for (size_t t = g_pinned.size(); t-- > 0;)
+        if (!g_pinned[t].busy) {
+            (void)hipHostFree(g_pinned[t].ptr);
+            g_pinned.erase(g_pinned.begin() + t);
+        }
+    for (size_t t = g_streams.size(); t-- > 0;)
+        if (!g_streams[t].busy) {
+            if (hipSetDevice(g_streams[t].device) == hipSuccess) {
+                (void)hipStreamDestroy(g_streams[t].comp);
+                (void)hipStreamDestroy(g_streams[t].copy);
+            }
+            g_streams.erase(g_streams.begin() + t);
+        }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    block_cache_release();
+    return CEG_OK;
+}
 
 extern "C" int ceg_grid_vdw(const double* pos, const int64_t* atomkind, int64_t natoms,
                             const double mat[9], const double invmat[9],

@@ -132,6 +132,11 @@ CEG_API int ceg_grid_coulomb(const double* pos, const double* charge, int64_t na
                      double lambda, double threshold,
                      float* grid, int32_t ngpus);
 
+/* The one-shot entry points keep, per process, one idle device output slab per GPU and one pinned
+ * staging ring (page-locking / hipMalloc of 0.5 GB cost as much as the build itself).  This frees
+ * whatever is idle; safe to call at any time, never required. */
+CEG_API int ceg_release_cached_buffers(void);
+
 /* ---- resident-plan API (device buffers, caller-owned stream) ---------------- */
 /*
  * A plan is one ProbeSystem + one GridCoordinatesSetup made resident on one
