@@ -261,8 +261,53 @@ class BlockFile:
         return bool(self.block[a - 1, b - 1, c - 1])
 
 
+def read_block_spheres(file, csetup: GridCoordinatesSetup):
+    """The host part of parse_blockfile (coordinates.jl:113-133): sphere centres snapped through
+    offsetpoint / inverse_offsetpoint, squared radii -> (centers[n, 3], radius2[n])."""
+    from .coordinates import inverse_offsetpoint
+    with open(file) as f:
+        lines = f.read().splitlines()
+    num = int(lines.pop(0))
+    centers, radius2 = [], []
+    for l in lines[:num]:
+        sl = l.split()
+        radius = float(sl.pop())
+        _center = csetup.cell.mat @ np.array([float(x) for x in sl])
+        centers.append(inverse_offsetpoint(offsetpoint(_center, csetup), csetup))
+        radius2.append(radius * radius)          # the reference squares the parsed radius (:127, :132)
+    return np.array(centers, dtype=np.float64).reshape(-1, 3), np.array(radius2, dtype=np.float64)
+
+
+def parse_blockfile_gpu(file, csetup: GridCoordinatesSetup, device: int = 0) -> BlockFile:
+    """parse_blockfile with the point x sphere scan (coordinates.jl:139-152) on the GPU (``ceg_block_spheres``)."""
+    from .utils import prepare_periodic_distance_computations
+    centers, radius2 = read_block_spheres(file, csetup)
+    if len(radius2) == 0:
+        return BlockFile(csetup)
+    lib = _abi.load_library()
+    dims = np.ascontiguousarray(csetup.dims, dtype=np.int32)
+    ortho, safemin = prepare_periodic_distance_computations(csetup.cell.mat)
+    out = np.empty(tuple(int(d) + 1 for d in csetup.dims), dtype=np.uint8)
+    _abi.check(lib, lib.ceg_block_spheres(device, _abi.i32ptr(dims), _abi.dptr(np.ascontiguousarray(csetup.delta, dtype=np.float64)),
+                                          _abi.dptr(np.ascontiguousarray(csetup.shift, dtype=np.float64)), _abi.dptr(_matT(csetup.cell.mat)),
+                                          _abi.dptr(_matT(csetup.cell.invmat)), int(ortho), safemin ** 2,
+                                          _abi.dptr(np.ascontiguousarray(centers.reshape(-1))), _abi.dptr(radius2), len(radius2),
+                                          out.ctypes.data))
+    return BlockFile(csetup, out.astype(bool))
+
+
+def blockfile_from_grid_gpu(g: EnergyGrid, device: int = 0, threshold: float = 5e6) -> BlockFile:
+    """``BlockFile(g::EnergyGrid)`` (grids.jl:188-204) on the GPU (``ceg_block_from_grid``)."""
+    lib = _abi.load_library()
+    dims = np.ascontiguousarray(g.csetup.dims, dtype=np.int32)
+    value = np.ascontiguousarray(g.grid[0], dtype=np.float32)
+    out = np.empty(value.shape, dtype=np.uint8)
+    _abi.check(lib, lib.ceg_block_from_grid(device, value.ctypes.data, 0, _abi.i32ptr(dims), float(threshold), out.ctypes.data))
+    return BlockFile(g.csetup, out.astype(bool))
+
+
 def parse_blockfile(file, csetup: GridCoordinatesSetup) -> BlockFile:
-    """coordinates.jl:112-167 (min-image sphere test on every grid point)."""
+    """coordinates.jl:112-167 (min-image sphere test on every grid point), host-side numpy mirror."""
     from .coordinates import inverse_offsetpoint
     from .utils import prepare_periodic_distance_computations
     with open(file) as f:

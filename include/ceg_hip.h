@@ -305,6 +305,26 @@ CEG_API int ceg_pairs_energy(ceg_pairs_t* handle, const double* trial, const int
 CEG_API int ceg_pairs_energy_device(ceg_pairs_t* handle, const double* d_trial, const int32_t* trial_kinds,
                                     int32_t m, int64_t n, int32_t exclude_molecule, double* d_out, void* stream);
 
+/* ---- blocking masks on the grid lattice ----------------------------- */
+/*
+ * BlockFile(g::EnergyGrid), src/grids.jl:188-204: a lattice cell (i, j, k), i < dims[0] etc., whose
+ * value g.grid[k,j,i,1] exceeds `threshold` (5e6 K there) blocks its 8 corners.
+ *  value   [(dims[0]+1)*(dims[1]+1)*(dims[2]+1)] float = channel 0 of the grid (host or device memory)
+ *  block   [same count] uint8 out, host memory, [x][y][z] with z fastest, 1 = blocked
+ */
+CEG_API int ceg_block_from_grid(int32_t device, const float* value, int32_t value_on_device,
+                                const int32_t dims[3], double threshold, uint8_t* block);
+/*
+ * The scan of parse_blockfile, src/coordinates.jl:139-152: lattice point (i, j, k) (0-based here) at
+ * inverse_offsetpoint = (i, j, k) .* delta .+ shift (src/coordinates.jl:68-70) is blocked iff its
+ * minimum-image distance (periodic_distance2_fromcartesian!, src/utils.jl:210-246, UNIT cell `mat`)
+ * to the centre of one of the spheres is < radius.  centers [3*nspheres] are the snapped centres the
+ * reference computes on the host (:128-131); radius2 [nspheres] = radius^2.
+ */
+CEG_API int ceg_block_spheres(int32_t device, const int32_t dims[3], const double delta[3], const double shift[3],
+                              const double mat[9], const double invmat[9], int32_t ortho, double safemin2,
+                              const double* centers, const double* radius2, int32_t nspheres, uint8_t* block);
+
 #ifdef __cplusplus
 }
 #endif

@@ -669,3 +669,47 @@ ORACLE_API void oracle_single_contribution_vdw(const double mat[9], const double
         out[p] = energy;
     }
 }
+
+/* ======================================================================================
+ * Row f4: blocking masks.
+ * src/grids.jl:188-204 BlockFile(g::EnergyGrid); src/coordinates.jl:139-152 the scan of parse_blockfile.
+ * Masks are uint8 [x][y][z], z fastest (Julia's block[i,j,k] with i = x).
+ * ====================================================================================== */
+ORACLE_API void oracle_block_from_grid(const float* value, const int32_t dims[3], double threshold, uint8_t* block)
+{
+    const int64_t a = dims[0] + 1, b = dims[1] + 1, c = dims[2] + 1;
+    memset(block, 0, (size_t)(a * b * c));
+#define BLK(i, j, k) block[(k) + c * ((j) + b * (i))]
+    for (int64_t i = 0; i < a - 1; ++i)                            /* grids.jl:191: 1:a-1 etc. */
+        for (int64_t j = 0; j < b - 1; ++j)
+            for (int64_t k = 0; k < c - 1; ++k)
+                if (value[k + c * (j + b * i)] > (float)threshold) {   /* g.grid[k,j,i,1] > 5e6 */
+                    BLK(i, j, k) = 1; BLK(i + 1, j, k) = 1; BLK(i, j + 1, k) = 1; BLK(i + 1, j + 1, k) = 1;
+                    BLK(i, j, k + 1) = 1; BLK(i + 1, j, k + 1) = 1; BLK(i, j + 1, k + 1) = 1; BLK(i + 1, j + 1, k + 1) = 1;
+                }
+#undef BLK
+}
+
+ORACLE_API void oracle_block_spheres(const int32_t dims[3], const double delta[3], const double shift[3], const double mat[9],
+                                     const double invmat[9], int32_t ortho, double safemin2, const double* centers,
+                                     const double* radius2, int32_t nspheres, uint8_t* block, int32_t nthreads)
+{
+    const int64_t a = dims[0] + 1, b = dims[1] + 1, c = dims[2] + 1;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t i = 0; i < a; ++i)
+        for (int64_t j = 0; j < b; ++j)
+            for (int64_t k = 0; k < c; ++k) {
+                /* inverse_offsetpoint(SVector(i,j,k)), coordinates.jl:68-70, 1-based there */
+                const double p[3] = {(double)i * delta[0] + shift[0], (double)j * delta[1] + shift[1], (double)k * delta[2] + shift[2]};
+                uint8_t blocked = 0;
+                for (int32_t s = 0; s < nspheres; ++s) {              /* :145-151 */
+                    double buffer[3] = {centers[3 * s] - p[0], centers[3 * s + 1] - p[1], centers[3 * s + 2] - p[2]};
+                    double buffer2[3];
+                    if (periodic_distance2_fromcartesian(buffer, mat, invmat, ortho, safemin2, buffer2) < radius2[s]) { blocked = 1; break; }
+                }
+                block[k + c * (j + b * i)] = blocked;
+            }
+}

@@ -73,6 +73,10 @@ def lib() -> C.CDLL:
         l.oracle_single_contribution_vdw.restype = None
         l.oracle_single_contribution_vdw.argtypes = [_dp, _dp, C.c_double, C.c_void_p, _i32p, C.c_int32, C.c_double, _dp, _i32p, _i32p,
                                                      C.c_int64, _dp, _i32p, C.c_int32, C.c_int64, C.c_int32, _dp, C.c_int32]
+        l.oracle_block_from_grid.restype = None
+        l.oracle_block_from_grid.argtypes = [C.c_void_p, _i32p, C.c_double, C.c_void_p]
+        l.oracle_block_spheres.restype = None
+        l.oracle_block_spheres.argtypes = [_i32p, _dp, _dp, _dp, _dp, C.c_int32, C.c_double, _dp, _dp, C.c_int32, C.c_void_p, C.c_int32]
         l.oracle_max_threads.restype = C.c_int
         l.oracle_max_threads.argtypes = []
         _lib = l
@@ -263,6 +267,30 @@ def single_contribution_vdw(mc, idx, trial, nthreads=0) -> np.ndarray:
                                          kinds.ctypes.data_as(_i32p), mol.ctypes.data_as(_i32p), len(pos), _d(t.reshape(-1)),
                                          tk.ctypes.data_as(_i32p), len(tk), len(t), mc.flat_index(*idx), _d(out), nthreads)
     return out
+
+
+def block_from_grid(g, threshold=5e6) -> np.ndarray:
+    """BlockFile(g::EnergyGrid) (grids.jl:188-204) -> bool[nx, ny, nz]."""
+    dims = np.ascontiguousarray(g.csetup.dims, dtype=np.int32)
+    value = np.ascontiguousarray(g.grid[0], dtype=np.float32)
+    out = np.empty(value.shape, dtype=np.uint8)
+    lib().oracle_block_from_grid(value.ctypes.data, dims.ctypes.data_as(_i32p), float(threshold), out.ctypes.data)
+    return out.astype(bool)
+
+
+def block_spheres(csetup, centers, radius2, nthreads=0) -> np.ndarray:
+    """The scan of parse_blockfile (coordinates.jl:139-152) -> bool[nx, ny, nz]."""
+    from ceg_hip.utils import prepare_periodic_distance_computations
+    dims = np.ascontiguousarray(csetup.dims, dtype=np.int32)
+    ortho, safemin = prepare_periodic_distance_computations(csetup.cell.mat)
+    c = np.ascontiguousarray(centers, dtype=np.float64).reshape(-1, 3)
+    r2 = np.ascontiguousarray(radius2, dtype=np.float64)
+    out = np.empty(tuple(int(d) + 1 for d in csetup.dims), dtype=np.uint8)
+    lib().oracle_block_spheres(dims.ctypes.data_as(_i32p), _d(np.ascontiguousarray(csetup.delta, dtype=np.float64)),
+                               _d(np.ascontiguousarray(csetup.shift, dtype=np.float64)), _d(_cm(csetup.cell.mat)),
+                               _d(_cm(csetup.cell.invmat)), int(ortho), safemin ** 2, _d(c.reshape(-1)), _d(r2), len(r2),
+                               out.ctypes.data, nthreads)
+    return out.astype(bool)
 
 
 def max_threads() -> int:

@@ -641,3 +641,28 @@ def test_truncated_and_synthetic_workloads(hip_lib, oracle):
             lam, thr = G.coulomb_scaling()
             ref, _ = oracle.grid_coulomb(w.probe_coulomb, w.alpha, w.cset, lam, thr, i, i + 1)
             compare_grids(gc[:, i:i + 1], ref[:, i:i + 1], f"{w.name}/coulomb/plane{i}")
+
+
+# ------------------------------------------------------------------ row f4: blocking masks
+def test_block_masks_vs_oracle(hip_lib, oracle, tmp_path):
+    """ceg_block_spheres (parse_blockfile scan, literal min-image routine in the UNIT cell -- small cells,
+    image search live) and ceg_block_from_grid (BlockFile(::EnergyGrid)) against the oracle, bit for bit."""
+    root = GOLDEN / "raspa" / "structures" / "block"
+    synth = tmp_path / "five.block"
+    synth.write_text("5\n0.05 0.5 0.95 2.5\n0.5 0.5 0.5 4.0\n0.99 0.01 0.5 1.2\n0.3 0.7 0.1 0.9\n0.0 0.0 0.0 3.3\n")
+    for fwname, blk, sp in (("CIT7block", root / "CIT7block.block", 0.15), ("CHA_1.4_3b4eeb96", synth, 0.3), ("CIT-7", synth, 0.2)):
+        fw = ceg.load_framework_RASPA(fwname, "BoulfelfelSholl2021")
+        cset = ceg.GridCoordinatesSetup.from_cell(fw.mat, sp)
+        centers, r2 = G.read_block_spheres(blk, cset)
+        ref = oracle.block_spheres(cset, centers, r2)
+        got = G.parse_blockfile_gpu(blk, cset)
+        assert ref.any() and np.array_equal(got.block, ref), fwname
+    assert G.parse_blockfile_gpu(root / "CHA.block", cset).empty            # "0" file
+    # BlockFile(g) on a grid built by the HIP kernels (Na in CHA: hard-sphere walls above 5e6 K)
+    w = W.fixture_workload("CHA_1.4_3b4eeb96", "Na", 0.4)
+    gv = G.build_vdw_array(w.probe_vdw, w.cset)
+    gk = (gv.astype(np.float64) * ceg.GRID_TO_KELVIN).astype(np.float32)
+    eg = G.EnergyGrid(w.cset, (1, 1, 1), math.inf, True, gk)
+    ref = oracle.block_from_grid(eg)
+    got = G.blockfile_from_grid_gpu(eg)
+    assert ref.any() and not ref.all() and np.array_equal(got.block, ref)

@@ -1,5 +1,6 @@
 """The oracle reproduces the committed golden samples bit for bit (guards the checker itself
 against accidental edits; the samples were produced by tests/golden/make_golden.py)."""
+import math
 from pathlib import Path
 
 import numpy as np
@@ -90,3 +91,35 @@ def test_oracle_reciprocal_equals_host_mirror(oracle):
             got = oracle.reciprocal_energies(ef, mol, pos)
             ref = np.array([ceg.compute_ewald(ef, ((mol.with_positions(p),),)) for p in pos])
             np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-10 * np.abs(ref).max())
+
+
+def test_oracle_block_masks_equal_host_mirror(oracle, tmp_path):
+    """Row f4: literal restatement of the parse_blockfile scan and of BlockFile(::EnergyGrid) against the
+    numpy mirror (``ceg_hip.grids.parse_blockfile``, pinned by runtests.jl:269-272 in test_reference_pins)
+    on the reference's block file CIT7block (a sphere straddling a periodic boundary of a triclinic cell;
+    the other block files of the fixtures are empty) and on a synthetic file with five spheres in CHA."""
+    import ceg_hip as ceg
+    root = Path(__file__).parent / "golden" / "raspa" / "structures" / "block"
+    synth = tmp_path / "five.block"
+    synth.write_text("5\n0.05 0.5 0.95 2.5\n0.5 0.5 0.5 4.0\n0.99 0.01 0.5 1.2\n0.3 0.7 0.1 0.9\n0.0 0.0 0.0 3.3\n")
+    for fwname, blk, sp in (("CIT7block", root / "CIT7block.block", 0.5), ("CHA_1.4_3b4eeb96", synth, 0.6), ("CIT-7", synth, 0.45)):
+        fw = ceg.load_framework_RASPA(fwname, "BoulfelfelSholl2021")
+        cset = ceg.GridCoordinatesSetup.from_cell(fw.mat, sp)
+        ref = G.parse_blockfile(blk, cset)
+        centers, r2 = G.read_block_spheres(blk, cset)
+        got = oracle.block_spheres(cset, centers, r2)
+        assert ref.block.any() and np.array_equal(got, ref.block)
+    # BlockFile(g): synthetic value channel with isolated, edge and corner cells above 5e6
+    w = W.fixture_workload("CIT-7", "Ar", 0.8)
+    nx, ny, nz = w.cset.npoints
+    rng = np.random.default_rng(2)
+    grid = np.zeros((8, nx, ny, nz), dtype=np.float32)
+    grid[0] = rng.uniform(0, 5.2e6, (nx, ny, nz)).astype(np.float32)
+    grid[0, nx - 1, :, :] = 9e6                   # last plane: not a cell origin, must not block anything by itself
+    g = G.EnergyGrid(w.cset, (1, 1, 1), math.inf, True, grid)
+    got = oracle.block_from_grid(g)
+    ref = np.zeros((nx, ny, nz), dtype=bool)
+    hot = np.argwhere(grid[0, :nx - 1, :ny - 1, :nz - 1] > 5e6)
+    for i, j, k in hot:
+        ref[i:i + 2, j:j + 2, k:k + 2] = True
+    assert hot.size and np.array_equal(got, ref)
