@@ -3,12 +3,12 @@
 device-resident data (ceg_block_* itself also uploads / downloads)."""
 import os, sys, time, ctypes as C
 here = os.path.dirname(os.path.abspath(__file__))
-sys.path[:0] = [os.path.join(here, '..', 'crystalenergygrids.jl_amd'), os.path.join(here, '..')]
+sys.path[:0] = [os.path.join(here, '..', '..', 'crystalenergygrids.jl_amd'), os.path.join(here, '..', '..')]
 import numpy as np, torch
 import ceg_hip as ceg
 from ceg_hip import _abi, grids as G, workloads as W
 from oracle import oracle as O
-ceg.setdir_RASPA(os.path.join(here, "..", "tests", "golden", "raspa"))
+ceg.setdir_RASPA(os.path.join(here, "..", "golden", "raspa"))
 lib = _abi.load_library()
 dev = torch.device("cuda", 0)
 # --- BlockFile(g)

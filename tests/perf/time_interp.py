@@ -2,7 +2,7 @@
 (CHA fixture, 0.15 A, Ar VdW grid), random positions; CPU oracle (literal COEFF*X) beside it."""
 import os, sys, time, math
 here = os.path.dirname(os.path.abspath(__file__))
-sys.path[:0] = [os.path.join(here, '..', 'crystalenergygrids.jl_amd'), os.path.join(here, '..')]
+sys.path[:0] = [os.path.join(here, '..', '..', 'crystalenergygrids.jl_amd'), os.path.join(here, '..', '..')]
 import numpy as np, torch
 import ceg_hip as ceg
 from ceg_hip import workloads as W, grids as G, _abi

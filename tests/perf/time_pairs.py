@@ -2,13 +2,13 @@
 pair rules of the fixture force field) in a 40 A cubic MC cell, trial placements of one more CO2; CPU oracle beside it."""
 import os, sys, time
 here = os.path.dirname(os.path.abspath(__file__))
-sys.path[:0] = [os.path.join(here, '..', 'crystalenergygrids.jl_amd'), os.path.join(here, '..')]
+sys.path[:0] = [os.path.join(here, '..', '..', 'crystalenergygrids.jl_amd'), os.path.join(here, '..', '..')]
 import numpy as np, torch
 import ceg_hip as ceg
 from ceg_hip import _abi, montecarlo as M, grids as G, workloads as W
 from ceg_hip.energy import PairEnergies
 from oracle import oracle as O
-ceg.setdir_RASPA(os.path.join(here, '..', 'tests', 'golden', 'raspa'))
+ceg.setdir_RASPA(os.path.join(here, '..', 'golden', 'raspa'))
 ff = ceg.parse_forcefield_RASPA("BoulfelfelSholl2021")
 co2 = ceg.load_molecule_RASPA("CO2", "TraPPE", "BoulfelfelSholl2021")
 base = np.asarray(co2.position).reshape(-1, 3)

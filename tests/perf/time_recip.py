@@ -2,14 +2,14 @@
 Na (1 atom) and CO2 (3 atoms) placements; CPU oracle (literal tables + loop) beside it."""
 import os, sys, time
 here = os.path.dirname(os.path.abspath(__file__))
-sys.path[:0] = [os.path.join(here, '..', 'crystalenergygrids.jl_amd'), os.path.join(here, '..')]
+sys.path[:0] = [os.path.join(here, '..', '..', 'crystalenergygrids.jl_amd'), os.path.join(here, '..', '..')]
 import numpy as np, torch
 import ceg_hip as ceg
 from ceg_hip import _abi
 from ceg_hip.energy import ReciprocalEwald
 from ceg_hip.ewald import ewald_context_constants
 from oracle import oracle as O
-ceg.setdir_RASPA(os.path.join(here, '..', 'tests', 'golden', 'raspa'))
+ceg.setdir_RASPA(os.path.join(here, '..', 'golden', 'raspa'))
 fw = ceg.load_framework_RASPA("CHA_1.4_3b4eeb96", "BoulfelfelSholl2021")
 ef = ceg.initialize_ewald(fw, (1, 1, 1))
 rec = ReciprocalEwald(ef)
