@@ -666,3 +666,49 @@ def test_block_masks_vs_oracle(hip_lib, oracle, tmp_path):
     ref = oracle.block_from_grid(eg)
     got = G.blockfile_from_grid_gpu(eg)
     assert ref.any() and not ref.all() and np.array_equal(got.block, ref)
+
+
+def test_consumer_edge_cases(hip_lib, oracle):
+    """Empty and degenerate inputs of the f2/f3 entry points: no guest atoms, no placements, a molecule
+    larger than the kernels hold, a trial atom exactly on a guest atom (r = 0), the excluded molecule
+    being the only one."""
+    import ctypes as C
+    from ceg_hip import montecarlo as M
+    from ceg_hip.energy import PairEnergies, ReciprocalEwald
+    ff = ceg.parse_forcefield_RASPA("BoulfelfelSholl2021")
+    co2 = ceg.load_molecule_RASPA("CO2", "TraPPE", "BoulfelfelSholl2021")
+    base = np.asarray(co2.position, dtype=np.float64).reshape(-1, 3)
+    ids = [ff.sdict[a] for a in co2.atomic_symbol]
+    mat = np.array([[30.0, 0, 0], [2.0, 31.0, 0], [-3.0, 1.0, 29.0]]).T
+    charges = np.full(len(ff.sdict) + 1, np.nan)
+    for k, ix in enumerate(ids):
+        charges[ix] = co2.atomic_charge[k]
+    guests = [base + np.array([5.0, 5.0, 5.0]), base + np.array([9.0, 6.0, 5.5])]
+    mc = M.MonteCarloSetup(ff, mat, np.linalg.inv(mat), [ids], charges, [guests], ceg.EwaldFramework.empty(mat),
+                           G.EnergyGrid.trivial(True), [], 0.0)
+    pe = PairEnergies(ff, mc.mat, mc.invmat)
+    trial = np.stack([base + np.array([7.0, 5.0, 5.0]), guests[1], base + np.array([35.0 + 7.0, 5.0 - 31.0, 5.0])])   # free, on top of guest 1, wrapped
+    # no guest atoms uploaded yet
+    assert np.array_equal(pe.energies(trial, ids), np.zeros(3))
+    pe.set_atoms(np.concatenate(guests), ids * 2, [0, 0, 0, 1, 1, 1])
+    assert len(pe.energies(np.empty((0, 3, 3)), ids)) == 0
+    got = pe.energies(trial, ids, exclude_molecule=0)
+    ref = oracle.single_contribution_vdw(mc, (0, 0), trial)
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(np.isinf(got), np.isinf(ref))
+    fin = np.isfinite(ref)
+    assert np.allclose(got[fin], ref[fin], rtol=1e-10, atol=1e-9)
+    assert not np.isfinite(ref[1])                                   # r = 0 pairs: the reference's Inf/NaN, reproduced
+    # every guest excluded
+    pe.set_atoms(guests[0], ids, [0, 0, 0])
+    assert np.array_equal(pe.energies(trial, ids, exclude_molecule=0), np.zeros(3))
+    # 17-atom molecule: refused, not truncated
+    big = np.zeros((1, 17, 3))
+    rc = hip_lib.ceg_pairs_energy(pe._h, _abi.dptr(big.reshape(-1)), _abi.i32ptr(np.zeros(17, dtype=np.int32)), 17, 1, -1,
+                                  _abi.dptr(np.zeros(1)))
+    assert rc == -5
+    pe.close()
+    fw = ceg.load_framework_RASPA("CIT-7", "BoulfelfelSholl2021")
+    rec = ReciprocalEwald(ceg.initialize_ewald(fw))
+    rc = hip_lib.ceg_recip_energy(rec._h, _abi.dptr(big.reshape(-1)), _abi.dptr(np.zeros(17)), 17, 1, 0.0, 0.0, _abi.dptr(np.zeros(1)))
+    assert rc == -5 and b"16" in hip_lib.ceg_last_error()
+    rec.close()

@@ -51,6 +51,54 @@ def test_no_device_is_an_error_not_a_fallback():
         G.build_coulomb_array(w.probe_coulomb, w.alpha, w.cset)
 
 
+def test_consumer_entry_points_reject_bad_arguments_and_have_no_cpu_path():
+    """The f1-f4 entry points validate their arguments before touching a device (CEG_ERR_INVALID /
+    CEG_ERR_UNSUPPORTED, message through ceg_last_error) and, with valid arguments on a box without a
+    GPU, fail with CEG_ERR_NO_DEVICE -- never a CPU result."""
+    import ctypes as C
+    lib = _abi.load_library()
+    h = C.c_void_p()
+    ks = np.array([2, 2, 2], dtype=np.int32)
+    inv = np.eye(3).reshape(-1) / 30.0
+    ijk = np.array([[1, 0, 0], [0, 1, -2]], dtype=np.int32)
+    kf = np.ones(2); re_ = np.zeros(2); im_ = np.zeros(2)
+    # k-vector outside the (kx, ky, kz) box
+    bad = np.array([[3, 0, 0], [0, 1, -2]], dtype=np.int32)
+    assert lib.ceg_recip_create(C.byref(h), 0, _abi.i32ptr(bad.reshape(-1)), _abi.dptr(kf), _abi.dptr(re_), _abi.dptr(im_), 2,
+                                _abi.i32ptr(ks), _abi.dptr(inv)) == -1
+    assert b"k-vector" in lib.ceg_last_error()
+    # k-space box larger than the LDS tables
+    big = np.array([200, 200, 200], dtype=np.int32)
+    assert lib.ceg_recip_create(C.byref(h), 0, _abi.i32ptr(ijk.reshape(-1)), _abi.dptr(kf), _abi.dptr(re_), _abi.dptr(im_), 2,
+                                _abi.i32ptr(big), _abi.dptr(inv)) == -5
+    # pair table: decreasing offsets, undefined interaction
+    rules = np.zeros(1, dtype=_abi.RULE_DTYPE)
+    rules[0]["kind"] = 7
+    mat = np.eye(3).reshape(-1) * 30.0
+    off_bad = np.array([0, 1, 0, 1, 1], dtype=np.int32)
+    assert lib.ceg_pairs_create(C.byref(h), 0, _abi.dptr(mat), _abi.dptr(inv), 144.0, rules.ctypes.data, _abi.i32ptr(off_bad), 2,
+                                1.0) == -1
+    off = np.array([0, 1, 1, 1, 1], dtype=np.int32)
+    assert lib.ceg_pairs_create(C.byref(h), 0, _abi.dptr(mat), _abi.dptr(inv), 144.0, rules.ctypes.data, _abi.i32ptr(off), 2,
+                                1.0) == -4
+    assert b"Undefined" in lib.ceg_last_error()
+    # blocking masks: null pointers / empty dims
+    dims = np.array([3, 3, 3], dtype=np.int32)
+    assert lib.ceg_block_from_grid(0, None, 0, _abi.i32ptr(dims), 5e6, None) == -1
+    assert lib.ceg_release_cached_buffers() == 0
+    if lib.ceg_device_count() > 0:
+        return
+    # valid arguments, no device: loud failure
+    rc = lib.ceg_recip_create(C.byref(h), 0, _abi.i32ptr(ijk.reshape(-1)), _abi.dptr(kf), _abi.dptr(re_), _abi.dptr(im_), 2,
+                              _abi.i32ptr(ks), _abi.dptr(inv))
+    assert rc == -2 and b"no HIP device" in lib.ceg_last_error() and not h.value
+    rules[0]["kind"] = 3
+    assert lib.ceg_pairs_create(C.byref(h), 0, _abi.dptr(mat), _abi.dptr(inv), 144.0, rules.ctypes.data, _abi.i32ptr(off), 2, 1.0) == -2
+    value = np.zeros((4, 4, 4), dtype=np.float32)
+    out = np.zeros((4, 4, 4), dtype=np.uint8)
+    assert lib.ceg_block_from_grid(0, value.ctypes.data, 0, _abi.i32ptr(dims), 5e6, out.ctypes.data) == -2
+
+
 # ------------------------------------------------------------------ geometry
 def test_grid_coordinates_setup_cha():
     """coordinates.jl:32-41 on the CHA fixture (numbers of SURVEY appendix A)."""
