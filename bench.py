@@ -45,6 +45,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--mode", choices=("fused", "vdw", "coulomb"), default="fused")
+    ap.add_argument("--probe", default="Ar", help="probe atom of the VdW grid (Ar: LJ; Na: Buckingham + hard sphere)")
     ap.add_argument("--algo", choices=("auto", "bruteforce", "culled"), default="auto")
     ap.add_argument("--gather", choices=("staged", "inplace"), default="staged", help="how a gathered chunk is placed (N > 1)")
     ap.add_argument("--chunks", type=int, default=4, help="x-chunks per rank pipelined with the all-gather (N > 1)")
@@ -111,7 +112,7 @@ def main():
     from ceg_hip.distributed import PipelinedGather, allgather_grid, cyclic_plan, slab_range
     from ceg_hip.plan import GridPlan
 
-    w = W.roofline_workload("Ar", args.n)
+    w = W.roofline_workload(args.probe, args.n)
     nx, ny, nz = w.cset.npoints
     npts = nx * ny * nz
     algo = {"auto": _abi.ALGO_AUTO, "bruteforce": _abi.ALGO_BRUTEFORCE, "culled": _abi.ALGO_CULLED}[args.algo]

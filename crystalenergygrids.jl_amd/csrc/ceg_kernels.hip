@@ -315,6 +315,21 @@ __global__ __launch_bounds__(256) void k_bruteforce(Geom g, AtomTable atoms, Rul
     if (valid) write_results<MODE>(g, out, POINTS, t, i, j, k, av, ac, smallest_d2);
 }
 
+#ifndef CEG_WAVES_FUSED_BUCK
+#define CEG_WAVES_FUSED_BUCK CEG_WAVES
+#endif
+#ifndef CEG_WAVES_FUSED_LJ
+#define CEG_WAVES_FUSED_LJ CEG_WAVES
+#endif
+#ifndef CEG_WAVES_VDW_LJ
+#define CEG_WAVES_VDW_LJ CEG_WAVES
+#endif
+#ifndef CEG_WAVES_VDW_BUCK
+#define CEG_WAVES_VDW_BUCK CEG_WAVES
+#endif
+#ifndef CEG_WAVES_COULOMB
+#define CEG_WAVES_COULOMB CEG_WAVES
+#endif
 #ifndef CEG_WAVES
 #define CEG_WAVES 4      // waves per SIMD the register allocator is asked to allow
 #endif
@@ -322,6 +337,16 @@ __global__ __launch_bounds__(256) void k_bruteforce(Geom g, AtomTable atoms, Rul
 #define CEG_WG 256       // threads per workgroup of k_culled (one tile per wave)
 #endif
 // pairs closer than this (A^2) take the literal min-image arithmetic in the culled kernel
+// waves per SIMD the register allocator plans for, per variant (measured, profiles/r01_variant_waves.txt)
+constexpr int culled_waves(int mode, int vdwk, bool fastew)
+{
+    return (mode == 2 && vdwk == 2 && fastew) ? CEG_WAVES_FUSED_BUCK
+           : (mode == 2 && vdwk == 1 && fastew) ? CEG_WAVES_FUSED_LJ
+           : (mode == 0 && vdwk == 1)         ? CEG_WAVES_VDW_LJ
+           : (mode == 0 && vdwk == 2)         ? CEG_WAVES_VDW_BUCK
+           : (mode == 1 && fastew)            ? CEG_WAVES_COULOMB
+                                              : CEG_WAVES;
+}
 [[maybe_unused]] constexpr double R_EXACT2 = CEG_R_EXACT2;
 static_assert(ERFCX_TAB_N == CEG_ERFCX_TAB_N, "table size mismatch");
 constexpr int META_SIMPLE = 1 << 24;      // image is the wrapped one for every point of the tile
@@ -397,7 +422,7 @@ __device__ __forceinline__ double wave_max(double x)
 //   FASTEW  alpha*cutoff <= ERFCX_XMAX: real-space Ewald term from ceg_math.h (one exp, erfcx
 //           polynomial, no division); otherwise libm-style erfc/exp
 template <int MODE, bool POINTS, int VDWK, bool FASTEW>
-__global__ __launch_bounds__(CEG_WG, CEG_WAVES) void k_culled(const PlanConst* __restrict__ pc, Output out, Points pts,
+__global__ __launch_bounds__(CEG_WG, culled_waves(MODE, VDWK, FASTEW)) void k_culled(const PlanConst* __restrict__ pc, Output out, Points pts,
                                                               int tiles_j, int tiles_k, int64_t ntiles)
 {
     // One workgroup = CEG_WG/64 waves; each wave owns one tile and its own slice of the staging
