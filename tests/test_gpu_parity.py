@@ -130,6 +130,40 @@ def test_cells_and_min_image_branches(hip_lib, oracle, name, lengths, angles):
     plan.close()
 
 
+def test_random_cells_fuzz(hip_lib, oracle):
+    """Seeded fuzz over what the named cases above fix by hand: 24 random cells (lengths 24.5-40 A, angles
+    58-122 degrees, rejected until every perpendicular width is >= 24 A), 40-200 atoms of random kinds and
+    charges, random cutoff (9-12 A), random odd grid dims; full-FP64 point sums of both kernels against the
+    oracle at 1e-9.  Covers ortho / non-ortho, safemin below and above the cutoff, partial tiles."""
+    rng = np.random.default_rng(20261004)
+    seen = {"ortho": 0, "stale": 0, "plain": 0}
+    done = 0
+    while done < 24:
+        lengths = rng.uniform(24.5, 40.0, 3)
+        angles = rng.uniform(58.0, 122.0, 3) if done % 4 else rng.uniform(88.6, 91.4, 3)
+        try:
+            mat = mat_from_parameters(tuple(lengths), tuple(angles))
+        except Exception:
+            continue
+        if not np.all(np.isfinite(mat)) or np.linalg.det(mat) <= 0 or perpendicular_lengths(mat).min() < 24.0:
+            continue
+        cutoff = float(rng.choice([9.0, 10.5, 12.0]))
+        n = int(rng.integers(40, 200))
+        pos = random_atoms(mat, n, rng, min_sep=1.2)
+        pv, pc = synthetic_probes(mat, pos, rng.integers(1, 5, n), rng.uniform(-1.5, 1.5, n), cutoff=cutoff)
+        ortho, safemin2 = pv.periodic_setup()
+        seen["ortho" if ortho else ("stale" if safemin2 < cutoff ** 2 else "plain")] += 1
+        dims = tuple(int(x) for x in 2 * rng.integers(1, 7, 3) + 1)
+        cset = W.grid_setup_with_dims(mat, dims)
+        alpha = float(rng.uniform(0.2, 0.3))
+        plan = GridPlan(cset, pv, pc, alpha)
+        assert plan.can_cull
+        _check_all(plan, pv, pc, alpha, cset, oracle, f"fuzz{done}: {np.round(lengths, 2)} {np.round(angles, 1)} cutoff {cutoff} dims {dims}")
+        plan.close()
+        done += 1
+    assert min(seen.values()) >= 2, seen
+
+
 @pytest.mark.parametrize("variant", ["generic-vdw", "wide-hard-sphere", "libm-ewald"])
 def test_kernel_variants_off_the_fast_path(hip_lib, oracle, variant):
     """Template variants the fixtures never select: generic rule runs in the hot loop (a LJ+Buckingham
