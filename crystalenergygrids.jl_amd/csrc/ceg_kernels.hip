@@ -398,6 +398,16 @@ __device__ __forceinline__ void slow_pairs(const PlanConst* __restrict__ pc, uns
     }
 }
 
+// A wave-uniform FP64 value held in an SGPR pair.  gfx950 has no scalar FP64 ALU, so the compiler keeps
+// every FP64 result in VGPRs even when all lanes hold the same number; for values that stay live across
+// the hot loop (tile box, thresholds) that costs two VGPRs each and, at 4 waves per SIMD, spills.
+__device__ __forceinline__ double uniform(double x)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double wave_min(double x)
 {
 #pragma unroll
@@ -439,7 +449,7 @@ __global__ __launch_bounds__(CEG_WG, culled_waves(MODE, VDWK, FASTEW)) void k_cu
     __shared__ __attribute__((aligned(16))) double s_erfcx[ERFCX_TAB_N * 6];
     __shared__ double s_exp2[64];
 
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double4* s_cand = s_cand_all[wave];
     double4* s_lj = s_lj_all[wave];
     int32_t* s_meta = s_meta_all[wave];
@@ -504,14 +514,14 @@ __global__ __launch_bounds__(CEG_WG, culled_waves(MODE, VDWK, FASTEW)) void k_cu
     }
 
     // ---- tile box (exact hull of the lanes' points)
-    const double blx = wave_min(px), bhx = wave_max(px);
-    const double bly = wave_min(py), bhy = wave_max(py);
-    const double blz = wave_min(pz), bhz = wave_max(pz);
-    const double cx = 0.5 * (blx + bhx), cy = 0.5 * (bly + bhy), cz = 0.5 * (blz + bhz);
-    const double hx = 0.5 * (bhx - blx), hy = 0.5 * (bhy - bly), hz = 0.5 * (bhz - blz);
+    const double blx = uniform(wave_min(px)), bhx = uniform(wave_max(px));
+    const double bly = uniform(wave_min(py)), bhy = uniform(wave_max(py));
+    const double blz = uniform(wave_min(pz)), bhz = uniform(wave_max(pz));
+    const double cx = uniform(0.5 * (blx + bhx)), cy = uniform(0.5 * (bly + bhy)), cz = uniform(0.5 * (blz + bhz));
+    const double hx = uniform(0.5 * (bhx - blx)), hy = uniform(0.5 * (bhy - bly)), hz = uniform(0.5 * (bhz - blz));
     // cutoff with a rounding margin: anything a lane can see with r2 < cutoff2 is kept
-    const double rc2 = cutoff2 * (1.0 + 1e-9) + 1e-9;
-    const double rc = sqrt(rc2);
+    const double rc2 = uniform(cutoff2 * (1.0 + 1e-9) + 1e-9);
+    const double rc = uniform(sqrt(rc2));
 
     // ---- bin rows (bx, by) intersecting the neighbourhood
     auto bin_of = [&](double x, int ax) -> int {
@@ -532,10 +542,10 @@ __global__ __launch_bounds__(CEG_WG, culled_waves(MODE, VDWK, FASTEW)) void k_cu
     const double band_cut = 1e-9 * cutoff2;
     const double alpha2 = pc->alpha2;
     const bool stale_possible = !ortho && safemin2 < cutoff2;
-    const double cut_hi = cutoff2 + band_cut;
+    const double cut_hi = uniform(cutoff2 + band_cut);
     // upper end of the regular range: below the cutoff band and, when the stale-vector branch of
     // the reference can fire (safemin2 < cutoff2, src/utils.jl:233-245), below safemin2's band too
-    const double reg_hi = stale_possible ? fmin(cutoff2 - band_cut, safemin2 * (1.0 - 1e-9)) : cutoff2 - band_cut;
+    const double reg_hi = uniform(stale_possible ? fmin(cutoff2 - band_cut, safemin2 * (1.0 - 1e-9)) : cutoff2 - band_cut);
     const double erf_inv_h = pc->erfcx_inv_h, erf_mx0 = pc->erfcx_mx0_inv_h;
 
     for (int rbase = 0; rbase < nrows; rbase += 64) {
@@ -569,7 +579,7 @@ __global__ __launch_bounds__(CEG_WG, culled_waves(MODE, VDWK, FASTEW)) void k_cu
         s_rowprefix[lane + 1] = incl;
         if (lane == 0) s_rowprefix[0] = 0;
         __builtin_amdgcn_wave_barrier();
-        const int total = s_rowprefix[64];
+        const int total = __builtin_amdgcn_readfirstlane(s_rowprefix[64]);
 
         for (int cbase = 0; cbase < total; cbase += 64) {
             // -- stage: lane loads one image of the flattened row list and tests it against the tile
