@@ -1,5 +1,4 @@
-"""Timings of the BASELINE.json configs other than the bench workload, plus the PCIe-inclusive
-one-shot rate (host buffers in, host grid out).  Prints one line per measurement."""
+"""Kernel timings of the BASELINE.json configs other than the bench workload.  Prints one line per measurement."""
 import os, sys, time
 here = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [os.path.join(here, '..', 'crystalenergygrids.jl_amd'), os.path.join(here, '..')]
@@ -37,9 +36,4 @@ for fw, atom, sp in (("CHA_1.4_3b4eeb96", "Na", 0.5), ("CHA_1.4_3b4eeb96", "Ar",
 w = W.roofline_workload("Na", 255)
 for mode in ("vdw", "fused"):
     time_plan(w, mode)
-# PCIe-inclusive one-shot (host in, host out), roofline workload, Ar VdW grid and Coulomb grid
-w = W.roofline_workload("Ar", 255)
-for name, fn in (("ceg_grid_vdw", lambda: G.build_vdw_array(w.probe_vdw, w.cset)), ("ceg_grid_coulomb", lambda: G.build_coulomb_array(w.probe_coulomb, w.alpha, w.cset))):
-    fn()
-    t = time.perf_counter(); fn(); dt = time.perf_counter() - t
-    print(f"one-shot {name}: {dt*1e3:.1f} ms wall for 16777216 points (plan build + H2D + kernel + D2H of 537 MB into pageable memory) = {16777216/dt:.3e} pts/s", flush=True)
+# (the PCIe-inclusive one-shot entry points are timed by scripts/time_oneshot.py)
