@@ -52,6 +52,8 @@ def parse_args():
     ap.add_argument("--n", type=int, default=255, help="dims per axis (odd); grid has (n+1)^3 points")
     ap.add_argument("--cpu-rows", type=int, default=-1, help="y-rows per x-plane the CPU baseline times, one plane per thread (-1 = auto ~12 s, 0 = skip)")
     ap.add_argument("--no-check", action="store_true", help="skip the built-in oracle spot check")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="N = 1 only: run the N > 1 code path (RCCL group of one rank, chunked build, collectives issued) -- a rehearsal")
     return ap.parse_args()
 
 
@@ -93,6 +95,12 @@ def cpu_baseline(w, mode: str, rows: int):
 
 def main():
     args = parse_args()
+    # stdout must carry exactly ONE JSON line: native libraries (RCCL prints a version banner when its first
+    # communicator is created) write to fd 1 behind Python's back, so fd 1 is pointed at stderr for the whole
+    # run and the result line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -103,7 +111,11 @@ def main():
         raise SystemExit("bench.py needs a HIP device (the grid build has no CPU path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_exchange          # take the sharded code path
+    if multi:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29512")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
@@ -122,7 +134,7 @@ def main():
     plane = ny * nz
     # N > 1: block-cyclic x-chunks so that each chunk is all-gathered in place (RCCL, side stream)
     # while the next one is computed; contiguous slabs + one gather at the end if nx does not divide.
-    cyc = cyclic_plan(nx, world, rank, nchunks=args.chunks) if world > 1 else None
+    cyc = cyclic_plan(nx, world, rank, nchunks=args.chunks) if multi else None
     if cyc is not None:
         n_local = cyc.n_local
     else:
@@ -131,7 +143,7 @@ def main():
     # full grids live on every rank (that is what the gather produces); rank-local buffers
     full_v = torch.empty((8, nx, ny, nz), dtype=torch.float32, device=dev) if need_v else None
     full_c = torch.empty((8, nx, ny, nz), dtype=torch.float32, device=dev) if need_c else None
-    if world == 1:
+    if not multi:
         loc_v, loc_c = full_v, full_c
     elif cyc is not None:      # one compact [8, m, ny, nz] block per chunk
         loc_v = torch.empty((cyc.nchunks, 8, cyc.m, ny, nz), dtype=torch.float32, device=dev) if need_v else None
@@ -154,7 +166,7 @@ def main():
 
     fulls = [t for t in (full_v, full_c) if t is not None]
     locs = [t for t in (loc_v, loc_c) if t is not None]
-    pipe = PipelinedGather(cyc, fulls, locs, mode=args.gather) if cyc is not None else None
+    pipe = PipelinedGather(cyc, fulls, locs, mode=args.gather, force_collectives=args.force_exchange) if cyc is not None else None
 
     def launch_chunk(j, ib, ie, blocks):
         it = iter(blocks)
@@ -168,30 +180,30 @@ def main():
         if pipe is not None:
             pipe.run(launch_chunk, on_compute_done=(lambda: ev1[k].record()) if k is not None else None)
         else:
-            launch(b, e, b if world > 1 else 0, loc_v.data_ptr() if need_v else 0, loc_c.data_ptr() if need_c else 0,
+            launch(b, e, b if multi else 0, loc_v.data_ptr() if need_v else 0, loc_c.data_ptr() if need_c else 0,
                    n_local * plane)
             if k is not None:
                 ev1[k].record()
-            if world > 1:
+            if multi:
                 for full, loc in zip(fulls, locs):
                     allgather_grid(full, loc)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(bb) for a, bb in zip(ev0, ev1)])) if args.steps else float("nan")
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kern_ms = float(t[0]), float(t[1])
@@ -256,11 +268,16 @@ def main():
                               "flops": "minimum-work count of SURVEY 8d: points x 310 neighbours x (47 + 50 LJ / + 140 Ewald)"},
             "selfcheck": check,
         }
+        if multi:
+            # gather time reported separately.  compute_ms = span of this rank's kernels
+            # (max over ranks); what is left of the step is the part of the exchange that was not hidden
+            out["exchange"] = {"compute_ms": kern_ms, "exposed_ms": max(0.0, ms - kern_ms), "mode": args.gather if cyc is not None else "slab",
+                               "bytes_gathered_per_rank": 32.0 * npts * ngrids * (world - 1) / world, "backend": "nccl (RCCL over xGMI)"}
         if world == 1 and args.cpu_rows != 0:
             out["cpu_baseline"] = cpu_baseline(w, args.mode, args.cpu_rows)
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     plan.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

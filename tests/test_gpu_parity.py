@@ -746,3 +746,30 @@ def test_consumer_edge_cases(hip_lib, oracle):
     rc = hip_lib.ceg_recip_energy(rec._h, _abi.dptr(big.reshape(-1)), _abi.dptr(np.zeros(17)), 17, 1, 0.0, 0.0, _abi.dptr(np.zeros(1)))
     assert rc == -5 and b"16" in hip_lib.ceg_last_error()
     rec.close()
+
+
+def test_bench_line_and_exchange_rehearsal(hip_lib):
+    """bench.py as the driver runs it: exactly ONE line on stdout, valid JSON with the contract's keys, the
+    roofline / cpu_baseline objects, and -- with --force-exchange -- the N > 1 code path (RCCL group, chunked
+    build, collectives on the side stream) ending in a grid that passes the oracle spot check."""
+    import json
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    for extra in ([], ["--force-exchange"]):
+        r = subprocess.run([sys.executable, str(root / "bench.py"), "--n", "63", "--steps", "2", "--warmup", "1", "--cpu-rows", "1"] + extra,
+                           capture_output=True, text=True, timeout=600, env={**os.environ, "MASTER_PORT": "29571"})
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1, r.stdout
+        d = json.loads(lines[0])
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                    "dtype", "data", "config", "roofline"):
+            assert key in d, key
+        assert d["steps"] == 2 and d["n_gpus"] == 1 and d["value"] > 0 and d["dtype"] == "f64"
+        assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+        assert d["selfcheck"]["max_rel_err"] <= 1e-6
+        if extra:
+            assert d["exchange"]["mode"] == "staged" and "block-cyclic" in d["config"]["parallelism"]
+        else:
+            assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
