@@ -773,3 +773,42 @@ def test_bench_line_and_exchange_rehearsal(hip_lib):
             assert d["exchange"]["mode"] == "staged" and "block-cyclic" in d["config"]["parallelism"]
         else:
             assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+
+
+def test_grid_beyond_32bit_indexing(hip_lib, oracle):
+    """Maximum size: a 1024^3 grid (1.07e9 points, 8.6e9 floats = 34 GB per grid, channel stride beyond 2^30
+    floats, flat offsets beyond 2^32) built into device memory through the plan API; sampled points of every
+    channel -- first and last planes, corners, random interior -- against the oracle.  Few atoms so that the
+    build itself stays around a second."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 * 2 ** 30:
+        pytest.skip("needs 34 GB of device memory")
+    mat = np.diag([60.0, 60.0, 60.0])
+    rng = np.random.default_rng(77)
+    pos = random_atoms(mat, 40, rng, min_sep=3.0)
+    pv, _ = synthetic_probes(mat, pos, rng.integers(1, 5, 40), np.zeros(40))
+    n = 1023
+    cset = W.grid_setup_with_dims(mat, (n, n, n))
+    nx = ny = nz = n + 1
+    plan = GridPlan(cset, pv, None, 0.0)
+    dev = torch.device("cuda", 0)
+    grid = torch.empty((8, nx, ny, nz), dtype=torch.float32, device=dev)
+    grid.fill_(float("nan"))
+    s = torch.cuda.current_stream().cuda_stream
+    plan.build_vdw(grid.data_ptr(), nx * ny * nz, 0, nx, 0, AUTO, s)
+    torch.cuda.synchronize()
+    idx = np.concatenate([rng.integers(0, nx, (3000, 3)),
+                          np.array([[0, 0, 0], [n, n, n], [n, 0, n], [0, n, 0], [n, n, 0], [1023, 1023, 1022], [512, 1023, 1023]]),
+                          np.stack([np.full(500, n), rng.integers(0, ny, 500), rng.integers(0, nz, 500)], axis=1)])
+    pts = np.stack([idx[:, a] * cset.size[a] / cset.dims[a] + cset.shift[a] for a in range(3)], axis=1)
+    lam, thr = G.vdw_scaling()
+    ref = oracle.set_gridpoints(oracle.points_vdw(pv, pts), cset.delta, lam, thr)            # float32[n, 8]
+    ti = torch.from_numpy(idx).to(dev)
+    got = grid[:, ti[:, 0], ti[:, 1], ti[:, 2]].T.cpu().numpy()
+    assert not np.isnan(got).any()
+    compare_grids(got.T[:, :, None, None], ref.T[:, :, None, None], "1024^3 samples")
+    assert not torch.isnan(grid[7, -1, -1, -8:]).any() and not torch.isnan(grid[0, 0, 0, :8]).any()
+    del grid
+    plan.close()
+    torch.cuda.empty_cache()
