@@ -137,7 +137,7 @@ def write_grid_file(file, cset: GridCoordinatesSetup, num_unitcell, grid: np.nda
         _create_grid_common(f, cset, num_unitcell)
         if ewald_precision is not None:
             f.write(struct.pack("<d", float(ewald_precision)))
-        f.write(np.ascontiguousarray(grid, dtype="<f4").tobytes())
+        f.write(memoryview(np.ascontiguousarray(grid, dtype="<f4")).cast("B"))       # no intermediate copy of the payload
         f.write(np.asarray(cset.cell.mat, dtype="<f8").T.tobytes())   # column-major 3x3, not part of RASPA grids
 
 
@@ -174,8 +174,13 @@ def parse_grid(file, iscoulomb: bool, mat=None) -> EnergyGrid:
         ewald_precision = struct.unpack("<d", io.read(8))[0] if iscoulomb else math.inf
         nx, ny, nz = (int(d) + 1 for d in dims)
         n = 8 * nx * ny * nz
-        grid = np.frombuffer(io.read(4 * n), dtype="<f4").reshape(8, nx, ny, nz)
-        grid = (grid.astype(np.float64) * GRID_TO_KELVIN).astype(np.float32)
+        grid = np.fromfile(io, dtype="<f4", count=n)
+        if len(grid) != n:
+            raise ValueError("truncated grid file")
+        grid = grid.reshape(8, nx, ny, nz)
+        # grid .*= GRID_TO_KELVIN (grids.jl:78): Float32 array times Float64 scalar, each product formed in
+        # Float64 and rounded to Float32 on store -- one buffered pass, no Float64 copy of the array
+        np.multiply(grid, GRID_TO_KELVIN, out=grid, dtype=np.float64, casting="same_kind")
         if mat is not None:
             newmat = mat if isinstance(mat, CellMatrix) else CellMatrix.from_mat(mat)
         else:
