@@ -237,4 +237,33 @@ function pairs_energy(h::Ptr{Cvoid}, placements, idx2::Vector{Int}, exclude_mole
     out
 end
 
+# ------------------------------------------------------------------ blocking masks (SURVEY 8f row f4)
+_to_bitarray(mask::Vector{UInt8}, a, b, c) = BitArray(permutedims(reshape(mask, c, b, a), (3, 2, 1)) .!= 0)
+
+"BlockFile(g::EnergyGrid) (src/grids.jl:188-204) with the cell scan on the GPU"
+function blockfile(g::CEG.EnergyGrid; device=0)
+    a, b, c = g.csetup.dims .+ 1
+    value = Array{Cfloat}(@view g.grid[:, :, :, 1])                 # [z, y, x] column-major = C order [x][y][z]
+    mask = Vector{UInt8}(undef, a*b*c)
+    dims = Int32[g.csetup.dims...]
+    GC.@preserve value mask dims _check(ccall((:ceg_block_from_grid, LIB[]), Cint,
+        (Int32, Ptr{Cfloat}, Int32, Ptr{Int32}, Float64, Ptr{UInt8}), device, value, 0, dims, 5e6, mask))
+    CEG.BlockFile(g.csetup, _to_bitarray(mask, a, b, c))
+end
+
+"The scan of parse_blockfile (src/coordinates.jl:139-152): `protoblocks` as built at :123-133"
+function block_spheres(csetup::GridCoordinatesSetup, centers::Vector{SVector{3,Float64}}, radius2::Vector{Float64}; device=0)
+    a, b, c = csetup.dims .+ 1
+    mat = NoUnits.(csetup.cell.mat ./ u"Å"); invmat = NoUnits.(csetup.cell.invmat .* u"Å")
+    _, ortho, safemin = CEG.prepare_periodic_distance_computations(mat)
+    dims, _, shift, Δ = _geometry(csetup)
+    cs = Float64[x for p in centers for x in p]
+    m = Vector{Float64}(vec(mat)); im = Vector{Float64}(vec(invmat))
+    mask = Vector{UInt8}(undef, a*b*c)
+    GC.@preserve dims Δ shift m im cs radius2 mask _check(ccall((:ceg_block_spheres, LIB[]), Cint,
+        (Int32, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32, Float64, Ptr{Float64}, Ptr{Float64}, Int32, Ptr{UInt8}),
+        device, dims, Δ, shift, m, im, ortho, safemin^2, cs, radius2, length(radius2), mask))
+    CEG.BlockFile(csetup, _to_bitarray(mask, a, b, c))
+end
+
 end # module
