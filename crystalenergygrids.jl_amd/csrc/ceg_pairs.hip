@@ -9,11 +9,13 @@
 // exp/erfc (ocml): this is a consumer kernel of a few thousand atoms, not the grid build.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstring>
 #include <vector>
 
 #include "../../include/ceg_hip.h"
 #include "ceg_internal.h"
+#include "ceg_math.h"
 
 using ceg::DevRule;
 
@@ -69,12 +71,64 @@ __device__ __forceinline__ double rule_energy(const DevRule& R, double r2, doubl
     return v - R.shift;
 }
 
-__global__ __launch_bounds__(64 * PAIRS_WAVES) void k_pairs(PairsGeom g, const DevRule* __restrict__ rules,
-                                                             const int32_t* __restrict__ offset,
+// Same energies with the shared sqrt / 1/r of the pair and the ceg_math.h functions (each <= 1.3e-13 relative):
+// valid for 0.25 A^2 <= r2 and alpha*r <= ERFCX_XMAX for every CoulombEwaldDirect rule (checked by the host);
+// closer pairs take rule_energy so that r -> 0 gives the reference's Inf / NaN.
+__device__ __forceinline__ double rule_energy_fast(const DevRule& R, double r2, double r, double rinv, double coulombic)
+{
+    double v;
+    switch (R.kind) {
+    case CEG_LENNARDJONES: {
+        const double q = (R.p1 * R.p1) * (rinv * rinv);
+        const double x6 = q * q * q;
+        v = 4.0 * R.p0 * x6 * (x6 - 1.0);
+        break;
+    }
+    case CEG_HARDSPHERE: {
+        const double s = R.p0 + R.p1;
+        v = (r2 < s * s) ? __builtin_huge_val() : 0.0;
+        break;
+    }
+    case CEG_NOINTERACTION: v = 0.0; break;
+    case CEG_COULOMB_EWALD_DIRECT: {
+        const double x = R.p0 * r;
+        v = (coulombic * R.p1 * R.p2) * (ceg::fast_exp_neg(-(x * x)) * ceg::erfcx_poly(x)) * rinv;
+        break;
+    }
+    case CEG_COULOMB: v = coulombic * R.p0 * R.p1 * rinv; break;
+    case CEG_BUCKINGHAM: {
+        const double i2 = rinv * rinv;
+        v = R.p0 * ceg::fast_exp_neg(-(R.p1 * r)) - R.p2 * (i2 * i2 * i2);
+        break;
+    }
+    case CEG_EXPONENTIAL: v = R.p0 * ceg::fast_exp_neg(-(R.p1 * r)); break;
+    default: return rule_energy(R, r2, coulombic);      // Monomial (pow) and anything else
+    }
+    return v - R.shift;
+}
+
+template <bool FAST, bool TABLE_IN_LDS>
+__global__ __launch_bounds__(64 * PAIRS_WAVES) void k_pairs(PairsGeom g, const DevRule* __restrict__ g_rules,
+                                                             const int32_t* __restrict__ g_offset, int32_t nrules,
                                                              const double4* __restrict__ atoms,      // x, y, z, (kind | molecule) bits
                                                              int64_t natoms, const double* __restrict__ trial, int64_t n,
                                                              double* __restrict__ out)
 {
+    // the pair table is read once per in-cutoff pair with lane-dependent indices: from global memory that
+    // is a dependent chain of vector loads inside a divergent branch, so it is staged in LDS when it fits
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_table[];
+    const DevRule* rules = g_rules;
+    const int32_t* offset = g_offset;
+    if (TABLE_IN_LDS) {
+        DevRule* lr = reinterpret_cast<DevRule*>(s_table);
+        int32_t* lo = reinterpret_cast<int32_t*>(s_table + sizeof(DevRule) * (size_t)(nrules > 0 ? nrules : 1));
+        const int nt = g.nkinds * g.nkinds + 1;
+        for (int t = threadIdx.x; t < nrules; t += 64 * PAIRS_WAVES) lr[t] = g_rules[t];
+        for (int t = threadIdx.x; t < nt; t += 64 * PAIRS_WAVES) lo[t] = g_offset[t];
+        __syncthreads();
+        rules = lr;
+        offset = lo;
+    }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t p = (int64_t)blockIdx.x * PAIRS_WAVES + wave;
     if (p >= n) return;
@@ -84,12 +138,40 @@ __global__ __launch_bounds__(64 * PAIRS_WAVES) void k_pairs(PairsGeom g, const D
     __builtin_amdgcn_wave_barrier();
     const double* M = g.mat;
     const double* I = g.invmat;
+    // Only ~10 % of the tested pairs are inside the cutoff (MC cells are 2-4 cutoffs wide), but a wave almost
+    // always contains one: evaluating the rules under the lane mask would cost every lane the full exp / erfc
+    // price per test.  Hits are therefore compacted into a per-wave LDS queue (r2, pair-table index) and the
+    // rules are evaluated on dense batches.
+    constexpr int QCAP = 128;
+    __shared__ double s_qr2[PAIRS_WAVES][QCAP];
+    __shared__ int32_t s_qt[PAIRS_WAVES][QCAP];
+    double* qr2 = s_qr2[wave];
+    int32_t* qt = s_qt[wave];
+    int qn = 0;                                   // wave-uniform
     double e = 0.0;
-    for (int64_t l = lane; l < natoms; l += 64) {
-        const double4 A = atoms[l];
+    auto flush = [&]() {
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < qn; i += 64) {
+            const double r2 = qr2[i];
+            const int t = qt[i];
+            if (FAST && r2 >= 0.25) {
+                double r, rinv;
+                ceg::fast_sqrt_rsqrt(r2, r, rinv);
+                for (int q = offset[t]; q < offset[t + 1]; ++q) e += rule_energy_fast(rules[q], r2, r, rinv, g.coulombic);
+            } else {
+                for (int q = offset[t]; q < offset[t + 1]; ++q) e += rule_energy(rules[q], r2, g.coulombic);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        qn = 0;
+    };
+    for (int64_t l0 = 0; l0 < natoms; l0 += 64) {
+        const int64_t l = l0 + lane;
+        const bool have = l < natoms;
+        const double4 A = atoms[have ? l : 0];
         const long long bits = __double_as_longlong(A.w);
         const int kind1 = (int)(bits & 0xffffffffll), mol = (int)(bits >> 32);
-        if (mol == g.exclude) continue;
+        const bool live = have && mol != g.exclude;
         for (int a = 0; a < g.m; ++a) {
             double r2;
             {
@@ -107,12 +189,20 @@ __global__ __launch_bounds__(64 * PAIRS_WAVES) void k_pairs(PairsGeom g, const D
                 const double vz = M[2] * f0 + M[5] * f1 + M[8] * f2;
                 r2 = vx * vx + vy * vy + vz * vz;
             }
-            if (r2 < g.cutoff2) {
-                const int t = kind1 * g.nkinds + g.kinds[a];
-                for (int q = offset[t]; q < offset[t + 1]; ++q) e += rule_energy(rules[q], r2, g.coulombic);
+            const bool hit = live && (r2 < g.cutoff2);             // energy.jl:422 (a NaN distance is no hit there either)
+            const unsigned long long mask = __ballot(hit);
+            const int cnt = __popcll(mask);
+            if (cnt == 0) continue;
+            if (qn + cnt > QCAP) flush();
+            if (hit) {
+                const int slot = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                qr2[slot] = r2;
+                qt[slot] = kind1 * g.nkinds + g.kinds[a];
             }
+            qn += cnt;
         }
     }
+    flush();
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
     if (lane == 0) out[p] = e;
@@ -131,6 +221,8 @@ struct ceg_pairs {
     double mat[9], invmat[9];
     double cutoff2 = 0.0, coulombic = 0.0;
     int32_t nkinds = 0;
+    bool fast = false;          // every exp / erfc argument inside the domain of the ceg_math.h functions
+    int32_t nrules = 0;
     DevRule* d_rules = nullptr;
     int32_t* d_offset = nullptr;
     double4* d_atoms = nullptr;
@@ -150,12 +242,16 @@ extern "C" int ceg_pairs_create(ceg_pairs_t** handle, int32_t device, const doub
     const int32_t nr = rule_offset[nt];
     if (nr > 0 && !rules) return perr(CEG_ERR_INVALID, "rules missing");
     std::vector<DevRule> dr((size_t)(nr > 0 ? nr : 1));
+    bool fast = true;
+    const double cutoff = std::sqrt(cutoff2);
     for (int32_t q = 0; q < nr; ++q) {
         const ceg_rule_t& r = rules[q];
         if (r.kind < CEG_HARDSPHERE || r.kind > CEG_NOINTERACTION) return perr(CEG_ERR_INVALID, "unknown rule kind");
         if (r.kind == CEG_UNDEFINED_INTERACTION) return perr(CEG_ERR_RULE, "Undefined interaction");     // interactions.jl:386-387
         dr[q].kind = r.kind; dr[q]._pad = 0;
         dr[q].p0 = r.p[0]; dr[q].p1 = r.p[1]; dr[q].p2 = r.p[2]; dr[q].shift = r.shift;
+        if (r.kind == CEG_COULOMB_EWALD_DIRECT && !(r.p[0] >= 0.0 && r.p[0] * cutoff <= 5.0 * (1.0 - 1e-9))) fast = false;
+        if ((r.kind == CEG_BUCKINGHAM || r.kind == CEG_EXPONENTIAL) && !(r.p[1] >= 0.0 && r.p[1] * cutoff <= 700.0)) fast = false;
     }
     if (ceg_device_count() <= 0) return perr(CEG_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
     if (device < 0 || device >= ceg_device_count()) return perr(CEG_ERR_NO_DEVICE, "device not present");
@@ -165,7 +261,7 @@ extern "C" int ceg_pairs_create(ceg_pairs_t** handle, int32_t device, const doub
     ceg_pairs* h = new ceg_pairs();
     h->device = device;
     for (int a = 0; a < 9; ++a) { h->mat[a] = mat[a]; h->invmat[a] = invmat[a]; }
-    h->cutoff2 = cutoff2; h->coulombic = coulombic; h->nkinds = nkinds;
+    h->cutoff2 = cutoff2; h->coulombic = coulombic; h->nkinds = nkinds; h->fast = fast; h->nrules = nr;
     bool ok = hipMalloc((void**)&h->d_rules, dr.size() * sizeof(DevRule)) == hipSuccess &&
               hipMalloc((void**)&h->d_offset, (size_t)(nt + 1) * sizeof(int32_t)) == hipSuccess;
     ok = ok && hipMemcpy(h->d_rules, dr.data(), dr.size() * sizeof(DevRule), hipMemcpyHostToDevice) == hipSuccess &&
@@ -243,8 +339,17 @@ extern "C" int ceg_pairs_energy_device(ceg_pairs_t* h, const double* d_trial, co
     int prev = -1;
     (void)hipGetDevice(&prev);
     if (hipSetDevice(h->device) != hipSuccess) return perr(CEG_ERR_HIP, "hipSetDevice failed");
-    hipLaunchKernelGGL(k_pairs, dim3((unsigned)nblocks), dim3(64 * PAIRS_WAVES), 0, (hipStream_t)stream, g, h->d_rules, h->d_offset,
-                       h->d_atoms, h->natoms, d_trial, n, d_out);
+    const size_t table_bytes = sizeof(DevRule) * (size_t)(h->nrules > 0 ? h->nrules : 1) + sizeof(int32_t) * ((size_t)h->nkinds * h->nkinds + 1);
+    const bool in_lds = table_bytes <= 48 * 1024;
+    const size_t lds = in_lds ? table_bytes : 0;
+    const dim3 grid((unsigned)nblocks), block(64 * PAIRS_WAVES);
+    hipStream_t st = (hipStream_t)stream;
+#define CEG_PAIRS_LAUNCH(F, L) hipLaunchKernelGGL((k_pairs<F, L>), grid, block, lds, st, g, h->d_rules, h->d_offset, h->nrules, h->d_atoms, h->natoms, d_trial, n, d_out)
+    if (h->fast && in_lds) CEG_PAIRS_LAUNCH(true, true);
+    else if (h->fast) CEG_PAIRS_LAUNCH(true, false);
+    else if (in_lds) CEG_PAIRS_LAUNCH(false, true);
+    else CEG_PAIRS_LAUNCH(false, false);
+#undef CEG_PAIRS_LAUNCH
     const hipError_t e = hipGetLastError();
     if (prev >= 0) (void)hipSetDevice(prev);
     if (e != hipSuccess) return perr(CEG_ERR_HIP, hipGetErrorString(e));
