@@ -22,15 +22,17 @@ class OracleGrid(G.EnergyGrid):
 
 @pytest.fixture()
 def oracle_grids(oracle, forcefield, monkeypatch):
-    fw = ceg.load_framework_RASPA("CIT-7", FFNAME)
-    cset = ceg.GridCoordinatesSetup.from_cell(fw.mat, 0.15)
+    """setup_montecarlo with grids that are never built: each interpolation asks the oracle for its 8 corners."""
+    from ceg_hip.utils import find_supercell
     probes = {}
 
     def fake_retrieve(grid_path, syst_framework, ff, gridstep, atom_or_ef, mat, new, cutoff, ngpus=1):
         iscoulomb = isinstance(atom_or_ef, ceg.EwaldFramework)
         if not iscoulomb and not ff.needsvdwgrid(atom_or_ef):
             return G.EnergyGrid.trivial(True)
-        g = OracleGrid(cset, (2, 3, 3), 1e-6 if iscoulomb else math.inf, True, None)
+        cset = ceg.GridCoordinatesSetup.from_cell(syst_framework.mat, gridstep)
+        g = OracleGrid(cset, tuple(find_supercell(syst_framework.mat, 12.0)), 1e-6 if iscoulomb else math.inf, True, None)
+        g.fw = syst_framework
         g.key = ("coulomb", atom_or_ef.alpha) if iscoulomb else ("vdw", atom_or_ef)
         return g
 
@@ -38,17 +40,16 @@ def oracle_grids(oracle, forcefield, monkeypatch):
         if g.ewald_precision == -math.inf:
             return 0.0
         kind, what = g.key
+        pk = (id(g.fw), kind if kind == "coulomb" else what)
+        if pk not in probes:
+            probes[pk] = ProbeSystem.build(g.fw, forcefield) if kind == "coulomb" else ProbeSystem.build(g.fw, forcefield, what)
         if kind == "vdw":
-            if what not in probes:
-                probes[what] = ProbeSystem.build(fw, forcefield, what)
-            return interpolate_with_oracle(oracle, cset, probes[what], point)
-        if "coulomb" not in probes:
-            probes["coulomb"] = ProbeSystem.build(fw, forcefield)
-        return interpolate_with_oracle(oracle, cset, probes["coulomb"], point, what)
+            return interpolate_with_oracle(oracle, g.csetup, probes[pk], point)
+        return interpolate_with_oracle(oracle, g.csetup, probes[pk], point, what)
 
     monkeypatch.setattr(M, "retrieve_or_create_grid", fake_retrieve)
     monkeypatch.setattr(M, "interpolate_grid", fake_interpolate)
-    return fw
+    return None
 
 
 def _mol(name, positions):
@@ -122,6 +123,26 @@ def test_sodium_and_two_co2_in_cit7(oracle_grids):
     assert diff_na == pytest.approx(5440.529635958557, rel=2e-5)           # observed 8.8e-6
     assert base == pytest.approx(-28322.179659, rel=1e-9)
     assert diff_na == pytest.approx(5440.481803253, rel=1e-9)
+
+
+def test_one_atom_frameworks_in_supercells(oracle_grids):
+    """runtests.jl:203-221 -- frameworks of one / a few atoms in the CIT-7 cell ("Mini", "Petit": the grids live
+    on the unit cell, the ProbeSystem and the Ewald sums on its 2x3x3 supercell, the framework carries a net
+    charge) against the same atoms written out as an explicit 1x1x1 supercell ("MiniRef", "PetitRef")."""
+    na_mini = [[-1.401612509676063, 14.86235802394228, 15.37932058231622]]
+    mini = float(M.baseline_energy(M.setup_montecarlo("Mini", FFNAME, [_mol("Na", na_mini)])))
+    miniref = float(M.baseline_energy(M.setup_montecarlo("MiniRef", FFNAME, [_mol("Na", na_mini)])))
+    assert mini == pytest.approx(miniref, rel=1e-3)                         # runtests.jl:209
+    assert mini == pytest.approx(-248304.58180794, rel=1e-3)                # :210
+    na_petit = [[18.77838182689036, 14.73031622108175, 3.669308624409278]]
+    petit = float(M.baseline_energy(M.setup_montecarlo("Petit", FFNAME, [_mol("Na", na_petit)])))
+    petitref = float(M.baseline_energy(M.setup_montecarlo("PetitRef", FFNAME, [_mol("Na", na_petit)])))
+    assert petit == pytest.approx(petitref, rel=1e-4)                       # :217
+    assert petit == pytest.approx(262204.85720076, rel=1e-3)                # :218
+    # observed: 6.2e-6 / 6.7e-6 from the literals, 1.8e-8 / 5.0e-7 between the two descriptions of the same crystal
+    assert mini == pytest.approx(-248304.58180794, rel=2e-5) and petit == pytest.approx(262204.85720076, rel=2e-5)
+    assert mini == pytest.approx(miniref, rel=1e-7) and petit == pytest.approx(petitref, rel=2e-6)
+    assert mini == pytest.approx(-248306.13377495, rel=1e-9) and petit == pytest.approx(262203.11093656, rel=1e-9)
 
 
 def _trio(M_):
@@ -202,5 +223,16 @@ def test_gpu_montecarlo_energies(hip_lib, oracle, tmp_path):
         b2 = float(gm2.baseline_energy())
         assert b2 == pytest.approx(-1789.77383582, rel=1e-7)
         gm2.close()
+        # one-atom framework on its 2x3x3 supercell vs the explicit supercell (runtests.jl:203-211)
+        na_mini = [[-1.401612509676063, 14.86235802394228, 15.37932058231622]]
+        vals = []
+        for fwname in ("Mini", "MiniRef"):
+            mc3 = M.setup_montecarlo(fwname, FFNAME, [_mol("Na", na_mini)])
+            gm3 = GpuMonteCarloEnergy(mc3)
+            M.baseline_energy(mc3)
+            vals.append(float(gm3.baseline_energy()))
+            gm3.close()
+        assert vals[0] == pytest.approx(-248304.58180794, rel=1e-3) and vals[0] == pytest.approx(vals[1], rel=1e-3)
+        assert vals[0] == pytest.approx(-248306.13377495, rel=1e-7) and vals[1] == pytest.approx(-248306.13817777, rel=1e-7)
     finally:
         ceg.setdir_RASPA(golden)
