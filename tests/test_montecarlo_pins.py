@@ -145,6 +145,16 @@ def test_one_atom_frameworks_in_supercells(oracle_grids):
     assert mini == pytest.approx(-248306.13377495, rel=1e-9) and petit == pytest.approx(262203.11093656, rel=1e-9)
 
 
+def test_sodium_in_supercit7_minus_one(oracle_grids):
+    """runtests.jl:200-202 -- the CIT-7 2x3x3 supercell written out as one P1 cell with one atom removed
+    (1079 atoms, charged framework)."""
+    mc = M.setup_montecarlo("SuperCIT7m1", FFNAME, [_mol("Na", [[4.935357501688667, 23.53557287745349, 25.71480449842175]])])
+    base = float(M.baseline_energy(mc))
+    assert base == pytest.approx(-8996.975999017683, rel=1e-3)
+    assert base == pytest.approx(-8996.975999017683, rel=1e-4)             # observed 3.8e-5
+    assert base == pytest.approx(-8997.318017862597, rel=1e-9)
+
+
 def _trio(M_):
     na = [[3.019388765467742, 0.8997706038543032, 26.11901621898599]]
     co2_1 = [[11.93940309885289, 8.48657378465003, 2.135736631609201], [11.10485516124311, 7.710040763525694, 1.991767166323031],
