@@ -67,6 +67,18 @@ def tail_correction(ff: ForceField, ffidx: List[List[int]], framework_atoms: Seq
     return value, framework, cross
 
 
+def modify_species_dryrun(framework: Sequence[float], cross: np.ndarray, numspecies: Sequence[int], i: int, num: int) -> float:
+    """tailcorrection.jl:89-99: change of the tail correction when ``num`` molecules of kind ``i`` (0-based)
+    are added (negative: removed) to a system holding ``numspecies``."""
+    diff = framework[i]
+    for j, other in enumerate(numspecies):
+        if j == i:
+            diff += (num + 2 * other) * cross[i, i]
+        else:
+            diff += 2 * other * cross[j, i]
+    return diff * num
+
+
 @dataclass
 class BaselineEnergyReport:
     """montecarlo.jl:447-456"""

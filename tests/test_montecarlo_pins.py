@@ -155,6 +155,44 @@ def test_sodium_in_supercit7_minus_one(oracle_grids):
     assert base == pytest.approx(-8997.318017862597, rel=1e-9)
 
 
+def test_tail_correction_species_counts(forcefield):
+    """runtests.jl:283-300 -- TailCorrection for 2 Na + 3 CO2 in CIT-7 (2x3x3), built directly and incrementally."""
+    fw = ceg.load_framework_RASPA("CIT-7", FFNAME)
+    cell = fw.mat * np.array([2.0, 3.0, 3.0])[None, :]
+    lam = 2 * math.pi / float(np.linalg.det(cell))
+    ffidx = [[forcefield.sdict["Na"]], [forcefield.sdict[a] for a in ("O_co2", "C_co2", "O_co2")]]
+    framework_atoms = [0, 720, 0, 0, 360] + [0] * 15                     # runtests.jl:283
+    assert len(framework_atoms) == len(forcefield.sdict)
+    v0, fwk, cross = M.tail_correction(forcefield, ffidx, framework_atoms, lam, [0, 0])
+    assert v0 == 0.0                                                     # :287
+    counts = [0, 0]
+    val = v0
+    for i, num in ((0, 2), (1, 3)):                                      # :288-289
+        val += M.modify_species_dryrun(fwk, cross, counts, i, num)
+        counts[i] += num
+    assert val == pytest.approx(-322.46442841047406, rel=1e-8)           # :290
+    v1, _, _ = M.tail_correction(forcefield, ffidx, framework_atoms, lam, [2, 3])
+    assert v1 == pytest.approx(val, rel=1e-12)                           # :293
+    v2, fwk2, cross2 = M.tail_correction(forcefield, ffidx, framework_atoms, lam, [1, 5])
+    counts = [1, 5]
+    for i, num in ((1, -1), (0, 1), (1, -1)):                            # :296-298
+        v2 += M.modify_species_dryrun(fwk2, cross2, counts, i, num)
+        counts[i] += num
+    assert v2 == pytest.approx(val, rel=1e-10)                           # :299
+
+
+def test_restart_co2_in_cha_na(oracle_grids):
+    """runtests.jl:452-455 -- one CO2 at the positions of the reference's restart fixture
+    (test/CHA_1.4_3b4eeb96_Na_11812.restart, lines 48-50) in the Na-exchanged CHA framework."""
+    pos = [[14.901841423007, 23.433903291107, 4.454129422603], [14.148462432033, 23.671252375058, 3.619691582913],
+           [13.395083441058, 23.908601459010, 2.785253743223]]
+    mc = M.setup_montecarlo("CHA_1.4_3b4eeb96_Na_11812", FFNAME, [_mol("CO2", pos)])
+    base = float(M.baseline_energy(mc))
+    assert base == pytest.approx(-14128.888030042883, rel=1e-3)
+    assert base == pytest.approx(-14128.888030042883, rel=1e-6)            # observed 2.7e-7
+    assert base == pytest.approx(-14128.88426348615, rel=1e-9)
+
+
 def _trio(M_):
     na = [[3.019388765467742, 0.8997706038543032, 26.11901621898599]]
     co2_1 = [[11.93940309885289, 8.48657378465003, 2.135736631609201], [11.10485516124311, 7.710040763525694, 1.991767166323031],
