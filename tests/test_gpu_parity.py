@@ -768,6 +768,7 @@ def test_bench_line_and_exchange_rehearsal(hip_lib):
             assert key in d, key
         assert d["steps"] == 2 and d["n_gpus"] == 1 and d["value"] > 0 and d["dtype"] == "f64"
         assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+        assert d["roofline"]["bound"] == "valu_fp64" and d["roofline_hbm"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
         assert d["selfcheck"]["max_rel_err"] <= 1e-6
         if extra:
             assert d["exchange"]["mode"] == "staged" and "block-cyclic" in d["config"]["parallelism"]
