@@ -164,6 +164,24 @@ def test_random_cells_fuzz(hip_lib, oracle):
     assert min(seen.values()) >= 2, seen
 
 
+@pytest.mark.parametrize("cutoff,edge", [(30.0, 64.0), (21.0, 47.0)])
+def test_large_cutoff_many_bin_rows(hip_lib, oracle, cutoff, edge):
+    """Cutoffs far beyond the reference's 12 A: the neighbourhood of a tile spans more than 64 bin rows, so the
+    row enumeration of the culled kernel takes several passes and a tile sees thousands of candidates."""
+    mat = mat_from_parameters((edge, edge + 3.0, edge + 5.0), (93.0, 97.0, 86.0))
+    assert perpendicular_lengths(mat).min() >= 2 * cutoff
+    rng = np.random.default_rng(int(cutoff))
+    n = 900
+    pos = random_atoms(mat, n, rng, min_sep=2.0)
+    pv, pc = synthetic_probes(mat, pos, rng.integers(1, 5, n), rng.uniform(-1.0, 1.0, n), cutoff=cutoff)
+    cset = W.grid_setup_with_dims(mat, (7, 9, 5))
+    alpha = 4.5 / cutoff
+    plan = GridPlan(cset, pv, pc, alpha)
+    assert plan.can_cull and plan.num_images > 3 * n
+    _check_all(plan, pv, pc, alpha, cset, oracle, f"cutoff {cutoff}")
+    plan.close()
+
+
 @pytest.mark.parametrize("variant", ["generic-vdw", "wide-hard-sphere", "libm-ewald"])
 def test_kernel_variants_off_the_fast_path(hip_lib, oracle, variant):
     """Template variants the fixtures never select: generic rule runs in the hot loop (a LJ+Buckingham
