@@ -137,7 +137,9 @@ def write_grid_file(file, cset: GridCoordinatesSetup, num_unitcell, grid: np.nda
         _create_grid_common(f, cset, num_unitcell)
         if ewald_precision is not None:
             f.write(struct.pack("<d", float(ewald_precision)))
-        f.write(memoryview(np.ascontiguousarray(grid, dtype="<f4")).cast("B"))       # no intermediate copy of the payload
+        payload = np.ascontiguousarray(grid, dtype="<f4")
+        if payload.size:
+            f.write(memoryview(payload.reshape(-1)).cast("B"))                       # no intermediate copy of the payload
         f.write(np.asarray(cset.cell.mat, dtype="<f8").T.tobytes())   # column-major 3x3, not part of RASPA grids
 
 

@@ -65,5 +65,28 @@ def main():
         print(f"{path.name}: {len(out['idx'])} points, dims {tuple(out['dims'])}, {nspecial} clamped Na points")
 
 
+def headers():
+    """grid_headers.json: the bytes create_grid_vdw / create_grid_coulomb put around the payload
+    (grids.jl:108-116 header, :154/:182 trailer, :180 Ewald precision) for the fixtures' default grids."""
+    import io
+    import json
+    from ceg_hip.utils import find_supercell
+    out = {}
+    for fwname, spacing in (("CHA_1.4_3b4eeb96", 0.15), ("CHA_1.4_3b4eeb96", 0.5), ("CIT-7", 0.15)):
+        w = W.fixture_workload(fwname, "Ar", spacing, coulomb=False)
+        nuc = tuple(int(x) for x in find_supercell(w.framework.mat, 12.0))
+        empty = np.empty((8, 0), dtype=np.float32)
+        for kind, prec in (("vdw", None), ("coulomb", 1e-6)):
+            buf = io.BytesIO()
+            G._create_grid_common(buf, w.cset, nuc)
+            head = buf.getvalue() + (np.float64(prec).tobytes() if prec is not None else b"")
+            tail = np.asarray(w.cset.cell.mat, dtype="<f8").T.tobytes()
+            out[f"{fwname}/{spacing}/{kind}"] = {"header_hex": head.hex(), "trailer_hex": tail.hex(), "dims": [int(d) for d in w.cset.dims],
+                                                 "num_unitcell": list(nuc), "payload_bytes": int(32 * np.prod(np.asarray(w.cset.dims) + 1))}
+    (Path(__file__).parent / "grid_headers.json").write_text(json.dumps(out, indent=1) + "\n")
+    print("grid_headers.json:", ", ".join(out))
+
+
 if __name__ == "__main__":
     main()
+    headers()

@@ -292,3 +292,25 @@ def test_roofline_workload_shape():
     assert w.probe_vdw.num_supercell == (1, 1, 1)
     np.testing.assert_array_equal(w.probe_vdw.positions, w.probe_coulomb.positions)
     assert abs(w.probe_coulomb.charges.sum() - 12 * (-122.769)) < 1e-6
+
+
+def test_grid_file_headers_match_committed_fixture(tmp_path):
+    """tests/golden/grid_headers.json ("headers of the corresponding .grid files"): the bytes around
+    the payload for the fixtures' grids -- spacing, dims (217,203,189 for CHA at 0.15 A),
+    size, shift, delta, unit-cell lengths, num_unitcell, Ewald precision, cell-matrix trailer."""
+    import json
+    fx = json.loads((ROOT / "tests" / "golden" / "grid_headers.json").read_text())
+    assert fx["CHA_1.4_3b4eeb96/0.15/vdw"]["dims"] == [217, 203, 189]
+    assert fx["CIT-7/0.15/vdw"]["num_unitcell"] == [2, 3, 3]
+    for key, rec in fx.items():
+        fwname, spacing, kind = key.split("/")
+        fw = ceg.load_framework_RASPA(fwname, FFNAME)
+        cset = ceg.GridCoordinatesSetup.from_cell(fw.mat, float(spacing))
+        grid = np.zeros((8, 0), dtype=np.float32)                 # header + trailer only: empty payload
+        f = tmp_path / "h.grid"
+        G.write_grid_file(f, cset, tuple(rec["num_unitcell"]), grid, 1e-6 if kind == "coulomb" else None)
+        raw = f.read_bytes()
+        nh = 136 if kind == "coulomb" else 128
+        assert len(raw) == nh + 72
+        assert raw[:nh].hex() == rec["header_hex"] and raw[nh:].hex() == rec["trailer_hex"], key
+        assert rec["payload_bytes"] == 32 * int(np.prod(np.asarray(cset.dims) + 1))
