@@ -32,63 +32,96 @@ struct RecipGeom {
     double energy_net_charges, static_contribution;
 };
 
+// k-space constants of one k-vector as the kernel reads them from LDS: packed (i, j, k) and the three
+// products the energy needs -- E = 2 sum(A sr + B si) + sum(kf (sr^2 + si^2)), A = kf Re S_f, B = kf Im S_f
+struct KPack {
+    double A, B, kf;
+    int32_t ijk;          // i | (j + 128) << 8 | (k + 128) << 16
+    int32_t _pad;
+};
+
 __global__ __launch_bounds__(64 * WAVES) void k_recip(RecipGeom g, const int32_t* __restrict__ ijk,
                                                        const double* __restrict__ kf, const double* __restrict__ sfre,
                                                        const double* __restrict__ sfim, int64_t nk,
                                                        const double* __restrict__ pos, int64_t n, double* __restrict__ out,
-                                                       int tab_stride)
+                                                       int tab_stride, int per_wave, int k_in_lds)
 {
-    extern __shared__ double2 s_tab[];                       // [WAVES][natoms][tab_stride]
+    // dynamic LDS: [k_in_lds ? nk : 0] KPack, then [WAVES][natoms][tab_stride] double2
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    KPack* s_k = reinterpret_cast<KPack*>(s_raw);
+    double2* s_tab = reinterpret_cast<double2*>(s_raw + (k_in_lds ? sizeof(KPack) * (size_t)nk : 0));
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t p = (int64_t)blockIdx.x * WAVES + wave;
-    if (p >= n) return;                                      // no workgroup barrier below
+    if (k_in_lds) {
+        // every placement of the workgroup reads all k-vectors: stage them once (32 B per k-vector)
+        for (int64_t q = threadIdx.x; q < nk; q += 64 * WAVES) {
+            KPack kp;
+            const double t = kf[q];
+            kp.A = t * sfre[q]; kp.B = t * sfim[q]; kp.kf = t;
+            kp.ijk = ijk[3 * q] | ((ijk[3 * q + 1] + 128) << 8) | ((ijk[3 * q + 2] + 128) << 16);
+            kp._pad = 0;
+            s_k[q] = kp;
+        }
+        __syncthreads();
+    }
     const int kx = g.ks[0], ky = g.ks[1], kz = g.ks[2];
     const int nxp = kx + 1, nyp = 2 * ky + 1, nzp = 2 * kz + 1;
     double2* tab = s_tab + (size_t)wave * g.natoms * tab_stride;
     const double* I = g.invmat;
-    // ---- tables: entry t of atom a = exp(2 pi i m f), m and the axis decoded from t
-    for (int a = 0; a < g.natoms; ++a) {
-        const double* r = pos + ((size_t)p * g.natoms + a) * 3;
-        const double fx = I[0] * r[0] + I[3] * r[1] + I[6] * r[2];
-        const double fy = I[1] * r[0] + I[4] * r[1] + I[7] * r[2];
-        const double fz = I[2] * r[0] + I[5] * r[1] + I[8] * r[2];
-        for (int t = lane; t < nxp + nyp + nzp; t += 64) {
-            double f;
-            int m;
-            if (t < nxp) { f = fx; m = t; }
-            else if (t < nxp + nyp) { f = fy; m = t - nxp - ky; }
-            else { f = fz; m = t - nxp - nyp - kz; }
-            const double ff = f - rint(f);                   // exp(2 pi i m f) is periodic in f
-            double s, c;
-            sincospi(2.0 * (double)m * ff, &s, &c);
-            tab[a * tab_stride + t] = make_double2(c, s);
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    // ---- k-vector loop
-    double fa = 0.0, aa = 0.0;
-    for (int64_t q = lane; q < nk; q += 64) {
-        const int i = ijk[3 * q], j = ijk[3 * q + 1], k = ijk[3 * q + 2];
-        double sr = 0.0, si = 0.0;
+    const int64_t p0 = ((int64_t)blockIdx.x * WAVES + wave) * per_wave;
+    for (int64_t p = p0; p < p0 + per_wave && p < n; ++p) {
+        // ---- tables: entry t of atom a = exp(2 pi i m f), m and the axis decoded from t
         for (int a = 0; a < g.natoms; ++a) {
-            const double2 ex = tab[a * tab_stride + i];
-            const double2 ey = tab[a * tab_stride + nxp + ky + j];
-            const double2 ez = tab[a * tab_stride + nxp + nyp + kz + k];
-            const double yr = ey.x * ez.x - ey.y * ez.y, yi = ey.x * ez.y + ey.y * ez.x;      // Eiky*Eikz
-            const double cr = g.q[a] * yr, ci = g.q[a] * yi;                                  // c*Eik_yz
-            sr += ex.x * cr - ex.y * ci;
-            si += ex.x * ci + ex.y * cr;
+            const double* r = pos + ((size_t)p * g.natoms + a) * 3;
+            const double fx = I[0] * r[0] + I[3] * r[1] + I[6] * r[2];
+            const double fy = I[1] * r[0] + I[4] * r[1] + I[7] * r[2];
+            const double fz = I[2] * r[0] + I[5] * r[1] + I[8] * r[2];
+            for (int t = lane; t < nxp + nyp + nzp; t += 64) {
+                double f;
+                int m;
+                if (t < nxp) { f = fx; m = t; }
+                else if (t < nxp + nyp) { f = fy; m = t - nxp - ky; }
+                else { f = fz; m = t - nxp - nyp - kz; }
+                const double ff = f - rint(f);                   // exp(2 pi i m f) is periodic in f
+                double s, c;
+                sincospi(2.0 * (double)m * ff, &s, &c);
+                tab[a * tab_stride + t] = make_double2(c, s);
+            }
         }
-        const double t = kf[q];
-        fa += t * (sfre[q] * sr + sfim[q] * si);
-        aa += t * (sr * sr + si * si);
-    }
+        __builtin_amdgcn_wave_barrier();
+        // ---- k-vector loop
+        double fa = 0.0, aa = 0.0;
+        for (int64_t q = lane; q < nk; q += 64) {
+            int i, j, k;
+            double A, B, t;
+            if (k_in_lds) {
+                const KPack kp = s_k[q];
+                i = kp.ijk & 0xff; j = ((kp.ijk >> 8) & 0xff) - 128; k = ((kp.ijk >> 16) & 0xff) - 128;
+                A = kp.A; B = kp.B; t = kp.kf;
+            } else {
+                i = ijk[3 * q]; j = ijk[3 * q + 1]; k = ijk[3 * q + 2];
+                t = kf[q]; A = t * sfre[q]; B = t * sfim[q];
+            }
+            double sr = 0.0, si = 0.0;
+            for (int a = 0; a < g.natoms; ++a) {
+                const double2 ex = tab[a * tab_stride + i];
+                const double2 ey = tab[a * tab_stride + nxp + ky + j];
+                const double2 ez = tab[a * tab_stride + nxp + nyp + kz + k];
+                const double yr = ey.x * ez.x - ey.y * ez.y, yi = ey.x * ez.y + ey.y * ez.x;      // Eiky*Eikz
+                const double cr = g.q[a] * yr, ci = g.q[a] * yi;                                  // c*Eik_yz
+                sr += ex.x * cr - ex.y * ci;
+                si += ex.x * ci + ex.y * cr;
+            }
+            fa += A * sr + B * si;
+            aa += t * (sr * sr + si * si);
+        }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        fa += __shfl_xor(fa, o);
-        aa += __shfl_xor(aa, o);
+        for (int o = 32; o > 0; o >>= 1) {
+            fa += __shfl_xor(fa, o);
+            aa += __shfl_xor(aa, o);
+        }
+        if (lane == 0) out[p] = 2.0 * (fa + g.energy_net_charges) + (aa + g.static_contribution);
+        __builtin_amdgcn_wave_barrier();                         // the tables are rewritten for the next placement
     }
-    if (lane == 0) out[p] = 2.0 * (fa + g.energy_net_charges) + (aa + g.static_contribution);
 }
 
 int rerr(int code, const char* msg)
@@ -195,15 +228,26 @@ extern "C" int ceg_recip_energy_device(ceg_recip_t* h, const double* d_positions
     g.energy_net_charges = energy_net_charges;
     g.static_contribution = static_contribution;
     const int tab_stride = h->ks[0] + 1 + 2 * h->ks[1] + 1 + 2 * h->ks[2] + 1;
-    const size_t lds = sizeof(double2) * (size_t)WAVES * natoms * tab_stride;
-    if (lds > 64 * 1024) return rerr(CEG_ERR_UNSUPPORTED, "tables do not fit in LDS");
-    const int64_t nblocks = (n + WAVES - 1) / WAVES;
+    const size_t tab_bytes = sizeof(double2) * (size_t)WAVES * natoms * tab_stride;
+    if (tab_bytes > 64 * 1024) return rerr(CEG_ERR_UNSUPPORTED, "tables do not fit in LDS");
+    // k-vector constants in LDS when they fit beside the tables (every placement reads all of them)
+    const size_t k_bytes = sizeof(KPack) * (size_t)h->nk;
+    const bool small_k = h->ks[1] < 128 && h->ks[2] < 128 && h->ks[0] < 256;
+    const int k_in_lds = (small_k && tab_bytes + k_bytes <= 60 * 1024) ? 1 : 0;
+    const size_t lds = tab_bytes + (k_in_lds ? k_bytes : 0);
+    // placements per wave: amortise the staging of the k-vectors, but keep >= ~4 workgroups per CU in flight
+    int per_wave = 1;
+    if (k_in_lds) {
+        per_wave = 8;
+        while (per_wave > 1 && n / ((int64_t)per_wave * WAVES) < 2048) per_wave >>= 1;
+    }
+    const int64_t nblocks = (n + (int64_t)WAVES * per_wave - 1) / ((int64_t)WAVES * per_wave);
     if (nblocks > 0x7fffffffLL) return rerr(CEG_ERR_INVALID, "too many placements");
     int prev = -1;
     (void)hipGetDevice(&prev);
     if (hipSetDevice(h->device) != hipSuccess) return rerr(CEG_ERR_HIP, "hipSetDevice failed");
     hipLaunchKernelGGL(k_recip, dim3((unsigned)nblocks), dim3(64 * WAVES), lds, (hipStream_t)stream, g, h->d_ijk, h->d_kf,
-                       h->d_re, h->d_im, h->nk, d_positions, n, d_out, tab_stride);
+                       h->d_re, h->d_im, h->nk, d_positions, n, d_out, tab_stride, per_wave, k_in_lds);
     const hipError_t e = hipGetLastError();
     if (prev >= 0) (void)hipSetDevice(prev);
     if (e != hipSuccess) return rerr(CEG_ERR_HIP, hipGetErrorString(e));
