@@ -47,7 +47,7 @@ def parse_args():
     ap.add_argument("--mode", choices=("fused", "vdw", "coulomb"), default="fused")
     ap.add_argument("--probe", default="Ar", help="probe atom of the VdW grid (Ar: LJ; Na: Buckingham + hard sphere)")
     ap.add_argument("--algo", choices=("auto", "bruteforce", "culled"), default="auto")
-    ap.add_argument("--gather", choices=("staged", "inplace"), default="staged", help="how a gathered chunk is placed (N > 1)")
+    ap.add_argument("--gather", choices=("staged", "inplace", "p2p"), default="staged", help="how a gathered chunk is placed (N > 1)")
     ap.add_argument("--chunks", type=int, default=4, help="x-chunks per rank pipelined with the all-gather (N > 1)")
     ap.add_argument("--n", type=int, default=255, help="dims per axis (odd); grid has (n+1)^3 points")
     ap.add_argument("--cpu-rows", type=int, default=-1, help="y-rows per x-plane the CPU baseline times, one plane per thread (-1 = auto ~12 s, 0 = skip)")

@@ -127,12 +127,16 @@ class PipelinedGather:
       ``[world, 8, m, ny, nz]`` staging buffer, then one strided device copy into the final
       ``[8, nx, ny, nz]`` array (channel and rank axes swapped);
     * ``"inplace"``: 8 ``all_gather_into_tensor`` calls per grid and chunk (one per channel)
-      straight into the final array -- no copy, more (smaller) collectives.
+      straight into the final array -- no copy, more (smaller) collectives;
+    * ``"p2p"``: the same staging buffer filled by one grouped ``batch_isend_irecv`` per chunk -- every
+      rank sends its block to each peer and receives each peer's block directly.  xGMI is a full mesh
+      of point-to-point links, so the 7 transfers of a rank travel on 7 different links at once and
+      no block is forwarded; an alternative to RCCL's ring all-gather to be compared on an 8-GPU node.
     """
 
     def __init__(self, plan: CyclicPlan, fulls: List[torch.Tensor], locals_: List[torch.Tensor], group=None,
                  mode: str = "staged", force_collectives: bool = False):
-        assert mode in ("staged", "inplace")
+        assert mode in ("staged", "inplace", "p2p")
         self.plan, self.fulls, self.locals, self.group, self.mode = plan, fulls, locals_, group, mode
         self.exchange = plan.world > 1 or force_collectives      # world 1: collectives only on request (tests)
         dev = fulls[0].device
@@ -140,7 +144,7 @@ class PipelinedGather:
         for full, loc in zip(fulls, locals_):
             assert tuple(loc.shape) == (plan.nchunks, full.shape[0], plan.m) + tuple(full.shape[2:]) and loc.is_contiguous()
         self.staging = None
-        if mode == "staged" and self.exchange:
+        if mode in ("staged", "p2p") and self.exchange:
             shape = (plan.world,) + tuple(locals_[0].shape[1:])
             self.staging = [[torch.empty(shape, dtype=f.dtype, device=dev) for f in fulls] for _ in range(2)]
 
@@ -148,6 +152,20 @@ class PipelinedGather:
         p = self.plan
         lo, hi = p.block(j)
         backend = dist.get_backend(self.group)
+        if self.mode == "p2p":
+            ops = []
+            for g, loc in enumerate(self.locals):
+                block, stage = loc[j], self.staging[j % 2][g]
+                stage[p.rank].copy_(block)
+                for r in range(p.world):
+                    if r != p.rank:
+                        ops.append(dist.P2POp(dist.isend, block, r, group=self.group))
+                        ops.append(dist.P2POp(dist.irecv, stage[r], r, group=self.group))
+            for req in (dist.batch_isend_irecv(ops) if ops else []):
+                req.wait()
+            for g, full in enumerate(self.fulls):
+                full[:, lo:hi].unflatten(1, (p.world, p.m)).copy_(self.staging[j % 2][g].permute(1, 0, 2, 3, 4))
+            return
         for g, (full, loc) in enumerate(zip(self.fulls, self.locals)):
             block = loc[j]                                            # [8, m, ny, nz], contiguous
             if self.mode == "inplace":

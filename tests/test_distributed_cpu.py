@@ -46,7 +46,7 @@ def _worker(rank, world, port, spacing, outdir):
         from ceg_hip.distributed import PipelinedGather, cyclic_plan
         cyc = cyclic_plan(nx, world, rank, nchunks=4, align=1)
         if cyc is not None:
-            for mode in ("staged", "inplace"):
+            for mode in ("staged", "inplace", "p2p"):
                 loc = torch.full((cyc.nchunks, 8, cyc.m, ny, nz), float("nan"), dtype=torch.float32)
                 full2 = torch.full((8, nx, ny, nz), float("nan"), dtype=torch.float32)
 
@@ -73,12 +73,12 @@ def test_slab_gather_gloo(tmp_path, world, spacing, oracle):
     for r in range(world):
         got = np.load(tmp_path / f"rank{r}.npy")
         np.testing.assert_array_equal(got, ref)
-        for mode in ("staged", "inplace"):
+        for mode in ("staged", "inplace", "p2p"):
             f = tmp_path / f"rank{r}_cyclic_{mode}.npy"
             if f.exists():
                 np.testing.assert_array_equal(np.load(f), ref)
                 ncyc += 1
-    assert ncyc in (0, 2 * world)
+    assert ncyc in (0, 3 * world)
 
 
 def test_cyclic_plan_shapes():

@@ -444,7 +444,7 @@ def test_pipelined_gather_over_rccl_single_rank(hip_lib):
         plan.build_fused(ref_v.data_ptr(), ref_c.data_ptr(), nx * plane, 0, nx, 0, CULLED, s)
         cyc = cyclic_plan(nx, 1, 0, nchunks=4)
         assert cyc.nchunks == 4 and cyc.m == 16
-        for mode in ("staged", "inplace"):
+        for mode in ("staged", "inplace", "p2p"):
             fulls = [torch.full_like(ref_v, float("nan")), torch.full_like(ref_c, float("nan"))]
             locs = [torch.full((4, 8, cyc.m, ny, nz), float("nan"), dtype=torch.float32, device=dev) for _ in range(2)]
             pipe = PipelinedGather(cyc, fulls, locs, mode=mode, force_collectives=True)
