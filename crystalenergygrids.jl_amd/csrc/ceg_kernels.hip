@@ -448,6 +448,7 @@ __global__ __launch_bounds__(CEG_WG, culled_waves(MODE, VDWK, FASTEW)) void k_cu
     __shared__ unsigned long long s_odd_all[NW][64];
     __shared__ __attribute__((aligned(16))) double s_erfcx[ERFCX_TAB_N * 6];
     __shared__ double s_exp2[64];
+    __shared__ int32_t s_org[NW][4];             // tile origins for the output transpose (grid mode)
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double4* s_cand = s_cand_all[wave];
@@ -500,14 +501,20 @@ __global__ __launch_bounds__(CEG_WG, culled_waves(MODE, VDWK, FASTEW)) void k_cu
         const int nq = (tiles_k + NW - 1) / NW;
         const int tk = (int)((tile % tiles_k + (int64_t)NW * ((ti + (out.i_begin >> 2) + tj) % nq)) % tiles_k);
         i0 = out.i_begin + 4 * ti; j0 = 4 * tj; k0 = 4 * tk;
+        if (lane == 0) {                     // read back after the final barrier; written here so that the
+            s_org[wave][0] = active ? i0 : -1;   // origin does not have to stay in registers across the loops
+            s_org[wave][1] = j0;
+            s_org[wave][2] = k0;
+        }
         i = i0 + (lane >> 4);
         j = j0 + ((lane >> 2) & 3);
         k = k0 + (lane & 3);
         valid = active && (i < out.i_end) && (j <= g.dims[1]) && (k <= g.dims[2]);
-        // out-of-range lanes take the tile's first point (always valid) so they stay inside the box
-        const int ci = valid ? i : (out.i_begin + 4 * ti);
-        const int cj = valid ? j : 4 * tj;
-        const int ck = valid ? k : 4 * tk;
+        // out-of-range lanes are clamped onto the last valid plane / row / column of the tile (its first
+        // point is always valid), so they stay inside the box of the valid ones and store nothing
+        const int ci = i < out.i_end ? i : out.i_end - 1;
+        const int cj = j <= g.dims[1] ? j : g.dims[1];
+        const int ck = k <= g.dims[2] ? k : g.dims[2];
         px = grid_coord(ci, g.size[0], g.dims[0], g.shift[0]);
         py = grid_coord(cj, g.size[1], g.dims[1], g.shift[1]);
         pz = grid_coord(ck, g.size[2], g.dims[2], g.shift[2]);
@@ -766,7 +773,6 @@ __global__ __launch_bounds__(CEG_WG, culled_waves(MODE, VDWK, FASTEW)) void k_cu
     // ---- grid mode: the NW tiles of a workgroup are consecutive along z (the fastest array
     // axis), so the workgroup transposes its results through LDS and writes rows of 4*NW
     // contiguous floats (64 B at NW = 4) per (channel, i, j) instead of 16-B fragments.
-    __shared__ int32_t s_org[NW][4];
     float* smv = reinterpret_cast<float*>(s_cand_all[wave]);     // 512 floats per wave, staging is done
     float* smc = reinterpret_cast<float*>(s_lj_all[wave]);
     __builtin_amdgcn_wave_barrier();
@@ -782,11 +788,6 @@ __global__ __launch_bounds__(CEG_WG, culled_waves(MODE, VDWK, FASTEW)) void k_cu
         gridpoint8(r, g.delta, out.lambda_coulomb, out.thr_coulomb, ac);
 #pragma unroll
         for (int c = 0; c < 8; ++c) smc[c * 64 + lane] = r[c];
-    }
-    if (lane == 0) {
-        s_org[wave][0] = active ? i0 : -1;
-        s_org[wave][1] = j0;
-        s_org[wave][2] = k0;
     }
     __syncthreads();
     const int64_t nz = g.dims[2] + 1, ny = g.dims[1] + 1;

@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage: scripts/time_variants.sh "<mode> <probe>" ...   -- bench.py with every library variant in build_variants/ (plus the in-tree one)
 mkdir -p gpurun_out
+shopt -s nullglob
 for lib in crystalenergygrids.jl_amd/csrc/libceg_hip.so build_variants/*.so; do
   for mp in "$@"; do
     read -r mode probe <<< "$mp"; probe=${probe:-Ar}
