@@ -12,7 +12,7 @@ import numpy as np
 from .ewald import EwaldFramework, initialize_ewald
 from .forcefields import ForceField
 from .grids import (BlockFile, CrystalEnergySetup, EnergyGrid, create_grid_coulomb, create_grid_vdw,
-                    parse_blockfile, parse_grid)
+                    parse_blockfile, parse_blockfile_gpu, parse_grid)
 from .coordinates import GridCoordinatesSetup
 from .raspa import (RASPASystem, _ff, _ffname, _ffpal, getdir_RASPA, load_framework_RASPA,
                     load_molecule_RASPA)
@@ -47,13 +47,18 @@ def decide_parse_block(blockfile, molecule: RASPASystem, framework_name) -> str:
     return str(newblockfile)
 
 
-def parse_block(blockfile, framework_name, framework: RASPASystem, molecule: RASPASystem, spacing: float) -> BlockFile:
-    """raspa.jl:397-403"""
+def parse_block(blockfile, framework_name, framework: RASPASystem, molecule: RASPASystem, spacing: float,
+                scan: str = "gpu") -> BlockFile:
+    """raspa.jl:397-403.  The point x sphere scan of parse_blockfile runs on the GPU (``ceg_block_spheres``);
+    ``scan="host"`` selects the numpy mirror of the reference loop (used by the CPU-only tests)."""
     blockpath = decide_parse_block(blockfile, molecule, framework_name)
     csetup = GridCoordinatesSetup.from_cell(framework.mat, spacing)
     if not blockpath:
         return BlockFile(csetup)
-    return parse_blockfile(os.path.join(getdir_RASPA(), "structures", "block", blockpath) + ".block", csetup)
+    path = os.path.join(getdir_RASPA(), "structures", "block", blockpath) + ".block"
+    if scan == "host":
+        return parse_blockfile(path, csetup)
+    return parse_blockfile_gpu(path, csetup)
 
 
 def grid_locations(framework, pff, forcefield: ForceField, atoms: List[str], gridstep: float, supercell):

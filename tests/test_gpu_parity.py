@@ -673,6 +673,21 @@ def test_reference_energy_grid_flow(hip_lib, tmp_path):
         assert egrid[28, 59, 59] == pytest.approx(-1.9278944364761321e6, rel=1e-4)
         assert egrid[28, 59, 59] == pytest.approx(-1927971.7327074807, rel=1e-9)
         gs.close()
+        # --- blocking sphere straddling a periodic boundary (runtests.jl:269-272); the sphere scan of
+        #     parse_blockfile runs on the GPU inside setup_RASPA
+        setup = ceg.setup_RASPA("CIT7block", "BoulfelfelSholl2021", "Ar", "TraPPE")
+        assert not setup.block.empty
+        assert ceg.energy_point(setup, [[12.5, 0.8, 0.3]]) == (1e100, 0.0)
+        assert ceg.energy_point(setup, [[20.175808361078516, 10.58027451750961, 9.185277912816744]]) == (1e100, 0.0)
+        gs = GpuEnergySetup(setup)
+        pts = np.concatenate([[[12.5, 0.8, 0.3]], np.random.default_rng(4).uniform(0.0, 12.0, (200, 3))])[:, None, :]
+        e = gs.energy_points(pts)
+        assert tuple(e[0]) == (1e100, 0.0) and np.all(e[:, 1] == 0.0)
+        host = np.array([ceg.energy_point(setup, p)[0] for p in pts])
+        assert np.array_equal(e[:, 0] == 1e100, host == 1e100) and (host != 1e100).any()
+        ok = host != 1e100
+        assert np.allclose(e[ok, 0], host[ok], rtol=1e-9, atol=1e-9)
+        gs.close()
     finally:
         ceg.setdir_RASPA(GOLDEN / "raspa")
 

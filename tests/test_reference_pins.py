@@ -145,7 +145,7 @@ def test_blocking_spheres(forcefield):
     pin = PINS["blocked_points"]
     fw = ceg.load_framework_RASPA(pin["framework"], FFNAME)
     ar = ceg.load_molecule_RASPA("Ar", "TraPPE", FFNAME, fw)
-    block = parse_block(None, pin["framework"], fw, ar, 0.15)
+    block = parse_block(None, pin["framework"], fw, ar, 0.15, scan="host")
     assert not block.empty
     setup = G.CrystalEnergySetup(fw, ar, G.EnergyGrid.trivial(True), [0.0], [G.EnergyGrid.trivial(True)], [0],
                                  ceg.EwaldFramework.empty(fw.mat), forcefield, block)
