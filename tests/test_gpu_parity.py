@@ -150,6 +150,8 @@ def test_random_cells_fuzz(hip_lib, oracle):
         cutoff = float(rng.choice([9.0, 10.5, 12.0]))
         n = int(rng.integers(40, 200))
         pos = random_atoms(mat, n, rng, min_sep=1.2)
+        if done % 2:                  # atoms given outside the unit cell (unwrapped input), as a CIF may list them
+            pos = pos + (mat @ rng.integers(-2, 3, (3, n))).T
         pv, pc = synthetic_probes(mat, pos, rng.integers(1, 5, n), rng.uniform(-1.5, 1.5, n), cutoff=cutoff)
         ortho, safemin2 = pv.periodic_setup()
         seen["ortho" if ortho else ("stale" if safemin2 < cutoff ** 2 else "plain")] += 1
