@@ -155,7 +155,7 @@ def test_random_cells_fuzz(hip_lib, oracle):
         pv, pc = synthetic_probes(mat, pos, rng.integers(1, 5, n), rng.uniform(-1.5, 1.5, n), cutoff=cutoff)
         ortho, safemin2 = pv.periodic_setup()
         seen["ortho" if ortho else ("stale" if safemin2 < cutoff ** 2 else "plain")] += 1
-        dims = tuple(int(x) for x in 2 * rng.integers(1, 7, 3) + 1)
+        dims = tuple(int(x) for x in 2 * rng.integers(0, 7, 3) + 1)             # 1 ... 13: down to 2 points per axis
         cset = W.grid_setup_with_dims(mat, dims)
         alpha = float(rng.uniform(0.2, 0.3))
         plan = GridPlan(cset, pv, pc, alpha)
