@@ -6,6 +6,12 @@ Same names and argument meaning as the reference's public functions for this pat
 ``interpolate_grid``, ``energy_point`` ...).  The compute path is the HIP library only;
 importing this package does not load it, the first grid build does and fails loudly if it
 is not built.
+
+Modules beyond the re-exports below: ``plan`` (resident-plan API, device buffers), ``distributed``
+(x-slab / block-cyclic sharding over ranks), ``interp`` / ``energy`` (batched GPU consumers of the
+grids: interpolation, reciprocal Ewald, pair energies, ``GpuEnergySetup``, ``GpuMonteCarloEnergy``),
+``montecarlo`` (host mirror of the reference's MC energy functions, used to pin them), ``workloads``
+(the BASELINE.json configurations).
 """
 from .constants import GRID_TO_KELVIN, COULOMBIC_CONVERSION_FACTOR
 from .interactions import FF, Mixing, InteractionRule, InteractionRuleSum, UndefinedInteractionError
