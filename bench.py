@@ -271,7 +271,9 @@ def main():
                                  "(>= 1e3 flop per compulsory HBM byte), see roofline_hbm for the byte view"},
             "roofline_hbm": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes,
-                             "note": "algorithmic bytes (32 B/point/grid written once + 36 B/image) over the kernel time; ~1 % by construction"},
+                             "measured_GBps": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
+                             "note": "algorithmic bytes (32 B/point/grid written once + 36 B/image) over the kernel time; ~1 % by construction; "
+                                     "measured_GBps = PMC traffic (WRITE_SIZE + 2 x FETCH_SIZE, profiles/hbm_traffic.json) over the same time"},
             "selfcheck": check,
         }
         if multi:
