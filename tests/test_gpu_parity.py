@@ -848,3 +848,34 @@ def test_grid_beyond_32bit_indexing(hip_lib, oracle):
     del grid
     plan.close()
     torch.cuda.empty_cache()
+
+
+def test_oneshot_reentrant_from_several_threads(hip_lib):
+    """the one-shot entry points must be re-entrant across different output buffers.  Four host
+    threads build different grids at the same time (ctypes releases the GIL during the call), repeatedly,
+    sharing the library's pinned / device / stream / block caches; every result equals the sequential one."""
+    import threading
+    ws = [W.fixture_workload("CIT-7", "Na", 0.25), W.fixture_workload("CHA_1.4_3b4eeb96", "Ar", 0.4)]
+    jobs = [(lambda w=w: G.build_vdw_array(w.probe_vdw, w.cset)) for w in ws] + \
+           [(lambda w=w: G.build_coulomb_array(w.probe_coulomb, w.alpha, w.cset)) for w in ws]
+    ref = [j() for j in jobs]
+    for rnd in range(3):
+        out = [None] * len(jobs)
+        err = []
+
+        def run(t):
+            try:
+                out[t] = jobs[t]()
+            except Exception as e:          # noqa: BLE001
+                err.append((t, repr(e)))
+        th = [threading.Thread(target=run, args=(t,)) for t in range(len(jobs))]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        assert not err, err
+        for t in range(len(jobs)):
+            assert np.array_equal(out[t], ref[t], equal_nan=True), (rnd, t)
+    assert hip_lib.ceg_release_cached_buffers() == 0
+    again = jobs[0]()                        # caches are rebuilt on demand
+    assert np.array_equal(again, ref[0], equal_nan=True)
