@@ -116,7 +116,10 @@ struct PlanConst {
 
 // shared between the host table builder and the kernels
 constexpr int CEG_ERFCX_TAB_N = 128;     // pieces of the erfcx table (= ERFCX_TAB_N of ceg_math.h)
-constexpr double CEG_R_EXACT2 = 4.0;     // pairs closer than this (A^2) take the exact path
+#ifndef CEG_R_EXACT2_VALUE
+#define CEG_R_EXACT2_VALUE 4.0
+#endif
+constexpr double CEG_R_EXACT2 = CEG_R_EXACT2_VALUE;     // pairs closer than this (A^2) take the exact path
 
 // launchers (ceg_kernels.hip)
 hipError_t launch_bruteforce(int mode, const Geom& g, const AtomTable& atoms, const RuleTable& rt,
