@@ -582,15 +582,30 @@ def test_roofline_workload_properties(hip_lib, oracle):
     compare_grids(full_c[:, i0:i1, j0:j1].cpu().numpy(), ref[:, i0:i1, j0:j1], "R/oracle/coulomb")
 
 
-def test_multi_device_oneshot_if_available(hip_lib, oracle):
-    """ngpus > 1 in the one-shot entry point (single process, slabs on several devices)."""
+def test_multi_device_oneshot(hip_lib, oracle, monkeypatch):
+    """ngpus > 1 in the one-shot entry point (single process, one host thread + plan + slab per device).  On a
+    one-GPU box the slabs are oversubscribed onto the one card (CEG_HIP_OVERSUBSCRIBE), which still runs the
+    slab split, the per-device threads and their concurrent use of the caches; uneven splits included."""
     n = hip_lib.ceg_device_count()
     if n < 2:
-        pytest.skip("one device visible")
+        monkeypatch.setenv("CEG_HIP_OVERSUBSCRIBE", "1")
     w = W.fixture_workload("CHA_1.4_3b4eeb96", "Ar", 0.7)
+    nx = w.cset.npoints[0]
     lam, thr = G.vdw_scaling()
     ref, _ = oracle.grid_vdw(w.probe_vdw, w.cset, lam, thr)
-    compare_grids(G.build_vdw_array(w.probe_vdw, w.cset, ngpus=min(n, 4)), ref, "multi-device")
+    one = G.build_vdw_array(w.probe_vdw, w.cset, ngpus=1)
+    for ng in (2, 3, 4) if n < 2 else (min(n, 4),):
+        got = G.build_vdw_array(w.probe_vdw, w.cset, ngpus=ng)
+        compare_grids(got, ref, f"multi-device x{ng}")
+        assert np.array_equal(got, one, equal_nan=True) or np.allclose(got, one, rtol=1e-6, equal_nan=True)
+    lamc, thrc = G.coulomb_scaling()
+    refc, _ = oracle.grid_coulomb(w.probe_coulomb, w.alpha, w.cset, lamc, thrc)
+    compare_grids(G.build_coulomb_array(w.probe_coulomb, w.alpha, w.cset, ngpus=3 if n < 2 else min(n, 4)), refc, "multi-device coulomb")
+    if n < 2:
+        monkeypatch.delenv("CEG_HIP_OVERSUBSCRIBE")
+        with pytest.raises(_abi.CegError) as ei:
+            G.build_vdw_array(w.probe_vdw, w.cset, ngpus=2)
+        assert ei.value.code == -2
 
 
 # ------------------------------------------------------------------ row f2: batched reciprocal Ewald + energy_grid
