@@ -49,9 +49,12 @@ def parse_args():
     ap.add_argument("--algo", choices=("auto", "bruteforce", "culled"), default="auto")
     ap.add_argument("--gather", choices=("staged", "inplace", "p2p"), default="staged", help="how a gathered chunk is placed (N > 1)")
     ap.add_argument("--chunks", type=int, default=4, help="x-chunks per rank pipelined with the all-gather (N > 1)")
-    ap.add_argument("--n", type=int, default=255, help="dims per axis (odd); grid has (n+1)^3 points")
+    ap.add_argument("--n", "--dims", dest="n", type=int, default=255, help="dims per axis (odd); grid has (n+1)^3 points")
     ap.add_argument("--cpu-rows", type=int, default=-1, help="y-rows per x-plane the CPU baseline times, one plane per thread (-1 = auto ~12 s, 0 = skip)")
     ap.add_argument("--no-check", action="store_true", help="skip the built-in oracle spot check")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="torch.distributed backend; gloo is a rehearsal aid: several ranks may then share one GPU "
+                         "(device = LOCAL_RANK mod device count), which RCCL refuses")
     ap.add_argument("--force-exchange", action="store_true",
                     help="N = 1 only: run the N > 1 code path (RCCL group of one rank, chunked build, collectives issued) -- a rehearsal")
     return ap.parse_args()
@@ -109,6 +112,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the grid build has no CPU path)")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     multi = world > 1 or args.force_exchange          # take the sharded code path
@@ -116,7 +121,10 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29512")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
@@ -280,7 +288,7 @@ def main():
             # gather time reported separately.  compute_ms = span of this rank's kernels
             # (max over ranks); what is left of the step is the part of the exchange that was not hidden
             out["exchange"] = {"compute_ms": kern_ms, "exposed_ms": max(0.0, ms - kern_ms), "mode": args.gather if cyc is not None else "slab",
-                               "bytes_gathered_per_rank": 32.0 * npts * ngrids * (world - 1) / world, "backend": "nccl (RCCL over xGMI)"}
+                               "bytes_gathered_per_rank": 32.0 * npts * ngrids * (world - 1) / world, "backend": "nccl (RCCL over xGMI)" if args.backend == "nccl" else "gloo (rehearsal)"}
         if world == 1 and args.cpu_rows != 0:
             out["cpu_baseline"] = cpu_baseline(w, args.mode, args.cpu_rows)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
