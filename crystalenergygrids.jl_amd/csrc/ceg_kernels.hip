@@ -354,6 +354,16 @@ constexpr int META_HASVDW = 1 << 25;      // the atom's kind has at least one Vd
 constexpr int META_BUCK = 1 << 26;        // fast class 2 (Buckingham) instead of 1 (Lennard-Jones)
 constexpr int META_KINDMASK = (1 << 24) - 1;
 
+// LDS record of one kept candidate of the culled kernel (80 B)
+struct __attribute__((aligned(16))) Quad { double x, y, z, w; };     // double4 would force 32-B alignment (96-B records)
+struct __attribute__((aligned(16))) CandRec {
+    Quad xyzq;          // lattice-image position, charge
+    Quad lj;            // fast VdW class parameters of the image's kind (4 eps, sigma^2, -, shift | A, B, C, shift)
+    int32_t meta;       // kind | META_* flags
+    int32_t atom;       // index of the original atom (slow path)
+    int32_t _pad[2];
+};
+
 // ------------------------------------------------------------------ culled kernel
 // Pairs the hot loop of k_culled sets aside: for candidate q of the current LDS chunk, s_odd[q] is
 // the mask of lanes whose pair with q is "odd" (very close, within 1e-9 of a decision threshold,
@@ -365,7 +375,7 @@ constexpr int META_KINDMASK = (1 << 24) - 1;
 template <int MODE, bool FASTEW, bool LJSLOW>
 __device__ __forceinline__ void slow_pairs(const PlanConst* __restrict__ pc, unsigned long long cands, int lane,
                                            double px, double py, double pz,
-                                           const int32_t* s_meta, const int32_t* s_atom,
+                                           const CandRec* s_rec,
                                            const unsigned long long* s_odd,
                                            Accum& av, Accum& ac, double& smallest_d2)
 {
@@ -375,8 +385,8 @@ __device__ __forceinline__ void slow_pairs(const PlanConst* __restrict__ pc, uns
         cands &= cands - 1ull;
         const unsigned long long lanes = s_odd[q];
         if (!((lanes >> lane) & 1ull)) continue;
-        const int mt = s_meta[q];
-        const double4 O = pc->ib.atoms[s_atom[q]];
+        const int mt = s_rec[q].meta;
+        const double4 O = pc->ib.atoms[s_rec[q].atom];
         double dx = px - O.x, dy = py - O.y, dz = pz - O.z;
         const double r2 = periodic_distance2_literal(g, dx, dy, dz);
         if (r2 >= g.cutoff2) continue;
@@ -421,6 +431,8 @@ __device__ __forceinline__ double wave_max(double x)
     return x;
 }
 
+static_assert(sizeof(CandRec) == 80, "candidate record layout");
+
 // Template flags of k_culled
 //   MODE    what is accumulated (VdW / Coulomb / both in one pass)
 //   POINTS  arbitrary point list (eval_points) instead of 4x4x4 grid tiles
@@ -439,10 +451,9 @@ __global__ __launch_bounds__(CEG_WG, culled_waves(MODE, VDWK, FASTEW)) void k_cu
     // arrays (waves never touch each other's slice, so no workgroup barrier inside the loops --
     // LDS operations of one wave complete in order).  The function tables are shared.
     constexpr int NW = CEG_WG / 64;
-    __shared__ double4 s_cand_all[NW][64];
-    __shared__ double4 s_lj_all[NW][64];
-    __shared__ int32_t s_meta_all[NW][64];
-    __shared__ int32_t s_atom_all[NW][64];
+    // one record per kept candidate: image position + charge, VdW parameters of its kind, flags, atom index.
+    // A single array so that the hot loop walks ONE LDS address (immediate offsets reach the fields).
+    __shared__ __attribute__((aligned(16))) CandRec s_rec_all[NW][64];
     __shared__ int32_t s_rowstart_all[NW][64];
     __shared__ int32_t s_rowprefix_all[NW][66];
     __shared__ unsigned long long s_odd_all[NW][64];
@@ -451,10 +462,7 @@ __global__ __launch_bounds__(CEG_WG, culled_waves(MODE, VDWK, FASTEW)) void k_cu
     __shared__ int32_t s_org[NW][4];             // tile origins for the output transpose (grid mode)
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double4* s_cand = s_cand_all[wave];
-    double4* s_lj = s_lj_all[wave];
-    int32_t* s_meta = s_meta_all[wave];
-    int32_t* s_atom = s_atom_all[wave];
+    CandRec* s_rec = s_rec_all[wave];
     int32_t* s_rowstart = s_rowstart_all[wave];
     int32_t* s_rowprefix = s_rowprefix_all[wave];
     unsigned long long* s_odd = s_odd_all[wave];
@@ -644,10 +652,10 @@ __global__ __launch_bounds__(CEG_WG, culled_waves(MODE, VDWK, FASTEW)) void k_cu
             if (keep) {
                 const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                                            __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                s_cand[slot] = P;
-                if (FASTVDW && MODE != MODE_COULOMB) s_lj[slot] = LJ;
-                s_meta[slot] = meta;
-                s_atom[slot] = aidx;
+                s_rec[slot].xyzq = Quad{P.x, P.y, P.z, P.w};
+                if (FASTVDW && MODE != MODE_COULOMB) s_rec[slot].lj = Quad{LJ.x, LJ.y, LJ.z, LJ.w};
+                s_rec[slot].meta = meta;
+                s_rec[slot].atom = aidx;
             }
             __builtin_amdgcn_wave_barrier();
 
@@ -658,8 +666,8 @@ __global__ __launch_bounds__(CEG_WG, culled_waves(MODE, VDWK, FASTEW)) void k_cu
             //    the reference's literal arithmetic (slow_pairs).
             unsigned long long slow = 0ull;     // wave-uniform: candidates with at least one odd lane
             for (int q = 0; q < nkeep; ++q) {
-                const double4 A = s_cand[q];
-                const int mt = __builtin_amdgcn_readfirstlane(s_meta[q]);
+                const Quad A = s_rec[q].xyzq;
+                const int mt = __builtin_amdgcn_readfirstlane(s_rec[q].meta);
                 double dx = px - A.x, dy = py - A.y, dz = pz - A.z;
                 const double r2 = dx * dx + dy * dy + dz * dz;
                 // regular: R_EXACT2 <= r2 < min(cutoff2 - band, stale limit), image provably the
@@ -688,7 +696,7 @@ __global__ __launch_bounds__(CEG_WG, culled_waves(MODE, VDWK, FASTEW)) void k_cu
                     if (VDWK == 2 && (mt & META_BUCK)) {
                         // derivativesGrid, Buckingham branch (src/interactions.jl:447-457); a hard
                         // sphere summed with it is 0 here (its radius lies inside the exact path)
-                        const double4 L = s_lj[q];             // A, B, C, shift
+                        const Quad L = s_rec[q].lj;            // A, B, C, shift
                         const double Br = L.y * rr;
                         const double xe = L.x * exp_neg_tab(s_exp2, -Br);
                         const double inv2 = inv * inv;
@@ -702,7 +710,7 @@ __global__ __launch_bounds__(CEG_WG, culled_waves(MODE, VDWK, FASTEW)) void k_cu
                                            -((Bxe * rinv3) * inv) * __builtin_fma(Br, add_sc(Br, 3.0), 3.0));
                     } else if (FASTVDW) {
                         // derivativesGrid, LJ branch (src/interactions.jl:434-441), with 1/r2 shared
-                        const double4 L = s_lj[q];             // 4 eps, sigma^2, -, shift
+                        const Quad L = s_rec[q].lj;            // 4 eps, sigma^2, -, shift
                         const double sx = L.y * inv;
                         const double x6 = sx * sx * sx;
                         const double t1 = L.x * x6;                        // 4 eps x6
@@ -762,7 +770,7 @@ __global__ __launch_bounds__(CEG_WG, culled_waves(MODE, VDWK, FASTEW)) void k_cu
             // -- the pairs set aside above, one per lane per round
             if (slow != 0ull) {
                 __builtin_amdgcn_wave_barrier();
-                slow_pairs<MODE, FASTEW, VDWK == 1>(pc, slow, lane, px, py, pz, s_meta, s_atom, s_odd, av, ac, smallest_d2);
+                slow_pairs<MODE, FASTEW, VDWK == 1>(pc, slow, lane, px, py, pz, s_rec, s_odd, av, ac, smallest_d2);
             }
         }
     }
@@ -773,8 +781,8 @@ __global__ __launch_bounds__(CEG_WG, culled_waves(MODE, VDWK, FASTEW)) void k_cu
     // ---- grid mode: the NW tiles of a workgroup are consecutive along z (the fastest array
     // axis), so the workgroup transposes its results through LDS and writes rows of 4*NW
     // contiguous floats (64 B at NW = 4) per (channel, i, j) instead of 16-B fragments.
-    float* smv = reinterpret_cast<float*>(s_cand_all[wave]);     // 512 floats per wave, staging is done
-    float* smc = reinterpret_cast<float*>(s_lj_all[wave]);
+    float* smv = reinterpret_cast<float*>(s_rec_all[wave]);      // 2 x 512 floats per wave (5120 B available), staging is done
+    float* smc = smv + 512;
     __builtin_amdgcn_wave_barrier();
     if (MODE != MODE_COULOMB) {
         float r[8];
@@ -804,13 +812,13 @@ __global__ __launch_bounds__(CEG_WG, culled_waves(MODE, VDWK, FASTEW)) void k_cu
         const int so = c * 64 + li * 16 + lj * 4;
         const int nvalid = (g.dims[2] + 1 - gk) < 4 ? (g.dims[2] + 1 - gk) : 4;
         if (MODE != MODE_COULOMB) {
-            const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(s_cand_all[w]) + so);
+            const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(s_rec_all[w]) + so);
             float* dst = out.vdw + idx;
             if (nvalid == 4) store_float4_unaligned(dst, v);
             else { dst[0] = v.x; if (nvalid > 1) dst[1] = v.y; if (nvalid > 2) dst[2] = v.z; }
         }
         if (MODE != MODE_VDW) {
-            const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(s_lj_all[w]) + so);
+            const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(s_rec_all[w]) + 512 + so);
             float* dst = out.coulomb + idx;
             if (nvalid == 4) store_float4_unaligned(dst, v);
             else { dst[0] = v.x; if (nvalid > 1) dst[1] = v.y; if (nvalid > 2) dst[2] = v.z; }
