@@ -1,5 +1,5 @@
 """Long randomized parity run (not part of the suite): random cells / atoms / cutoffs / grids, both kernels
-(brute force, culled) and the stored Float32 grids against the oracle.  usage: fuzz_soak.py [nconfigs] [seed]"""
+(brute force, culled) and the stored Float32 grids against the oracle.  usage: fuzz_soak.py [nconfigs] [seed] [max_atoms] [max_half_dim]"""
 import os, sys, time
 here = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [os.path.join(here, '..', '..', 'crystalenergygrids.jl_amd'), os.path.join(here, '..', '..'), os.path.join(here, '..')]
@@ -13,6 +13,8 @@ from util import compare_raw, grid_points, random_atoms, synthetic_probes
 
 n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+max_atoms = int(sys.argv[3]) if len(sys.argv) > 3 else 260
+max_half_dim = int(sys.argv[4]) if len(sys.argv) > 4 else 9
 rng = np.random.default_rng(seed)
 done = fails = 0
 stats = {"ortho": 0, "stale": 0, "plain": 0, "generic": 0, "onatom": 0}
@@ -29,7 +31,7 @@ while done < n_cfg:
     cutoff = float(rng.choice([8.0, 9.5, 11.0, 12.0]))
     if perpendicular_lengths(mat).min() < 2 * cutoff:
         continue
-    n = int(rng.integers(1, 260))
+    n = int(rng.integers(1, max_atoms))
     pos = random_atoms(mat, n, rng, min_sep=float(rng.uniform(0.9, 2.0)))
     generic = rng.random() < 0.2
     hs = float(rng.choice([1.5, 1.5, 2.6]))
@@ -37,7 +39,7 @@ while done < n_cfg:
     ortho, safemin2 = pv.periodic_setup()
     stats["ortho" if ortho else ("stale" if safemin2 < cutoff ** 2 else "plain")] += 1
     stats["generic"] += int(generic)
-    dims = tuple(int(x) for x in 2 * rng.integers(1, 9, 3) + 1)
+    dims = tuple(int(x) for x in 2 * rng.integers(0, max_half_dim, 3) + 1)
     cset = W.grid_setup_with_dims(mat, dims)
     alpha = float(rng.uniform(0.18, 0.33))
     what = f"cfg{done} seed{seed}: L {np.round(lengths, 3)} A {np.round(angles, 2)} cutoff {cutoff} n {n} dims {dims} alpha {alpha:.4f} generic {generic} hs {hs}"
