@@ -41,6 +41,19 @@ PROTOTYPES = {
         C.c_int32, C.c_double, C.c_double, C.c_double,
         c_int32_p, c_double_p, c_double_p, c_double_p,
         C.c_double, C.c_double, c_float_p, C.c_int32]),
+    "ceg_grid_vdw_file": (C.c_int, [
+        c_double_p, c_int64_p, C.c_int64, c_double_p, c_double_p,
+        C.c_int32, C.c_double, C.c_double,
+        C.c_void_p, c_int32_p, C.c_int32,
+        c_int32_p, c_double_p, c_double_p, c_double_p,
+        C.c_double, C.c_double, c_float_p, C.c_int32,
+        C.c_char_p, C.c_char_p, C.c_int64, C.c_char_p, C.c_int64]),
+    "ceg_grid_coulomb_file": (C.c_int, [
+        c_double_p, c_double_p, C.c_int64, c_double_p, c_double_p,
+        C.c_int32, C.c_double, C.c_double, C.c_double,
+        c_int32_p, c_double_p, c_double_p, c_double_p,
+        C.c_double, C.c_double, c_float_p, C.c_int32,
+        C.c_char_p, C.c_char_p, C.c_int64, C.c_char_p, C.c_int64]),
     "ceg_release_cached_buffers": (C.c_int, []),
     "ceg_plan_create": (C.c_int, [
         C.POINTER(C.c_void_p), C.c_int32,

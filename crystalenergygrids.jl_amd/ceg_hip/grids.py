@@ -88,8 +88,20 @@ def _matT(m: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(np.asarray(m, dtype=np.float64).T.reshape(9))
 
 
-def build_vdw_array(probe: ProbeSystem, cset: GridCoordinatesSetup, ngpus: int = 1) -> np.ndarray:
-    """The loop nest of grids.jl:144-150 on the GPU (``ceg_grid_vdw``)."""
+def _file_frame(cset: GridCoordinatesSetup, num_unitcell, ewald_precision: Optional[float]):
+    """(header, trailer) bytes of a .grid file: what _create_grid_common (grids.jl:108-116) [+ the Ewald
+    precision, :180] writes before the payload and the cell matrix written after it (:154, :182)."""
+    import io
+    buf = io.BytesIO()
+    _create_grid_common(buf, cset, num_unitcell)
+    if ewald_precision is not None:
+        buf.write(struct.pack("<d", float(ewald_precision)))
+    return buf.getvalue(), np.asarray(cset.cell.mat, dtype="<f8").T.tobytes()
+
+
+def build_vdw_array(probe: ProbeSystem, cset: GridCoordinatesSetup, ngpus: int = 1, file=None, num_unitcell=None) -> np.ndarray:
+    """The loop nest of grids.jl:144-150 on the GPU (``ceg_grid_vdw``).  With ``file`` the .grid file is
+    written by the library while the grid is being built (``ceg_grid_vdw_file``)."""
     lib = _abi.load_library()
     ff = probe.forcefield
     ff.check_vdw_grid(probe.probe, np.unique(probe.atomkinds))
@@ -102,17 +114,23 @@ def build_vdw_array(probe: ProbeSystem, cset: GridCoordinatesSetup, ngpus: int =
     pos = np.ascontiguousarray(probe.positions, dtype=np.float64)
     kinds = np.ascontiguousarray(probe.atomkinds, dtype=np.int64)
     mat, invmat = _matT(probe.mat), _matT(probe.invmat)
-    rc = lib.ceg_grid_vdw(_abi.dptr(pos), _abi.i64ptr(kinds), len(kinds), _abi.dptr(mat), _abi.dptr(invmat),
-                          int(ortho), safemin2, probe.cutoff2,
-                          rules.ctypes.data, _abi.i32ptr(offsets), ff.nkinds,
-                          _abi.i32ptr(dims), _abi.dptr(size), _abi.dptr(shift), _abi.dptr(delta),
-                          lam, thr, _abi.fptr(grid), ngpus)
+    args = (_abi.dptr(pos), _abi.i64ptr(kinds), len(kinds), _abi.dptr(mat), _abi.dptr(invmat),
+            int(ortho), safemin2, probe.cutoff2,
+            rules.ctypes.data, _abi.i32ptr(offsets), ff.nkinds,
+            _abi.i32ptr(dims), _abi.dptr(size), _abi.dptr(shift), _abi.dptr(delta),
+            lam, thr, _abi.fptr(grid), ngpus)
+    if file is None:
+        rc = lib.ceg_grid_vdw(*args)
+    else:
+        header, trailer = _file_frame(cset, num_unitcell, None)
+        rc = lib.ceg_grid_vdw_file(*args, os.fsencode(str(file)), header, len(header), trailer, len(trailer))
     _abi.check(lib, rc)
     return grid
 
 
-def build_coulomb_array(probe: ProbeSystem, alpha: float, cset: GridCoordinatesSetup, ngpus: int = 1) -> np.ndarray:
-    """The loop nest of grids.jl:171-177 on the GPU (``ceg_grid_coulomb``)."""
+def build_coulomb_array(probe: ProbeSystem, alpha: float, cset: GridCoordinatesSetup, ngpus: int = 1, file=None,
+                        num_unitcell=None, ewald_precision: float = 1e-6) -> np.ndarray:
+    """The loop nest of grids.jl:171-177 on the GPU (``ceg_grid_coulomb``; with ``file``: ``ceg_grid_coulomb_file``)."""
     lib = _abi.load_library()
     ortho, safemin2 = probe.periodic_setup()
     lam, thr = coulomb_scaling()
@@ -122,10 +140,15 @@ def build_coulomb_array(probe: ProbeSystem, alpha: float, cset: GridCoordinatesS
     pos = np.ascontiguousarray(probe.positions, dtype=np.float64)
     q = np.ascontiguousarray(probe.charges, dtype=np.float64)
     mat, invmat = _matT(probe.mat), _matT(probe.invmat)
-    rc = lib.ceg_grid_coulomb(_abi.dptr(pos), _abi.dptr(q), len(q), _abi.dptr(mat), _abi.dptr(invmat),
-                              int(ortho), safemin2, probe.cutoff2, alpha,
-                              _abi.i32ptr(dims), _abi.dptr(size), _abi.dptr(shift), _abi.dptr(delta),
-                              lam, thr, _abi.fptr(grid), ngpus)
+    args = (_abi.dptr(pos), _abi.dptr(q), len(q), _abi.dptr(mat), _abi.dptr(invmat),
+            int(ortho), safemin2, probe.cutoff2, alpha,
+            _abi.i32ptr(dims), _abi.dptr(size), _abi.dptr(shift), _abi.dptr(delta),
+            lam, thr, _abi.fptr(grid), ngpus)
+    if file is None:
+        rc = lib.ceg_grid_coulomb(*args)
+    else:
+        header, trailer = _file_frame(cset, num_unitcell, ewald_precision)
+        rc = lib.ceg_grid_coulomb_file(*args, os.fsencode(str(file)), header, len(header), trailer, len(trailer))
     _abi.check(lib, rc)
     return grid
 
@@ -147,9 +170,8 @@ def create_grid_vdw(file, framework, forcefield: ForceField, spacing: float, ato
     """grids.jl:137-157"""
     cset, num_unitcell = _setup_grid_common(framework, spacing, forcefield.cutoff)
     probe_vdw = ProbeSystem.build(framework, forcefield, atom)
-    grid = build_vdw_array(probe_vdw, cset, ngpus)
-    write_grid_file(file, cset, num_unitcell, grid)
-    return grid
+    # header, payload (chunk by chunk while the build is running) and trailer are written by the library
+    return build_vdw_array(probe_vdw, cset, ngpus, file=file, num_unitcell=num_unitcell)
 
 
 def create_grid_coulomb(file, framework, forcefield: ForceField, spacing: float,
@@ -158,9 +180,8 @@ def create_grid_coulomb(file, framework, forcefield: ForceField, spacing: float,
     cset, num_unitcell = _setup_grid_common(framework, spacing, 12.0)
     ewald = _ewald if isinstance(_ewald, EwaldFramework) else initialize_ewald(framework, num_unitcell)
     probe_coulomb = ProbeSystem.build(framework, forcefield)
-    grid = build_coulomb_array(probe_coulomb, ewald.alpha, cset, ngpus)
-    write_grid_file(file, cset, num_unitcell, grid, ewald.precision)
-    return grid
+    return build_coulomb_array(probe_coulomb, ewald.alpha, cset, ngpus, file=file, num_unitcell=num_unitcell,
+                               ewald_precision=ewald.precision)
 
 
 def parse_grid(file, iscoulomb: bool, mat=None) -> EnergyGrid:

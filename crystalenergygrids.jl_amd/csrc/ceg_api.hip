@@ -8,6 +8,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <fcntl.h>
+#include <unistd.h>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -860,26 +862,42 @@ void pinned_release(void* ptr)
 
 // copy `nseg` segments in parallel; first touch of a fresh destination is page-fault bound, and the
 // faults of different threads proceed in parallel
-struct Segment { float* dst; const float* src; size_t n; };
-void parallel_copy(const std::vector<Segment>& segs, int nthreads)
+struct Segment { float* dst; const float* src; size_t n; int64_t file_offset; };
+// fd >= 0: every piece is also written to the file at its byte offset (pwrite is thread-safe); dst may be null.
+// Returns false if a write failed.
+bool parallel_copy(const std::vector<Segment>& segs, int nthreads, int fd = -1)
 {
     // cut every segment into pieces of <= 1 MiB so that all threads have work
     std::vector<Segment> pieces;
     const size_t piece = 256 * 1024;
     for (const auto& sg : segs)
-        for (size_t o = 0; o < sg.n; o += piece) pieces.push_back({sg.dst + o, sg.src + o, std::min(piece, sg.n - o)});
+        for (size_t o = 0; o < sg.n; o += piece)
+            pieces.push_back({sg.dst ? sg.dst + o : nullptr, sg.src + o, std::min(piece, sg.n - o), sg.file_offset + (int64_t)(o * sizeof(float))});
     std::atomic<size_t> next{0};
+    std::atomic<bool> ok{true};
     auto work = [&]() {
         for (;;) {
             const size_t t = next.fetch_add(1);
             if (t >= pieces.size()) return;
-            std::memcpy(pieces[t].dst, pieces[t].src, pieces[t].n * sizeof(float));
+            const Segment& pc = pieces[t];
+            if (pc.dst) std::memcpy(pc.dst, pc.src, pc.n * sizeof(float));
+            if (fd >= 0) {
+                const char* ptr = reinterpret_cast<const char*>(pc.src);
+                size_t left = pc.n * sizeof(float);
+                int64_t off = pc.file_offset;
+                while (left > 0) {
+                    const ssize_t w = pwrite(fd, ptr, left, (off_t)off);
+                    if (w <= 0) { ok.store(false); break; }
+                    ptr += w; left -= (size_t)w; off += w;
+                }
+            }
         }
     };
     std::vector<std::thread> th;
     for (int t = 1; t < nthreads; ++t) th.emplace_back(work);
     work();
     for (auto& x : th) x.join();
+    return ok.load();
 }
 
 // One device's share of a one-shot build: x-planes [b, e) of the grid, computed in chunks of `cx`
@@ -889,7 +907,8 @@ int device_pipeline(int mode, int d, int b, int e, int nx, int64_t plane, const 
                     const double* charge, int64_t natoms, const double* mat, const double* invmat, int32_t ortho,
                     double safemin2, double cutoff2, const ceg_rule_t* rules, const int32_t* rule_offset, int32_t nkinds,
                     double alpha, const int32_t* dims, const double* size, const double* shift, const double* delta,
-                    double lambda, double threshold, float* grid, int copy_threads, std::string* err)
+                    double lambda, double threshold, float* grid, int copy_threads, std::string* err, int fd = -1,
+                    int64_t payload_offset = 0)
 {
     auto bad = [&](int code, const char* what) {
         *err = std::string(what) + " (device " + std::to_string(d) + "): " + hipGetErrorString(hipGetLastError());
@@ -956,8 +975,11 @@ int device_pipeline(int mode, int d, int b, int e, int nx, int64_t plane, const 
                 const size_t cpts = (size_t)(ce - cb) * plane;
                 const float* slot = h_ring + (size_t)(j % R) * slot_floats;
                 std::vector<Segment> segs;
-                for (int c = 0; c < 8; ++c) segs.push_back({grid + (size_t)c * npts + (size_t)cb * plane, slot + (size_t)c * cpts, cpts});
-                parallel_copy(segs, copy_threads);
+                for (int c = 0; c < 8; ++c) {
+                    const size_t at = (size_t)c * npts + (size_t)cb * plane;           // float offset inside the payload
+                    segs.push_back({grid ? grid + at : nullptr, slot + (size_t)c * cpts, cpts, payload_offset + (int64_t)(at * sizeof(float))});
+                }
+                if (!parallel_copy(segs, copy_threads, fd)) drain_rc.store(CEG_ERR_INVALID);
                 drained.store(j + 1);
             }
         });
@@ -979,6 +1001,7 @@ int device_pipeline(int mode, int d, int b, int e, int nx, int64_t plane, const 
         stamp("copies enqueued");
         drain.join();
         stamp("drained into caller array");
+        if (!rc && drain_rc.load() == CEG_ERR_INVALID) { *err = "writing the grid file failed"; rc = CEG_ERR_INVALID; }
         if (!rc && drain_rc.load() != CEG_OK) rc = bad(CEG_ERR_HIP, "kernel execution or D2H copy failed");
     }
     (void)hipStreamSynchronize(s_comp);
@@ -999,9 +1022,12 @@ int oneshot(int mode, const double* pos, const int64_t* atomkind, const double* 
             const double* mat, const double* invmat, int32_t ortho, double safemin2, double cutoff2,
             const ceg_rule_t* rules, const int32_t* rule_offset, int32_t nkinds, double alpha,
             const int32_t* dims, const double* size, const double* shift, const double* delta,
-            double lambda, double threshold, float* grid, int32_t ngpus)
+            double lambda, double threshold, float* grid, int32_t ngpus, const char* path = nullptr,
+            const void* header = nullptr, int64_t header_bytes = 0, const void* trailer = nullptr, int64_t trailer_bytes = 0)
 {
-    if (!grid) return fail(CEG_ERR_INVALID, "grid is NULL");
+    if (!grid && !path) return fail(CEG_ERR_INVALID, "grid is NULL");
+    if (path && (header_bytes < 0 || trailer_bytes < 0 || (header_bytes > 0 && !header) || (trailer_bytes > 0 && !trailer)))
+        return fail(CEG_ERR_INVALID, "bad header / trailer");
     if (int rc = check_common(pos, natoms, mat, invmat, dims, size, shift, delta)) return rc;
     const int ndev = ceg_device_count();
     if (ndev <= 0) return fail(CEG_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
@@ -1022,19 +1048,36 @@ int oneshot(int mode, const double* pos, const int64_t* atomkind, const double* 
     if (hw > 0) copy_threads = std::min<int>(copy_threads, (int)hw);
     copy_threads = std::max(1, copy_threads / ngpus);
 
+    // optional file: header, payload streamed chunk by chunk at its offsets while the build runs, trailer
+    int fd = -1;
+    const int64_t payload_bytes = (int64_t)sizeof(float) * 8 * plane * nx;
+    if (path) {
+        fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (fd < 0) return fail(CEG_ERR_INVALID, "cannot open %s for writing", path);
+        bool ok = ftruncate(fd, (off_t)(header_bytes + payload_bytes + trailer_bytes)) == 0;
+        ok = ok && (header_bytes == 0 || pwrite(fd, header, (size_t)header_bytes, 0) == (ssize_t)header_bytes);
+        ok = ok && (trailer_bytes == 0 ||
+                    pwrite(fd, trailer, (size_t)trailer_bytes, (off_t)(header_bytes + payload_bytes)) == (ssize_t)trailer_bytes);
+        if (!ok) {
+            close(fd);
+            return fail(CEG_ERR_INVALID, "cannot write the header of %s", path);
+        }
+    }
     std::vector<int> rcs(ngpus, CEG_OK);
     std::vector<std::string> errs(ngpus);
     auto run = [&](int d) {
         int b, e;
         slab(nx, ngpus, d, &b, &e);
         rcs[d] = device_pipeline(mode, d % ndev, b, e, nx, plane, pos, atomkind, charge, natoms, mat, invmat, ortho, safemin2, cutoff2, rules,
-                                 rule_offset, nkinds, alpha, dims, size, shift, delta, lambda, threshold, grid, copy_threads, &errs[d]);
+                                 rule_offset, nkinds, alpha, dims, size, shift, delta, lambda, threshold, grid, copy_threads, &errs[d], fd,
+                                 header_bytes);
     };
     std::vector<std::thread> workers;
     for (int d = 1; d < ngpus; ++d) workers.emplace_back(run, d);      // one host thread per extra device
     run(0);
     for (auto& w : workers) w.join();
     if (prev >= 0) (void)hipSetDevice(prev);
+    if (fd >= 0 && close(fd) != 0 && !rcs[0]) { rcs[0] = CEG_ERR_INVALID; errs[0] = "closing the grid file failed"; }
     for (int d = 0; d < ngpus; ++d)
         if (rcs[d]) return fail(rcs[d], "%s", errs[d].c_str());
     return CEG_OK;
@@ -1081,6 +1124,30 @@ extern "C" int ceg_grid_vdw(const double* pos, const int64_t* atomkind, int64_t 
     if (!rules || !rule_offset || !atomkind || nkinds <= 0) return fail(CEG_ERR_INVALID, "rule table / atomkind missing");
     return oneshot(MODE_VDW, pos, atomkind, nullptr, natoms, mat, invmat, ortho, safemin2, cutoff2, rules,
                    rule_offset, nkinds, 0.0, dims, size, shift, delta, lambda, threshold, grid, ngpus);
+}
+
+extern "C" int ceg_grid_vdw_file(const double* pos, const int64_t* atomkind, int64_t natoms, const double mat[9], const double invmat[9],
+                                 int32_t ortho, double safemin2, double cutoff2, const ceg_rule_t* rules, const int32_t* rule_offset,
+                                 int32_t nkinds, const int32_t dims[3], const double size[3], const double shift[3],
+                                 const double delta[3], double lambda, double threshold, float* grid, int32_t ngpus,
+                                 const char* path, const void* header, int64_t header_bytes, const void* trailer, int64_t trailer_bytes)
+{
+    if (!rules || !rule_offset || !atomkind || nkinds <= 0) return fail(CEG_ERR_INVALID, "rule table / atomkind missing");
+    if (!path) return fail(CEG_ERR_INVALID, "path is NULL");
+    return oneshot(MODE_VDW, pos, atomkind, nullptr, natoms, mat, invmat, ortho, safemin2, cutoff2, rules, rule_offset, nkinds, 0.0, dims,
+                   size, shift, delta, lambda, threshold, grid, ngpus, path, header, header_bytes, trailer, trailer_bytes);
+}
+
+extern "C" int ceg_grid_coulomb_file(const double* pos, const double* charge, int64_t natoms, const double mat[9], const double invmat[9],
+                                     int32_t ortho, double safemin2, double cutoff2, double alpha, const int32_t dims[3],
+                                     const double size[3], const double shift[3], const double delta[3], double lambda, double threshold,
+                                     float* grid, int32_t ngpus, const char* path, const void* header, int64_t header_bytes,
+                                     const void* trailer, int64_t trailer_bytes)
+{
+    if (!charge) return fail(CEG_ERR_INVALID, "charge is NULL");
+    if (!path) return fail(CEG_ERR_INVALID, "path is NULL");
+    return oneshot(MODE_COULOMB, pos, nullptr, charge, natoms, mat, invmat, ortho, safemin2, cutoff2, nullptr, nullptr, 0, alpha, dims, size,
+                   shift, delta, lambda, threshold, grid, ngpus, path, header, header_bytes, trailer, trailer_bytes);
 }
 
 extern "C" int ceg_grid_coulomb(const double* pos, const double* charge, int64_t natoms,

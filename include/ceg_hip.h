@@ -132,6 +132,32 @@ CEG_API int ceg_grid_coulomb(const double* pos, const double* charge, int64_t na
                      double lambda, double threshold,
                      float* grid, int32_t ngpus);
 
+/*
+ * The same two builds with the .grid file written on the way ("device -> file"):
+ * `header` (the bytes of _create_grid_common, src/grids.jl:108-116, + the Ewald precision for a Coulomb
+ * grid, :180) is written first, every finished chunk of the payload is written at its offset while later
+ * chunks are still being computed, `trailer` (the cell matrix, :154/:182) goes after the payload.  The
+ * library does not interpret header or trailer -- the host produces them with the reference's own writer.
+ * `grid` may be NULL (file only) or a host array that is filled as by ceg_grid_vdw / ceg_grid_coulomb.
+ */
+CEG_API int ceg_grid_vdw_file(const double* pos, const int64_t* atomkind, int64_t natoms,
+                 const double mat[9], const double invmat[9],
+                 int32_t ortho, double safemin2, double cutoff2,
+                 const ceg_rule_t* rules, const int32_t* rule_offset, int32_t nkinds,
+                 const int32_t dims[3], const double size[3], const double shift[3],
+                 const double delta[3], double lambda, double threshold,
+                 float* grid, int32_t ngpus,
+                 const char* path, const void* header, int64_t header_bytes,
+                 const void* trailer, int64_t trailer_bytes);
+CEG_API int ceg_grid_coulomb_file(const double* pos, const double* charge, int64_t natoms,
+                     const double mat[9], const double invmat[9],
+                     int32_t ortho, double safemin2, double cutoff2, double alpha,
+                     const int32_t dims[3], const double size[3], const double shift[3],
+                     const double delta[3], double lambda, double threshold,
+                     float* grid, int32_t ngpus,
+                     const char* path, const void* header, int64_t header_bytes,
+                     const void* trailer, int64_t trailer_bytes);
+
 /* The one-shot entry points keep, per process, one idle device output slab per GPU and one pinned
  * staging ring (page-locking / hipMalloc of 0.5 GB cost as much as the build itself).  This frees
  * whatever is idle; safe to call at any time, never required. */

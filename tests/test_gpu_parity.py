@@ -921,3 +921,41 @@ def test_bench_two_and_three_ranks_on_one_gpu(hip_lib):
         assert d["n_gpus"] == nranks and d["scaling"] == "strong" and d["exchange"]["mode"] == mode
         assert d["selfcheck"]["max_rel_err"] <= 1e-6 and d["selfcheck"]["points"] > 0
         assert d["exchange"]["bytes_gathered_per_rank"] > 0
+
+
+def test_grid_file_streamed_by_the_library(hip_lib, tmp_path, forcefield):
+    """ceg_grid_vdw_file / ceg_grid_coulomb_file (row f4, device -> file): the .grid file written chunk by
+    chunk during the build is byte-identical to the one the host writer produces from the returned array;
+    file-only mode (no host array) gives the same bytes; an unwritable path is an error, not a silent skip."""
+    import ctypes as C
+    fw = ceg.load_framework_RASPA("CHA_1.4_3b4eeb96", "BoulfelfelSholl2021")
+    for spacing in (0.45, 0.2):                         # one chunk / several chunks of the pipeline
+        g = ceg.create_grid_vdw(tmp_path / "v.grid", fw, forcefield, spacing, "Na")
+        cset, nuc = G._setup_grid_common(fw, spacing, forcefield.cutoff)
+        G.write_grid_file(tmp_path / "v_host.grid", cset, nuc, g)
+        assert (tmp_path / "v.grid").read_bytes() == (tmp_path / "v_host.grid").read_bytes()
+        ew = ceg.initialize_ewald(fw)
+        gc = ceg.create_grid_coulomb(tmp_path / "c.grid", fw, forcefield, spacing, ew)
+        G.write_grid_file(tmp_path / "c_host.grid", cset, nuc, gc, ew.precision)
+        assert (tmp_path / "c.grid").read_bytes() == (tmp_path / "c_host.grid").read_bytes()
+        eg = ceg.parse_grid(tmp_path / "c.grid", True)
+        assert eg.ewald_precision == 1e-6 and tuple(eg.csetup.dims) == tuple(cset.dims)
+    # file only: grid pointer NULL
+    w = W.fixture_workload("CHA_1.4_3b4eeb96", "Na", 0.2)
+    header, trailer = G._file_frame(w.cset, (1, 1, 1), None)
+    ff = w.probe_vdw.forcefield
+    rules, offsets = ff.rule_table(w.probe_vdw.probe)
+    ortho, safemin2 = w.probe_vdw.periodic_setup()
+    lam, thr = G.vdw_scaling()
+    dims, size, shift, delta = G._grid_args(w.cset)
+    pos = np.ascontiguousarray(w.probe_vdw.positions, dtype=np.float64)
+    kinds = np.ascontiguousarray(w.probe_vdw.atomkinds, dtype=np.int64)
+    mat, invmat = G._matT(w.probe_vdw.mat), G._matT(w.probe_vdw.invmat)
+    args = (_abi.dptr(pos), _abi.i64ptr(kinds), len(kinds), _abi.dptr(mat), _abi.dptr(invmat), int(ortho), safemin2,
+            w.probe_vdw.cutoff2, rules.ctypes.data, _abi.i32ptr(offsets), ff.nkinds, _abi.i32ptr(dims), _abi.dptr(size),
+            _abi.dptr(shift), _abi.dptr(delta), lam, thr, None, 1)
+    path = tmp_path / "only.grid"
+    _abi.check(hip_lib, hip_lib.ceg_grid_vdw_file(*args, os.fsencode(str(path)), header, len(header), trailer, len(trailer)))
+    assert path.read_bytes() == (tmp_path / "v.grid").read_bytes()
+    rc = hip_lib.ceg_grid_vdw_file(*args, os.fsencode(str(tmp_path / "no_such_dir" / "x.grid")), header, len(header), trailer, len(trailer))
+    assert rc == -1 and b"cannot open" in hip_lib.ceg_last_error()
