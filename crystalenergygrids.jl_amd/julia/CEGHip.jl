@@ -266,4 +266,32 @@ function block_spheres(csetup::GridCoordinatesSetup, centers::Vector{SVector{3,F
     CEG.BlockFile(csetup, _to_bitarray(mask, a, b, c))
 end
 
+# ------------------------------------------------------------------ build + file in one call (row f4)
+"create_grid_vdw with the .grid file written by the library while the grid is built (ceg_grid_vdw_file)"
+function create_grid_vdw_streamed(file, framework::AbstractSystem{3}, forcefield::ForceField, spacing::TÅ, atom::Symbol)
+    cset, num_unitcell = CEG._setup_grid_common(framework, spacing, forcefield.cutoff)
+    grid = Array{Cfloat,4}(undef, cset.dims[3]+1, cset.dims[2]+1, cset.dims[1]+1, 8)
+    probe = ProbeSystem(framework, forcefield, atom)
+    ff = probe.forcefield
+    check_rules(ff, probe.probe, probe.atomkinds)
+    rules, offsets = rule_table(ff, probe.probe)
+    _, ortho, safemin = CEG.prepare_periodic_distance_computations(probe.mat)
+    λ = ustrip(u"K^-1", inv(GRID_TO_KELVIN)); thr = inv(λ)*1e7            # grids.jl:141-143,148
+    io = IOBuffer(); CEG._create_grid_common(io, cset, num_unitcell); header = take!(io)   # grids.jl:108-116
+    trailer = reinterpret(UInt8, Vector{Float64}(vec(NoUnits.(cset.cell.mat ./ u"Å")))) |> collect   # :154
+    dims, size, shift, Δ = _geometry(cset)
+    pos = _flatpos(probe); kinds = Int64.(probe.atomkinds)
+    mat = Vector{Float64}(vec(probe.mat)); invmat = Vector{Float64}(vec(probe.invmat))
+    GC.@preserve grid pos kinds mat invmat rules offsets dims size shift Δ header trailer begin
+        _check(ccall((:ceg_grid_vdw_file, LIB[]), Cint,
+            (Ptr{Float64}, Ptr{Int64}, Int64, Ptr{Float64}, Ptr{Float64}, Int32, Float64, Float64,
+             Ptr{CegRule}, Ptr{Int32}, Int32, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+             Float64, Float64, Ptr{Cfloat}, Int32, Cstring, Ptr{UInt8}, Int64, Ptr{UInt8}, Int64),
+            pos, kinds, length(kinds), mat, invmat, ortho, safemin^2, NoUnits(ff.cutoff^2/u"Å^2"),
+            rules, offsets, length(offsets)-1, dims, size, shift, Δ, λ, thr, grid, ngpus(),
+            String(file), header, length(header), trailer, length(trailer)))
+    end
+    grid
+end
+
 end # module
