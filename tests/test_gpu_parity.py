@@ -807,8 +807,12 @@ def test_bench_line_and_exchange_rehearsal(hip_lib):
     import sys
     root = Path(__file__).resolve().parent.parent
     for extra in ([], ["--force-exchange"]):
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
         r = subprocess.run([sys.executable, str(root / "bench.py"), "--n", "63", "--steps", "2", "--warmup", "1", "--cpu-rows", "1"] + extra,
-                           capture_output=True, text=True, timeout=600, env={**os.environ, "MASTER_PORT": "29571"})
+                           capture_output=True, text=True, timeout=600, env={**os.environ, "MASTER_PORT": str(port)})
         assert r.returncode == 0, r.stderr[-2000:]
         lines = [l for l in r.stdout.splitlines() if l.strip()]
         assert len(lines) == 1, r.stdout
