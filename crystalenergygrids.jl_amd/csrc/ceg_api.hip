@@ -1049,18 +1049,26 @@ int oneshot(int mode, const double* pos, const int64_t* atomkind, const double* 
     copy_threads = std::max(1, copy_threads / ngpus);
 
     // optional file: header, payload streamed chunk by chunk at its offsets while the build runs, trailer
+    // The reference opens the file only once the whole grid exists (grids.jl:151,178), and its cache looks no
+    // further than isfile(path) (raspa.jl:426): a file must never be visible at `path` unless it is complete.
+    // Everything goes into `<path>.tmp.<pid>.<n>`, renamed onto `path` after every device pipeline returned
+    // CEG_OK and close() succeeded; any failure unlinks the temporary.
     int fd = -1;
+    std::string tmp_path;
     const int64_t payload_bytes = (int64_t)sizeof(float) * 8 * plane * nx;
     if (path) {
-        fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
-        if (fd < 0) return fail(CEG_ERR_INVALID, "cannot open %s for writing", path);
+        static std::atomic<unsigned> tmp_serial{0};
+        tmp_path = std::string(path) + ".tmp." + std::to_string((long long)getpid()) + "." + std::to_string(tmp_serial.fetch_add(1));
+        fd = open(tmp_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (fd < 0) return fail(CEG_ERR_INVALID, "cannot open %s for writing", tmp_path.c_str());
         bool ok = ftruncate(fd, (off_t)(header_bytes + payload_bytes + trailer_bytes)) == 0;
         ok = ok && (header_bytes == 0 || pwrite(fd, header, (size_t)header_bytes, 0) == (ssize_t)header_bytes);
         ok = ok && (trailer_bytes == 0 ||
                     pwrite(fd, trailer, (size_t)trailer_bytes, (off_t)(header_bytes + payload_bytes)) == (ssize_t)trailer_bytes);
         if (!ok) {
             close(fd);
-            return fail(CEG_ERR_INVALID, "cannot write the header of %s", path);
+            (void)unlink(tmp_path.c_str());
+            return fail(CEG_ERR_INVALID, "cannot write the header of %s", tmp_path.c_str());
         }
     }
     std::vector<int> rcs(ngpus, CEG_OK);
@@ -1079,7 +1087,14 @@ int oneshot(int mode, const double* pos, const int64_t* atomkind, const double* 
     if (prev >= 0) (void)hipSetDevice(prev);
     if (fd >= 0 && close(fd) != 0 && !rcs[0]) { rcs[0] = CEG_ERR_INVALID; errs[0] = "closing the grid file failed"; }
     for (int d = 0; d < ngpus; ++d)
-        if (rcs[d]) return fail(rcs[d], "%s", errs[d].c_str());
+        if (rcs[d]) {
+            if (path) (void)unlink(tmp_path.c_str());
+            return fail(rcs[d], "%s", errs[d].c_str());
+        }
+    if (path && rename(tmp_path.c_str(), path) != 0) {
+        (void)unlink(tmp_path.c_str());
+        return fail(CEG_ERR_INVALID, "cannot rename %s onto %s", tmp_path.c_str(), path);
+    }
     return CEG_OK;
 }
 

@@ -11,7 +11,9 @@
 # `CrystalEnergySetup` and `energy_point` keep working without modification.
 #
 # NOT EXECUTED IN THIS REPOSITORY'S CI: the build image has no Julia toolchain.  The Python
-# package `ceg_hip` is the tested twin of this file (same argument marshalling, same C calls).
+# package `ceg_hip` is the tested twin of this file (same argument marshalling, same C calls), and
+# tests/test_boundary_static.py parses every `ccall` below and checks symbol, arity and C types
+# against include/ceg_hip.h and ceg_hip/_abi.py.
 #
 # Usage (after `using CrystalEnergyGrids`):
 #     include("CEGHip.jl"); CEGHip.install!()        # overrides the two methods
@@ -209,7 +211,7 @@ function recip_handle(ef::EwaldFramework; device=0)
     end
     sf = ef.StoreRigidChargeFramework
     re, im_ = Vector{Float64}(real.(sf)), Vector{Float64}(imag.(sf))
-    ks = Int32[ef.kspace.ks...]; invmat = Vector{Float64}(vec(ef.invmat))
+    ks = Int32[ef.kspace.ks...]; invmat = Vector{Float64}(vec(NoUnits.(ef.invmat .* u"Å")))    # invmat carries Å^-1 (ewald.jl:44)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve ijk re im_ ks invmat _check(ccall((:ceg_recip_create, LIB[]), Cint,
         (Ref{Ptr{Cvoid}}, Int32, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Int32}, Ptr{Float64}),
@@ -276,7 +278,7 @@ function create_grid_vdw_streamed(file, framework::AbstractSystem{3}, forcefield
     check_rules(ff, probe.probe, probe.atomkinds)
     rules, offsets = rule_table(ff, probe.probe)
     _, ortho, safemin = CEG.prepare_periodic_distance_computations(probe.mat)
-    λ = ustrip(u"K^-1", inv(GRID_TO_KELVIN)); thr = inv(λ)*1e7            # grids.jl:141-143,148
+    λ = inv(GRID_TO_KELVIN); thr = GRID_TO_KELVIN*1e7                       # grids.jl:141-143,148 (GRID_TO_KELVIN is a plain Float64, constants.jl:20)
     io = IOBuffer(); CEG._create_grid_common(io, cset, num_unitcell); header = take!(io)   # grids.jl:108-116
     trailer = reinterpret(UInt8, Vector{Float64}(vec(NoUnits.(cset.cell.mat ./ u"Å")))) |> collect   # :154
     dims, size, shift, Δ = _geometry(cset)

@@ -256,16 +256,26 @@ def single_contribution_vdw(mc, idx, trial, nthreads=0) -> np.ndarray:
         pos.append(p)
         kinds += [k - 1 for k in ids]
         mol += [m] * len(ids)
-    pos = np.ascontiguousarray(np.concatenate(pos) if pos else np.empty((0, 3)), dtype=np.float64)
+    pos = np.concatenate(pos) if pos else np.empty((0, 3))
+    tk = [k - 1 for k in mc.ffidx[idx[0]]]
+    return single_contribution_vdw_raw(mc.mat, mc.invmat, mc.ff.cutoff ** 2, rules, offsets, mc.ff.nkinds, COULOMBIC_CONVERSION_FACTOR,
+                                       pos, kinds, mol, trial, tk, mc.flat_index(*idx), nthreads)
+
+def single_contribution_vdw_raw(mat, invmat, cutoff2, rules, offsets, nkinds, coulombic, positions, kinds, molecule, trial,
+                                trial_kinds, exclude, nthreads=0) -> np.ndarray:
+    """oracle_single_contribution_vdw on an explicit pair table (0-based kinds; the same arrays
+    ``ceg_pairs_create`` / ``ceg_pairs_set_atoms`` take): energy.jl:407-427 without a MonteCarloSetup."""
+    pos = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, 3)
     kinds = np.ascontiguousarray(kinds, dtype=np.int32)
-    mol = np.ascontiguousarray(mol, dtype=np.int32)
-    tk = np.ascontiguousarray([k - 1 for k in mc.ffidx[idx[0]]], dtype=np.int32)
+    mol = np.ascontiguousarray(molecule, dtype=np.int32)
+    tk = np.ascontiguousarray(trial_kinds, dtype=np.int32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int32)
     t = np.ascontiguousarray(trial, dtype=np.float64).reshape(-1, len(tk), 3)
     out = np.empty(len(t), dtype=np.float64)
-    lib().oracle_single_contribution_vdw(_d(_cm(mc.mat)), _d(_cm(mc.invmat)), mc.ff.cutoff ** 2, rules.ctypes.data,
-                                         offsets.ctypes.data_as(_i32p), mc.ff.nkinds, COULOMBIC_CONVERSION_FACTOR, _d(pos.reshape(-1)),
+    lib().oracle_single_contribution_vdw(_d(_cm(mat)), _d(_cm(invmat)), float(cutoff2), rules.ctypes.data,
+                                         offsets.ctypes.data_as(_i32p), int(nkinds), float(coulombic), _d(pos.reshape(-1)),
                                          kinds.ctypes.data_as(_i32p), mol.ctypes.data_as(_i32p), len(pos), _d(t.reshape(-1)),
-                                         tk.ctypes.data_as(_i32p), len(tk), len(t), mc.flat_index(*idx), _d(out), nthreads)
+                                         tk.ctypes.data_as(_i32p), len(tk), len(t), int(exclude), _d(out), nthreads)
     return out
 
 

@@ -1,0 +1,142 @@
+"""Static check of the drop-in boundary: the three descriptions of the C ABI -- the header
+`include/ceg_hip.h`, the ctypes table `ceg_hip/_abi.py` and the `ccall` stubs of the reference-side
+binding `julia/CEGHip.jl` (never executed here: no Julia in the image) -- must name the same symbols with
+the same arity and the same C types, argument by argument.  Also flags unit-stripping of the reference's
+unitless constants in the Julia text (constants.jl:20: GRID_TO_KELVIN is a plain Float64)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+from ceg_hip import _abi
+
+ROOT = Path(__file__).resolve().parent.parent
+HEADER = ROOT / "include" / "ceg_hip.h"
+JULIA = ROOT / "crystalenergygrids.jl_amd" / "julia" / "CEGHip.jl"
+
+
+def _strip_comments(text: str) -> str:
+    return re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+
+
+def _c_class(decl: str) -> str:
+    """C parameter declaration -> canonical class: 'f64*', 'i32', 'void*', 'handle**' ..."""
+    d = re.sub(r"\bconst\b", " ", decl).strip()
+    d = re.sub(r"\[\s*\d*\s*\]", "*", d)                      # double mat[9] -> double mat*
+    stars = d.count("*")
+    d = d.replace("*", " ")
+    toks = d.split()
+    if len(toks) > 1:                                          # drop the parameter name
+        toks = toks[:-1]
+    base = " ".join(toks)
+    base = {"double": "f64", "float": "f32", "int32_t": "i32", "int64_t": "i64", "int": "i32", "char": "char", "void": "void",
+            "ceg_rule_t": "rule"}.get(base, "handle" if base.startswith("ceg_") and base.endswith("_t") else base)
+    return base + "*" * stars
+
+
+def header_prototypes():
+    text = _strip_comments(HEADER.read_text())
+    out = {}
+    for m in re.finditer(r"CEG_API\s+([\w\s\*]+?)\b(ceg_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+        ret, name, args = m.group(1).strip(), m.group(2), " ".join(m.group(3).split())
+        params = [] if args in ("void", "") else [_c_class(a) for a in args.split(",")]
+        out[name] = (_c_class(ret + " x"), params)
+    return out
+
+
+_CTYPES_CLASS = {
+    C.c_int: "i32", C.c_int32: "i32", C.c_int64: "i64", C.c_double: "f64", C.c_char_p: "char*",
+    _abi.c_double_p: "f64*", _abi.c_float_p: "f32*", _abi.c_int32_p: "i32*", _abi.c_int64_p: "i64*",
+    C.POINTER(C.c_void_p): "handle**",
+}
+
+
+def _compatible(header_cls: str, other: str) -> bool:
+    """`other` may be an untyped pointer where the header has a typed one (device pointers, opaque handles, byte buffers)."""
+    if header_cls == other:
+        return True
+    if other == "void*":
+        return header_cls.endswith("*") and not header_cls.endswith("**")
+    if header_cls == "void*":                     # untyped byte buffers of the header (file header / trailer, masks)
+        return other in ("char*", "u8*")
+    return False
+
+
+def test_header_and_ctypes_table_agree():
+    hp = header_prototypes()
+    assert len(hp) >= 30
+    assert set(hp) == set(_abi.PROTOTYPES), (sorted(set(hp) ^ set(_abi.PROTOTYPES)))
+    for name, (ret, params) in hp.items():
+        restype, argtypes = _abi.PROTOTYPES[name]
+        assert _CTYPES_CLASS.get(restype, "void*") == ret, (name, ret)
+        assert len(argtypes) == len(params), (name, len(argtypes), len(params))
+        for pos, (h, a) in enumerate(zip(params, argtypes)):
+            cls = "void*" if a is C.c_void_p else _CTYPES_CLASS[a]
+            assert _compatible(h, cls), (name, pos, h, cls)
+
+
+_JULIA_CLASS = {
+    "Float64": "f64", "Int64": "i64", "Int32": "i32", "Cint": "i32", "Cstring": "char*",
+    "Ptr{Float64}": "f64*", "Ptr{Int64}": "i64*", "Ptr{Int32}": "i32*", "Ptr{Cfloat}": "f32*",
+    "Ptr{CegRule}": "rule*", "Ptr{Cvoid}": "void*", "Ref{Ptr{Cvoid}}": "handle**", "Ptr{UInt8}": "void*",
+}
+
+
+def _split_top(s: str):
+    """split on commas that are not inside (), [], {}"""
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip()); cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def julia_ccalls():
+    text = "\n".join(l.split("#")[0] if not l.lstrip().startswith("#") else "" for l in JULIA.read_text().splitlines())
+    calls = []
+    for m in re.finditer(r"ccall\(", text):
+        depth, i = 1, m.end()
+        while depth:
+            depth += {"(": 1, ")": -1}.get(text[i], 0)
+            i += 1
+        parts = _split_top(text[m.end(): i - 1])
+        sym = re.match(r"\(\s*:(\w+)\s*,\s*LIB\[\]\s*\)", parts[0])
+        assert sym, parts[0]
+        types = _split_top(parts[2].strip()[1:-1]) if parts[2].strip() != "()" else []
+        calls.append((sym.group(1), parts[1], types, parts[3:]))
+    return calls
+
+
+def test_julia_ccalls_match_the_header():
+    hp = header_prototypes()
+    calls = julia_ccalls()
+    assert len(calls) >= 11
+    for name, ret, types, args in calls:
+        assert name in hp, f"CEGHip.jl calls {name}, which include/ceg_hip.h does not declare"
+        hret, hparams = hp[name]
+        assert _JULIA_CLASS[ret] == hret, (name, ret, hret)
+        assert len(types) == len(hparams), f"{name}: {len(types)} ccall types, {len(hparams)} C parameters"
+        assert len(args) == len(types), f"{name}: {len(args)} values passed for {len(types)} ccall types"
+        for pos, (t, h) in enumerate(zip(types, hparams)):
+            assert t in _JULIA_CLASS, (name, pos, t)
+            assert _compatible(h, _JULIA_CLASS[t]), f"{name} argument {pos}: Julia {t} vs C {h}"
+    # the two methods the shim overrides and the streamed variant all reach their entry point
+    assert {"ceg_grid_vdw", "ceg_grid_coulomb", "ceg_grid_vdw_file", "ceg_last_error"} <= {c[0] for c in calls}
+
+
+def test_julia_shim_does_not_strip_units_off_unitless_constants():
+    """GRID_TO_KELVIN = NoUnits(...) (constants.jl:20) is a Float64: ustrip/uconvert of it to a dimensionful unit throws a
+    DimensionError.  COULOMBIC_CONVERSION_FACTOR does carry K*Å/e_au^2 (constants.jl:21) and must be stripped."""
+    text = JULIA.read_text()
+    for m in re.finditer(r"(ustrip|uconvert)\(([^()]*(?:\([^()]*\)[^()]*)*)\)", text):
+        assert "GRID_TO_KELVIN" not in m.group(2), m.group(0)
+    assert 'ustrip(u"K*Å/e_au^2", COULOMBIC_CONVERSION_FACTOR)/GRID_TO_KELVIN' in text      # grids.jl:169
+    # unitful fields must be made unitless before they reach a Float64 buffer (ewald.jl:42-44, coordinates.jl:15-23)
+    assert "vec(ef.invmat))" not in text and 'NoUnits(ewald.α*u"Å")' in text

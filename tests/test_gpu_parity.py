@@ -963,3 +963,42 @@ def test_grid_file_streamed_by_the_library(hip_lib, tmp_path, forcefield):
     assert path.read_bytes() == (tmp_path / "v.grid").read_bytes()
     rc = hip_lib.ceg_grid_vdw_file(*args, os.fsencode(str(tmp_path / "no_such_dir" / "x.grid")), header, len(header), trailer, len(trailer))
     assert rc == -1 and b"cannot open" in hip_lib.ceg_last_error()
+
+
+def test_grid_file_never_visible_when_the_build_fails(hip_lib, tmp_path):
+    """The cache of the reference only checks isfile(path) (raspa.jl:426) and the reference opens the file after the
+    grid is complete (grids.jl:151,178): a streamed build that fails after its file was opened must leave nothing at
+    `path` -- neither a new full-size file with a zero payload nor a truncated older one -- and no temporary behind."""
+    w = W.fixture_workload("CIT-7", "Ar", 0.5)
+    header, trailer = G._file_frame(w.cset, (1, 1, 1), None)
+    ff = w.probe_vdw.forcefield
+    rules, offsets = ff.rule_table(w.probe_vdw.probe)
+    rules = rules.copy()
+    lam, thr = G.vdw_scaling()
+    dims, size, shift, delta = G._grid_args(w.cset)
+    pos = np.ascontiguousarray(w.probe_vdw.positions, dtype=np.float64)
+    kinds = np.ascontiguousarray(w.probe_vdw.atomkinds, dtype=np.int64)
+    mat, invmat = G._matT(w.probe_vdw.mat), G._matT(w.probe_vdw.invmat)
+    ortho, safemin2 = w.probe_vdw.periodic_setup()
+
+    def call(rt, path):
+        return hip_lib.ceg_grid_vdw_file(_abi.dptr(pos), _abi.i64ptr(kinds), len(kinds), _abi.dptr(mat), _abi.dptr(invmat), int(ortho),
+                                         safemin2, w.probe_vdw.cutoff2, rt.ctypes.data, _abi.i32ptr(offsets), ff.nkinds, _abi.i32ptr(dims),
+                                         _abi.dptr(size), _abi.dptr(shift), _abi.dptr(delta), lam, thr, None, 1, os.fsencode(str(path)),
+                                         header, len(header), trailer, len(trailer))
+    good = tmp_path / "good.grid"
+    assert call(rules, good) == 0 and good.stat().st_size > len(header) + len(trailer)
+    reference_bytes = good.read_bytes()
+    # a rule the kernels refuse (Monomial has no VdW grid form, interactions.jl:462-465) on a kind that is present:
+    # detected by the plan, i.e. after oneshot() has created its output file
+    present = int(kinds[0]) - 1
+    bad = rules.copy()
+    assert offsets[present + 1] > offsets[present]
+    bad[offsets[present]]["kind"] = 5
+    fresh = tmp_path / "fresh.grid"
+    assert call(bad, fresh) != 0
+    assert not fresh.exists()
+    # an older complete file at the same path survives a failed rebuild untouched
+    assert call(bad, good) != 0
+    assert good.read_bytes() == reference_bytes
+    assert sorted(p.name for p in tmp_path.iterdir()) == ["good.grid"]
