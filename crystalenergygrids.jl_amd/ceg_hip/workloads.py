@@ -157,3 +157,55 @@ def synthetic_workload(natoms: int, n: int = 127, edge: float = 40.0, seed: int 
     alpha, _ = ewald_alpha()
     cset = grid_setup_with_dims(mat, (n, n, n))
     return Workload(f"synthetic {edge:g} A cube, {natoms} random LJ atoms (+1/-1), {n + 1}^3 grid", fw, ff, cset, pv, pc, alpha)
+
+
+def count_pair_work(w: Workload, planes: int = 8, stride: int = 4) -> dict:
+    """Counted minimum work of a grid build (the flop count behind bench.py's ``roofline``): on a sample of the
+    grid points -- ``planes`` x-planes spread over the grid, every ``stride``-th point along y and z -- the exact
+    number of framework-atom images inside the cutoff (what compute_derivatives_* accumulates, probes.jl:83,107)
+    and of those whose kind has a VdW rule for the probe, per rule class.  Host side, k-d tree over the lattice
+    images; because every perpendicular width of a ProbeSystem is >= 2 cutoffs (probes.jl:24) an image inside the
+    cutoff is the one the min-image routine selects."""
+    from scipy.spatial import cKDTree
+    p = w.probe_vdw if w.probe_vdw is not None else w.probe_coulomb
+    pos = np.asarray(p.positions, dtype=np.float64)
+    mat = np.asarray(p.mat, dtype=np.float64)
+    cutoff = float(np.sqrt(p.cutoff2))
+    nx, ny, nz = w.cset.npoints
+    ii = np.unique(np.linspace(0, nx - 1, planes).round().astype(int))
+    jj, kk = np.arange(0, ny, stride), np.arange(0, nz, stride)
+    I, J, K = np.meshgrid(ii, jj, kk, indexing="ij")
+    pts = np.stack([I * w.cset.size[0] / w.cset.dims[0] + w.cset.shift[0],
+                    J * w.cset.size[1] / w.cset.dims[1] + w.cset.shift[1],
+                    K * w.cset.size[2] / w.cset.dims[2] + w.cset.shift[2]], axis=-1).reshape(-1, 3)
+    lo, hi = pts.min(axis=0) - cutoff, pts.max(axis=0) + cutoff
+    shifts = np.array([[a, b, c] for a in (-1, 0, 1) for b in (-1, 0, 1) for c in (-1, 0, 1)], dtype=np.float64) @ mat.T
+    img = (pos[None, :, :] + shifts[:, None, :]).reshape(-1, 3)
+    idx = np.tile(np.arange(len(pos)), len(shifts))
+    keep = np.all((img >= lo) & (img <= hi), axis=1)
+    img, idx = img[keep], idx[keep]
+    n_in = cKDTree(img).query_ball_point(pts, cutoff, return_length=True)
+    out = {"sampled_points": int(len(pts)), "in_cutoff_per_point": float(np.mean(n_in)), "lj_per_point": 0.0,
+           "buckingham_per_point": 0.0, "other_vdw_per_point": 0.0}
+    if w.probe_vdw is not None:
+        from .interactions import FF, rules_of
+        ff, probe = w.forcefield, w.probe_vdw.probe
+        kinds = np.asarray(w.probe_vdw.atomkinds)
+        cls = np.zeros(ff.nkinds + 1, dtype=np.int8)           # 0 none, 1 LJ, 2 Buckingham (+ hard sphere), 3 anything else
+        for k in range(1, ff.nkinds + 1):
+            ks = [int(r.kind) for r in rules_of(ff.interactions[k - 1][probe - 1])
+                  if int(r.kind) not in (int(FF.NoInteraction), int(FF.CoulombEwaldDirect))]
+            if not ks:
+                continue
+            if ks == [int(FF.LennardJones)]:
+                cls[k] = 1
+            elif int(FF.Buckingham) in ks and set(ks) <= {int(FF.Buckingham), int(FF.HardSphere)}:
+                cls[k] = 2
+            else:
+                cls[k] = 3
+        c_img = cls[kinds[idx]]
+        for c, name in ((1, "lj_per_point"), (2, "buckingham_per_point"), (3, "other_vdw_per_point")):
+            sel = c_img == c
+            if sel.any():
+                out[name] = float(np.mean(cKDTree(img[sel]).query_ball_point(pts, cutoff, return_length=True)))
+    return out

@@ -114,16 +114,21 @@ def _geom(cset):
             np.ascontiguousarray(cset.shift, dtype=np.float64), np.ascontiguousarray(cset.delta, dtype=np.float64))
 
 
-def grid_vdw(probe, cset, lam, thr, i_begin=0, i_end=None, want_raw=False, nthreads=0, j_begin=0, j_end=None):
+def grid_vdw(probe, cset, lam, thr, i_begin=0, i_end=None, want_raw=False, nthreads=0, j_begin=0, j_end=None, out=None):
     """Loop nest of create_grid_vdw (grids.jl:144-150) for x-planes [i_begin, i_end).
     Returns (grid float32[8,nx,ny,nz], raw float64[nx,ny,nz,8] or None); planes outside the
-    range are left NaN."""
+    range are left NaN.  ``out``: a caller-owned float32[8,nx,ny,nz] array written in place (not NaN-filled:
+    for timing the loop nest without the allocation)."""
     p = _Probe(probe)
     dims, size, shift, delta = _geom(cset)
     nx, ny, nz = (int(d) + 1 for d in dims)
     i_end = nx if i_end is None else i_end
     j_end = ny if j_end is None else j_end
-    grid = np.full((8, nx, ny, nz), np.nan, dtype=np.float32)
+    if out is None:
+        grid = np.full((8, nx, ny, nz), np.nan, dtype=np.float32)
+    else:
+        assert out.shape == (8, nx, ny, nz) and out.dtype == np.float32 and out.flags.c_contiguous
+        grid = out
     raw = np.full((nx, ny, nz, 8), np.nan, dtype=np.float64) if want_raw else None
     rc = lib().oracle_grid_vdw(_d(p.pos), p.kinds.ctypes.data_as(_i64p), p.n, _d(p.mat), _d(p.invmat),
                                int(p.ortho), p.safemin2, p.cutoff2, p.rules.ctypes.data,
@@ -136,14 +141,18 @@ def grid_vdw(probe, cset, lam, thr, i_begin=0, i_end=None, want_raw=False, nthre
     return grid, raw
 
 
-def grid_coulomb(probe, alpha, cset, lam, thr, i_begin=0, i_end=None, want_raw=False, nthreads=0, j_begin=0, j_end=None):
-    """Loop nest of create_grid_coulomb (grids.jl:171-177)."""
+def grid_coulomb(probe, alpha, cset, lam, thr, i_begin=0, i_end=None, want_raw=False, nthreads=0, j_begin=0, j_end=None, out=None):
+    """Loop nest of create_grid_coulomb (grids.jl:171-177).  ``out`` as for grid_vdw."""
     p = _Probe(probe)
     dims, size, shift, delta = _geom(cset)
     nx, ny, nz = (int(d) + 1 for d in dims)
     i_end = nx if i_end is None else i_end
     j_end = ny if j_end is None else j_end
-    grid = np.full((8, nx, ny, nz), np.nan, dtype=np.float32)
+    if out is None:
+        grid = np.full((8, nx, ny, nz), np.nan, dtype=np.float32)
+    else:
+        assert out.shape == (8, nx, ny, nz) and out.dtype == np.float32 and out.flags.c_contiguous
+        grid = out
     raw = np.full((nx, ny, nz, 8), np.nan, dtype=np.float64) if want_raw else None
     lib().oracle_grid_coulomb(_d(p.pos), _d(p.q), p.n, _d(p.mat), _d(p.invmat), int(p.ortho), p.safemin2,
                               p.cutoff2, alpha, dims.ctypes.data_as(_i32p), _d(size), _d(shift), _d(delta),
@@ -305,3 +314,28 @@ def block_spheres(csetup, centers, radius2, nthreads=0) -> np.ndarray:
 
 def max_threads() -> int:
     return lib().oracle_max_threads()
+
+
+def usable_cpus() -> int:
+    """Host threads this process may really use: the scheduler affinity mask, capped by the cgroup CPU quota
+    (v2 ``cpu.max``, v1 ``cpu.cfs_quota_us``) -- omp_get_max_threads() reports the machine's logical CPUs even when
+    the container owns a fraction of them."""
+    import math
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(period)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, math.floor(quota + 1e-9)))
+    return max(1, min(n, max_threads()))
