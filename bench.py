@@ -294,6 +294,7 @@ def main():
                 lane_util = rec.get("lane_util")
             except Exception:
                 pass
+        transport = "RCCL" if args.backend == "nccl" else "gloo (rehearsal)"
         out = {
             "metric": "grid-points/sec", "value": value, "unit": "grid-points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -302,8 +303,8 @@ def main():
             "config": {"workload": w.name, "grid_points": npts, "framework_atoms": w.natoms,
                        "lattice_images": plan.num_images, "grids_per_step": ngrids, "mode": args.mode,
                        "algo": "culled" if (algo != _abi.ALGO_BRUTEFORCE and plan.can_cull) else "bruteforce",
-                       "parallelism": (f"block-cyclic x-chunks over {world} GPUs ({cyc.nchunks} chunks of {cyc.m} planes per rank), each chunk all-gathered over {"RCCL" if args.backend == "nccl" else "gloo (rehearsal)"} ({args.gather}) while the next is computed" if cyc is not None
-                                       else f"x-slab sharding over {world} GPU(s)" + ((", RCCL all-gather of slabs" if args.backend == "nccl" else ", gloo all-gather of slabs (rehearsal)") if world > 1 else ""))},
+                       "parallelism": (f"block-cyclic x-chunks over {world} GPUs ({cyc.nchunks} chunks of {cyc.m} planes per rank), each chunk all-gathered over {transport} ({args.gather}) while the next is computed" if cyc is not None
+                                       else f"x-slab sharding over {world} GPU(s)" + (f", {transport} all-gather of slabs" if world > 1 else ""))},
             # neither HBM nor MFMA bounds this path (FP64 vector ALU does); `roofline` is the binding
             # one -- minimum-work flops / t against the FP64 vector peak -- and the HBM view sits alongside
             "roofline": {"bound": "valu_fp64", "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",

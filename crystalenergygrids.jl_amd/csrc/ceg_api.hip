@@ -90,11 +90,16 @@ struct ceg_plan {
     PlanConst* d_pc = nullptr;   // device copy of {g, ib, rt, tables}
     double* d_erfcx = nullptr;
     double* d_exp2 = nullptr;
-    int vdwk = 0;                // hot-loop VdW variant: 0 generic, 1 LJ-only, 2 LJ/Buckingham classes
+    int vdwk = 0;                // hot-loop VdW variant: 0 generic, 1 LJ-only, 2 LJ/Buckingham classes, 3 one tabulated Buckingham class
+    bool single_buck = false;    // every present kind with a VdW rule is the same Buckingham (+ hard sphere) -> candidate for vdwk 3
+    double bk[4] = {0, 0, 0, 0}; // its A, B, C, shift
+    double* d_bk2 = nullptr;
     double r_exact2 = CEG_R_EXACT2;
     std::vector<FastVdw> h_fast;
     FastVdw* d_fast = nullptr;
     bool fast_ewald = false;     // alpha*cutoff within the erfcx polynomial's domain
+    bool ew2 = false;            // r^2-indexed Ewald tables built (hot-loop variant EWK = 2)
+    double* d_ew2 = nullptr;
 };
 
 namespace {
@@ -211,6 +216,18 @@ int convert_rules(ceg_plan* p, const ceg_rule_t* rules, const int32_t* rule_offs
         if (f.cls > 2) all_fast = false;
     }
     p->vdwk = all_lj ? 1 : (all_fast ? 2 : 0);
+    // one Buckingham parameter set for every present VdW-active kind (the Na probe of the fixture force field: Na-O only)
+    if (p->vdwk == 2) {
+        bool first = true, same = true;
+        for (int32_t k = 0; k < nkinds && same; ++k) {
+            const FastVdw& f = p->h_fast[k];
+            if (!present[k] || f.cls == 0) continue;
+            if (f.cls != 2) { same = false; break; }
+            if (first) { p->bk[0] = f.p0; p->bk[1] = f.p1; p->bk[2] = f.p2; p->bk[3] = f.shift; first = false; }
+            else same = f.p0 == p->bk[0] && f.p1 == p->bk[1] && f.p2 == p->bk[2] && f.shift == p->bk[3];
+        }
+        p->single_buck = same && !first && p->bk[1] > 0.0;
+    }
     // hard spheres must lie inside the exact-path radius for the fast Buckingham class
     p->r_exact2 = std::max(CEG_R_EXACT2, hs_max2 * (1.0 + 1e-9) + 1e-9);
     if (p->r_exact2 >= p->g.cutoff2) p->vdwk = 0, p->r_exact2 = CEG_R_EXACT2;
@@ -470,6 +487,124 @@ bool build_ewald_tables_uncached(double alpha, double cutoff2, std::vector<doubl
     return true;
 }
 
+// r^2-indexed tables of B0(s) = erfc(alpha sqrt(s))/sqrt(s) and C(s) = 2 alpha/sqrt(pi) exp(-alpha^2 s) (ceg_internal.h,
+// CEG_EW2_*): per interval a degree-5 interpolant at the Chebyshev nodes of the interval, in long double, expressed in
+// t = s - s_lo (the interval's lower end: clearing the low bits of s gives it).  Returns false if the range needs more than CEG_EW2_NI_MAX intervals or a polynomial misses `tol`
+// (relative) anywhere -- the caller then keeps the erfcx / libm variants.
+// `which` 0: the two Ewald functions (record = CEG_EW2_STRIDE doubles, tolerance relative);  1: G0(s) = A exp(-B sqrt(s)) of a
+// Buckingham class with alpha := B, record = CEG_BK2_STRIDE doubles, tolerance relative to G0 at the start of the table + the
+// dispersion term C/s^3 it is added to (exp(-B r) spans 17 decades up to the cutoff).
+bool build_ew2_table_uncached(double alpha, double r_exact2, double cutoff2, std::vector<double>& tab, int32_t* base_out,
+                              int32_t* ni_out, double* worst_out, int which = 0, double bkA = 0.0, double bkC = 0.0)
+{
+    const int SHIFT = which == 0 ? CEG_EW2_SHIFT : CEG_BK2_SHIFT, ni_max = which == 0 ? CEG_EW2_NI_MAX : CEG_BK2_NI_MAX;
+    auto key_of = [SHIFT](double s) { uint64_t b; memcpy(&b, &s, 8); return (int32_t)((uint32_t)(b >> 32) >> SHIFT); };
+    if (!(alpha > 0.0) || !(r_exact2 >= 1.0) || !(cutoff2 > r_exact2)) return false;
+    const int32_t base = key_of(r_exact2), last = key_of(cutoff2 * (1.0 + 4e-9) + 4e-9);
+    const int32_t ni = last - base + 1;
+    if (ni < 1 || ni > ni_max) return false;
+    const long double a = alpha, ka = 2.0L * a / sqrtl(3.14159265358979323846264338327950288L);
+    auto B0 = [&](long double s) { const long double r = sqrtl(s); return which == 0 ? erfcl(a * r) / r : (long double)bkA * expl(-a * r); };
+    auto Cf = [&](long double s) { return ka * expl(-a * a * s); };
+    const int nf = which == 0 ? 2 : 1, stride = which == 0 ? CEG_EW2_STRIDE : CEG_BK2_STRIDE;
+    const int ND = which == 0 ? 7 : 6;                     // coefficients per polynomial: degree 6 (Ewald pair, 14 doubles) / degree 5
+    const long double PI = 3.14159265358979323846264338327950288L;
+    long double node[7];
+    for (int k = 0; k < ND; ++k) node[k] = cosl(PI * (k + 0.5L) / (long double)ND);       // u in [-1, 1]
+    tab.assign((size_t)ni * stride, 0.0);
+    double worst = 0.0;
+    for (int32_t i = 0; i < ni; ++i) {
+        const uint64_t lo_bits = (uint64_t)(uint32_t)((base + i) << SHIFT) << 32;
+        const uint64_t mid_bits = lo_bits | ((uint64_t)1 << (32 + SHIFT - 1));
+        const uint64_t hi_bits = (uint64_t)(uint32_t)((base + i + 1) << SHIFT) << 32;
+        double s_lo, s_mid, s_hi;
+        memcpy(&s_lo, &lo_bits, 8); memcpy(&s_mid, &mid_bits, 8); memcpy(&s_hi, &hi_bits, 8);
+        const long double hh = 0.5L * ((long double)s_hi - (long double)s_lo);           // half width; s_mid is the exact centre
+        for (int f = 0; f < nf; ++f) {
+            long double V[7][8];
+            for (int r = 0; r < ND; ++r) {
+                long double pw = 1.0L;
+                for (int c = 0; c < ND; ++c) { V[r][c] = pw; pw *= node[r]; }
+                const long double s = (long double)s_mid + node[r] * hh;
+                V[r][ND] = f == 0 ? B0(s) : Cf(s);
+            }
+            for (int c = 0; c < ND; ++c) {                      // Gauss-Jordan with partial pivoting
+                int piv = c;
+                for (int r = c + 1; r < ND; ++r) if (fabsl(V[r][c]) > fabsl(V[piv][c])) piv = r;
+                for (int q = 0; q <= ND; ++q) std::swap(V[c][q], V[piv][q]);
+                const long double d = V[c][c];
+                for (int q = 0; q <= ND; ++q) V[c][q] /= d;
+                for (int r = 0; r < ND; ++r) if (r != c) {
+                    const long double g = V[r][c];
+                    for (int q = 0; q <= ND; ++q) V[r][q] -= g * V[c][q];
+                }
+            }
+            // P(u), u = (t - hh)/hh with t = s - s_lo  ->  coefficients in t (binomial expansion in long double)
+            long double cu[7], ct[7] = {0, 0, 0, 0, 0, 0, 0};
+            long double sc = 1.0L;
+            for (int c = 0; c < ND; ++c) { cu[c] = V[c][ND] * sc; sc /= hh; }             // in (t - hh)
+            for (int c = 0; c < ND; ++c) {                                                 // (t - hh)^c = sum_k C(c,k) t^k (-hh)^(c-k)
+                long double binom = 1.0L;
+                for (int k = 0; k <= c; ++k) {
+                    ct[k] += cu[c] * binom * powl(-hh, c - k);
+                    binom = binom * (c - k) / (k + 1);
+                }
+            }
+            double* co = &tab[(size_t)i * stride + ND * f];
+            for (int c = 0; c < ND; ++c) co[c] = (double)ct[c];
+            for (int q = 0; q <= 16; ++q) {                      // accuracy check with the kernel's double Horner
+                const double t = (double)(((long double)q / 16.0L) * 2.0L * hh * (1.0L - 1e-12L));
+                double pv = co[ND - 1];
+                for (int c = ND - 2; c >= 0; --c) pv = __builtin_fma(pv, t, co[c]);
+                const long double s = (long double)s_lo + (long double)t;
+                const long double ref = f == 0 ? B0(s) : Cf(s);
+                const long double scale = which == 0 ? fabsl(ref) : fabsl(ref) + fabsl((long double)bkC) / (s * s * s);
+                worst = std::max(worst, (double)fabsl(((long double)pv - ref) / scale));
+            }
+        }
+    }
+    *base_out = base; *ni_out = ni; *worst_out = worst;
+    return worst < 5e-11;
+}
+
+bool build_ew2_table(double alpha, double r_exact2, double cutoff2, std::vector<double>& tab, int32_t* base_out, int32_t* ni_out)
+{
+    struct Memo { bool valid = false, ok = false; double alpha = 0, r_exact2 = 0, cutoff2 = 0; int32_t base = 0, ni = 0; std::vector<double> tab; };
+    static std::mutex m;
+    static Memo memo;
+    std::lock_guard<std::mutex> lock(m);
+    if (!(memo.valid && memo.alpha == alpha && memo.r_exact2 == r_exact2 && memo.cutoff2 == cutoff2)) {
+        memo.tab.clear();
+        double worst = 0.0;
+        memo.ok = build_ew2_table_uncached(alpha, r_exact2, cutoff2, memo.tab, &memo.base, &memo.ni, &worst);
+        memo.alpha = alpha; memo.r_exact2 = r_exact2; memo.cutoff2 = cutoff2; memo.valid = true;
+        if (std::getenv("CEG_HIP_TRACE"))
+            fprintf(stderr, "[ceg_hip] r^2-indexed Ewald table: %d intervals, worst relative error %.2e -> %s\n", memo.ni, worst,
+                    memo.ok ? "used" : "not used");
+    }
+    tab = memo.tab; *base_out = memo.base; *ni_out = memo.ni;
+    return memo.ok;
+}
+
+bool build_bk2_table(double A, double B, double C, double r_exact2, double cutoff2, std::vector<double>& tab, int32_t* base_out, int32_t* ni_out)
+{
+    struct Memo { bool valid = false, ok = false; double A = 0, B = 0, C = 0, r_exact2 = 0, cutoff2 = 0; int32_t base = 0, ni = 0; std::vector<double> tab; };
+    static std::mutex m;
+    static Memo memo;
+    std::lock_guard<std::mutex> lock(m);
+    if (!(memo.valid && memo.A == A && memo.B == B && memo.C == C && memo.r_exact2 == r_exact2 && memo.cutoff2 == cutoff2)) {
+        memo.tab.clear();
+        double worst = 0.0;
+        memo.ok = build_ew2_table_uncached(B, r_exact2, cutoff2, memo.tab, &memo.base, &memo.ni, &worst, 1, A, C) && worst < 2e-12;
+        memo.A = A; memo.B = B; memo.C = C; memo.r_exact2 = r_exact2; memo.cutoff2 = cutoff2; memo.valid = true;
+        if (std::getenv("CEG_HIP_TRACE"))
+            fprintf(stderr, "[ceg_hip] r^2-indexed Buckingham table: %d intervals, worst error %.2e of the pair energy -> %s\n", memo.ni, worst,
+                    memo.ok ? "used" : "not used");
+    }
+    tab = memo.tab; *base_out = memo.base; *ni_out = memo.ni;
+    return memo.ok;
+}
+
 int check_common(const double* pos, int64_t natoms, const double* mat, const double* invmat,
                  const int32_t* dims, const double* size, const double* shift, const double* delta)
 {
@@ -600,6 +735,30 @@ extern "C" int ceg_plan_create(ceg_plan_t** plan, int32_t device,
                 hc.erfcx_mx0_inv_h = mx0;
                 p->fast_ewald = want_ewald;
             }
+            hc.two_alpha2 = 2.0 * alpha * alpha;
+            if (ok && want_ewald && !rc && !std::getenv("CEG_HIP_NO_EW2")) {
+                std::vector<double> t2;
+                int32_t base = 0, ni = 0;
+                if (build_ew2_table(alpha, p->r_exact2, cutoff2, t2, &base, &ni)) {
+                    rc = upload(&p->d_ew2, t2.data(), t2.size());
+                    hc.ew2_tab = p->d_ew2;
+                    hc.ew2_ni = ni;
+                    hc.ew2_base = base;
+                    p->ew2 = !rc;
+                }
+            }
+        }
+        if (!rc && p->vdwk == 2 && p->single_buck && !std::getenv("CEG_HIP_NO_BK2")) {
+            std::vector<double> tb;
+            int32_t base = 0, ni = 0;
+            if (build_bk2_table(p->bk[0], p->bk[1], p->bk[2], p->r_exact2, cutoff2, tb, &base, &ni)) {
+                rc = upload(&p->d_bk2, tb.data(), tb.size());
+                hc.bk2_tab = p->d_bk2;
+                hc.bk2_ni = ni;
+                hc.bk2_base = base;
+                hc.bk_B = p->bk[1]; hc.bk_C = p->bk[2]; hc.bk_shift = p->bk[3];
+                if (!rc) p->vdwk = 3;
+            }
         }
         if (!rc) rc = upload(&p->d_pc, &hc, 1);
     }
@@ -619,7 +778,7 @@ extern "C" int ceg_plan_destroy(ceg_plan_t* p)
     (void)hipDeviceSynchronize();          // what hipFree would do: no kernel of this plan is still running
     for (void* ptr : {(void*)p->d_atoms, (void*)p->d_kind, (void*)p->d_rules, (void*)p->d_offset, (void*)p->d_images,
                       (void*)p->d_imgkind, (void*)p->d_imgatom, (void*)p->d_binstart, (void*)p->d_pc, (void*)p->d_erfcx,
-                      (void*)p->d_exp2, (void*)p->d_fast})
+                      (void*)p->d_exp2, (void*)p->d_fast, (void*)p->d_ew2, (void*)p->d_bk2})
         cached_free(ptr);
     delete p;
     return CEG_OK;
@@ -653,7 +812,7 @@ int run(ceg_plan* p, int mode, const Output& out, const Points& pts, bool culled
     RuleTable rt{p->d_rules, p->d_offset, p->nkinds};
     hipError_t e;
     if (culled) {
-        e = launch_culled(mode, p->d_pc, p->g, p->vdwk, p->fast_ewald, out, pts, stream);
+        e = launch_culled(mode, p->d_pc, p->g, p->vdwk, p->ew2 ? 2 : (p->fast_ewald ? 1 : 0), out, pts, stream);
     } else {
         AtomTable at{p->d_atoms, p->has_rules ? p->d_kind : nullptr, p->natoms};
         e = launch_bruteforce(mode, p->g, at, rt, out, pts, stream);

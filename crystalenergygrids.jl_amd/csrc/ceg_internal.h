@@ -112,6 +112,15 @@ struct PlanConst {
     double erfcx_inv_h;        // 1/h
     double erfcx_mx0_inv_h;    // -x0/h
     double alpha2;             // alpha^2
+    // r^2-indexed tables of the real-space Ewald radial functions (EWK = 2, see ceg_math.h): [ew2_ni][CEG_EW2_STRIDE]
+    const double* ew2_tab;
+    int32_t ew2_ni;            // intervals in the table (<= CEG_EW2_NI_MAX)
+    int32_t ew2_base;          // key of the first interval: hi32(r_exact2) >> CEG_EW2_SHIFT
+    double two_alpha2;         // 2 alpha^2
+    // single Buckingham class (VDWK = 3): G0(s) = A exp(-B sqrt(s)) on r^2 intervals of its own (CEG_BK2_LOGM), [bk2_ni][CEG_BK2_STRIDE]
+    const double* bk2_tab;
+    int32_t bk2_ni, bk2_base;
+    double bk_B, bk_C, bk_shift;
 };
 
 // shared between the host table builder and the kernels
@@ -121,10 +130,28 @@ constexpr int CEG_ERFCX_TAB_N = 128;     // pieces of the erfcx table (= ERFCX_T
 #endif
 constexpr double CEG_R_EXACT2 = CEG_R_EXACT2_VALUE;     // pairs closer than this (A^2) take the exact path
 
+// r^2-indexed Ewald tables: the interval of s = r^2 is read off the bits of s -- exponent + the CEG_EW2_LOGM leading
+// mantissa bits, i.e. 2^LOGM intervals per octave -- and each interval holds two degree-6 polynomials in t = s - s_lo:
+//   B0(s) = erfc(alpha sqrt(s)) / sqrt(s),   C(s) = (2 alpha / sqrt(pi)) exp(-alpha^2 s)
+// from which derivatives_ewald (src/ewald.jl:299-312) follows by the recurrence B_{n+1} = ((2n+1) B_n + (2 alpha^2)^n C) / s.
+// Record = 7 + 7 coefficients = 112 B: with 16-byte LDS reads, 16 consecutive intervals fall into 16 different bank
+// groups (a 96-byte record of two degree-5 polynomials would use 8).  Degree 5 left 7e-10 of the term itself in the last
+// octave before the cutoff (visible at 1e-9 in sums that hold far pairs only); degree 6: <= 1e-11 there, 2e-15 below 8 A.
+constexpr int CEG_EW2_LOGM = 5;
+constexpr int CEG_EW2_SHIFT = 20 - CEG_EW2_LOGM;               // bits of the high word below the interval key
+constexpr int CEG_EW2_STRIDE = 14;                             // doubles per interval record
+constexpr int CEG_EW2_NI_MAX = 176;                            // cutoff 12 A from r_exact 2 A: 165 intervals
+constexpr int CEG_BK2_STRIDE = 6;                              // one degree-5 polynomial per interval (48 B: 16 bank groups too)
+constexpr int CEG_BK2_LOGM = 6;                                // A exp(-B sqrt(s)) varies faster: 64 intervals per octave of s
+constexpr int CEG_BK2_SHIFT = 20 - CEG_BK2_LOGM;
+constexpr int CEG_BK2_NI_MAX = 2 * CEG_EW2_NI_MAX;
+
 // launchers (ceg_kernels.hip)
 hipError_t launch_bruteforce(int mode, const Geom& g, const AtomTable& atoms, const RuleTable& rt,
                              const Output& out, const Points& pts, hipStream_t stream);
-hipError_t launch_culled(int mode, const PlanConst* d_pc, const Geom& g, int vdwk, bool fastew,
+// ewk: real-space Ewald arithmetic of the hot loop -- 0 libm-grade erfc / exp, 1 erfcx table + exp (alpha*cutoff <= 5),
+// 2 r^2-indexed tables
+hipError_t launch_culled(int mode, const PlanConst* d_pc, const Geom& g, int vdwk, int ewk,
                          const Output& out, const Points& pts, hipStream_t stream);
 
 }  // namespace ceg

@@ -26,6 +26,8 @@
 //    O(N_grid * n_cut).
 //
 // No MFMA: this is a pairwise FP64 reduction, bound by the FP64 vector ALU.
+#include <type_traits>
+
 #include "ceg_internal.h"
 #include "ceg_math.h"
 #include "ceg_minimage.h"
@@ -338,15 +340,21 @@ __global__ __launch_bounds__(256) void k_bruteforce(Geom g, AtomTable atoms, Rul
 #endif
 // pairs closer than this (A^2) take the literal min-image arithmetic in the culled kernel
 // waves per SIMD the register allocator plans for, per variant (measured, profiles/r01_variant_waves.txt)
-constexpr int culled_waves(int mode, int vdwk, bool fastew)
+constexpr int culled_waves(int mode, int vdwk, int ewk)
 {
-    return (mode == 2 && vdwk == 2 && fastew) ? CEG_WAVES_FUSED_BUCK
-           : (mode == 2 && vdwk == 1 && fastew) ? CEG_WAVES_FUSED_LJ
-           : (mode == 0 && vdwk == 1)         ? CEG_WAVES_VDW_LJ
-           : (mode == 0 && vdwk == 2)         ? CEG_WAVES_VDW_BUCK
-           : (mode == 1 && fastew)            ? CEG_WAVES_COULOMB
-                                              : CEG_WAVES;
+    return (mode == 2 && vdwk >= 2 && ewk) ? CEG_WAVES_FUSED_BUCK
+           : (mode == 2 && vdwk == 1 && ewk) ? CEG_WAVES_FUSED_LJ
+           : (mode == 0 && vdwk == 1)      ? CEG_WAVES_VDW_LJ
+           : (mode == 0 && vdwk >= 2)      ? CEG_WAVES_VDW_BUCK
+           : (mode == 1 && ewk)            ? CEG_WAVES_COULOMB
+                                           : CEG_WAVES;
 }
+#ifndef CEG_NW_EW2
+#define CEG_NW_EW2 8     // waves per workgroup of the variants that keep the r^2-indexed Ewald tables in LDS
+#endif
+// waves (= tiles) per workgroup: the r^2-indexed Ewald tables take 18 KB of LDS, shared by 8 waves instead of 4 so that
+// two workgroups (16 waves, 4 per SIMD) still fit a CU's 160 KB
+constexpr int culled_nw(int mode, int vdwk, int ewk) { return ((mode != 0 && ewk == 2) || (mode != 1 && vdwk == 3)) ? CEG_NW_EW2 : CEG_WG / 64; }
 [[maybe_unused]] constexpr double R_EXACT2 = CEG_R_EXACT2;
 static_assert(ERFCX_TAB_N == CEG_ERFCX_TAB_N, "table size mismatch");
 constexpr int META_SIMPLE = 1 << 24;      // image is the wrapped one for every point of the tile
@@ -372,10 +380,10 @@ struct __attribute__((aligned(16))) CandRec {
 // position, invmat*d, wrap, mat*f, neighbour search (periodic_distance2_literal) -- and evaluated
 // with the literal radial formulas.  Runs after the hot loop so that its registers do not
 // overlap the hot loop's.
-template <int MODE, bool FASTEW, bool LJSLOW>
+template <int MODE, bool FASTEW, bool LJSLOW, typename Rec>
 __device__ __forceinline__ void slow_pairs(const PlanConst* __restrict__ pc, unsigned long long cands, int lane,
                                            double px, double py, double pz,
-                                           const CandRec* s_rec,
+                                           const Rec* s_rec,
                                            const unsigned long long* s_odd,
                                            Accum& av, Accum& ac, double& smallest_d2)
 {
@@ -394,6 +402,9 @@ __device__ __forceinline__ void slow_pairs(const PlanConst* __restrict__ pc, uns
             const int kd = mt & META_KINDMASK;
             double v, p1, p2, p3;
             vdw_terms<LJSLOW>(pc->rt.rules, pc->rt.offset[kd], pc->rt.offset[kd + 1], r2, v, p1, p2, p3);
+            if (LJSLOW) {        // the LJ-only hot loop accumulates p1/-12, p2/168, p3/-2688 (scaled once per tile at the end)
+                p1 *= -1.0 / 12.0; p2 *= 1.0 / 168.0; p3 *= -1.0 / 2688.0;
+            }
             accum_add(av, v, p1, p2, p3, dx, dy, dz);
         }
         if (MODE != MODE_VDW) {
@@ -406,6 +417,14 @@ __device__ __forceinline__ void slow_pairs(const PlanConst* __restrict__ pc, uns
             accum_add(ac, v, p1, p2, p3, dx, dy, dz);
         }
     }
+}
+
+// a*b + c on 24-bit operands, c in a scalar register (one VALU instruction)
+__device__ __forceinline__ int mad_u24(int a, int b, int c)
+{
+    int r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
 }
 
 // A wave-uniform FP64 value held in an SGPR pair.  gfx950 has no scalar FP64 ALU, so the compiler keeps
@@ -432,45 +451,73 @@ __device__ __forceinline__ double wave_max(double x)
 }
 
 static_assert(sizeof(CandRec) == 80, "candidate record layout");
+// the same without the per-candidate VdW parameters (Coulomb-only builds, generic rules, the single tabulated Buckingham class)
+struct __attribute__((aligned(16))) CandRecS {
+    Quad xyzq;
+    int32_t meta;
+    int32_t atom;
+    int32_t _pad[2];
+};
+static_assert(sizeof(CandRecS) == 48, "candidate record layout");
 
 // Template flags of k_culled
 //   MODE    what is accumulated (VdW / Coulomb / both in one pass)
 //   POINTS  arbitrary point list (eval_points) instead of 4x4x4 grid tiles
 //   VDWK    0: generic rule runs evaluated with vdw_terms in the hot loop;
 //           1: every kind present has at most one rule and it is Lennard-Jones;
+//           3: every kind present is none or ONE Buckingham (+ hard sphere inside the exact-path radius): A exp(-B r) from
+//              an r^2-indexed table, B, C, shift in scalar registers, no per-candidate parameters
 //           2: every kind present is none / LJ / Buckingham (+ hard spheres that lie inside the
 //              exact-path radius): the per-kind parameters travel with the candidate through LDS
 //              and the pair term uses the shared 1/r (and the table exp for Buckingham)
-//   FASTEW  alpha*cutoff <= ERFCX_XMAX: real-space Ewald term from ceg_math.h (one exp, erfcx
+//   (EWK replaces round 1's FASTEW flag; FASTEW = EWK != 0 below: the erfcx-polynomial slow path is valid)
 //           polynomial, no division); otherwise libm-style erfc/exp
-template <int MODE, bool POINTS, int VDWK, bool FASTEW>
-__global__ __launch_bounds__(CEG_WG, culled_waves(MODE, VDWK, FASTEW)) void k_culled(const PlanConst* __restrict__ pc, Output out, Points pts,
+//   EWK     real-space Ewald term: 0 libm-style erfc / exp; 1 (alpha*cutoff <= ERFCX_XMAX) one table exp + erfcx table,
+//           no division; 2 B0(r^2), C(r^2) from r^2-indexed polynomial tables + the B_n recurrence, no sqrt / exp / erfc
+template <int MODE, bool POINTS, int VDWK, int EWK>
+__global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE, VDWK, EWK)) void k_culled(const PlanConst* __restrict__ pc, Output out, Points pts,
                                                               int tiles_j, int tiles_k, int64_t ntiles)
 {
+    constexpr bool FASTEW = EWK != 0;
+    constexpr bool EW2 = EWK == 2 && MODE != MODE_VDW;
+    constexpr int WG = 64 * culled_nw(MODE, VDWK, EWK);
+    constexpr bool BK2 = VDWK == 3 && MODE != MODE_COULOMB;       // one Buckingham class, G0(r^2) tabulated
     // One workgroup = CEG_WG/64 waves; each wave owns one tile and its own slice of the staging
     // arrays (waves never touch each other's slice, so no workgroup barrier inside the loops --
     // LDS operations of one wave complete in order).  The function tables are shared.
-    constexpr int NW = CEG_WG / 64;
+    constexpr int NW = WG / 64;
     // one record per kept candidate: image position + charge, VdW parameters of its kind, flags, atom index.
     // A single array so that the hot loop walks ONE LDS address (immediate offsets reach the fields).
-    __shared__ __attribute__((aligned(16))) CandRec s_rec_all[NW][64];
+    constexpr bool HAS_LJ = (VDWK == 1 || VDWK == 2) && MODE != MODE_COULOMB;      // per-candidate VdW parameters travel in the record
+    using Rec = std::conditional_t<HAS_LJ, CandRec, CandRecS>;
+    __shared__ __attribute__((aligned(16))) Rec s_rec_all[NW][64];
     __shared__ int32_t s_rowstart_all[NW][64];
     __shared__ int32_t s_rowprefix_all[NW][66];
     __shared__ unsigned long long s_odd_all[NW][64];
-    __shared__ __attribute__((aligned(16))) double s_erfcx[ERFCX_TAB_N * 6];
+    __shared__ __attribute__((aligned(16))) double s_erfcx[EW2 ? 2 : ERFCX_TAB_N * 6];
+    __shared__ __attribute__((aligned(16))) double s_ew2[EW2 ? CEG_EW2_NI_MAX * CEG_EW2_STRIDE : 2];
+    __shared__ __attribute__((aligned(16))) double s_bk2[BK2 ? CEG_BK2_NI_MAX * CEG_BK2_STRIDE : 2];
     __shared__ double s_exp2[64];
     __shared__ int32_t s_org[NW][4];             // tile origins for the output transpose (grid mode)
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    CandRec* s_rec = s_rec_all[wave];
+    Rec* s_rec = s_rec_all[wave];
     int32_t* s_rowstart = s_rowstart_all[wave];
     int32_t* s_rowprefix = s_rowprefix_all[wave];
     unsigned long long* s_odd = s_odd_all[wave];
 
     constexpr bool FASTVDW = VDWK != 0;
-    if (FASTEW && MODE != MODE_VDW)
-        for (int t = threadIdx.x; t < ERFCX_TAB_N * 6; t += CEG_WG) s_erfcx[t] = pc->erfcx_tab[t];
-    if ((FASTEW && MODE != MODE_VDW) || (VDWK == 2 && MODE != MODE_COULOMB))
+    if (EW2) {
+        const int nt = pc->ew2_ni * CEG_EW2_STRIDE;
+        for (int t = threadIdx.x; t < nt; t += WG) s_ew2[t] = pc->ew2_tab[t];
+    } else if (FASTEW && MODE != MODE_VDW) {
+        for (int t = threadIdx.x; t < ERFCX_TAB_N * 6; t += WG) s_erfcx[t] = pc->erfcx_tab[t];
+    }
+    if (BK2) {
+        const int nt = pc->bk2_ni * CEG_BK2_STRIDE;
+        for (int t = threadIdx.x; t < nt; t += WG) s_bk2[t] = pc->bk2_tab[t];
+    }
+    if ((FASTEW && !EW2 && MODE != MODE_VDW) || (VDWK == 2 && MODE != MODE_COULOMB))
         if (threadIdx.x < 64) s_exp2[threadIdx.x] = pc->exp2_tab[threadIdx.x];
     __syncthreads();
     const int64_t tile_raw = (int64_t)blockIdx.x * NW + wave;
@@ -562,6 +609,20 @@ __global__ __launch_bounds__(CEG_WG, culled_waves(MODE, VDWK, FASTEW)) void k_cu
     // the reference can fire (safemin2 < cutoff2, src/utils.jl:233-245), below safemin2's band too
     const double reg_hi = uniform(stale_possible ? fmin(cutoff2 - band_cut, safemin2 * (1.0 - 1e-9)) : cutoff2 - band_cut);
     const double erf_inv_h = pc->erfcx_inv_h, erf_mx0 = pc->erfcx_mx0_inv_h;
+    // integer forms of the range tests of the hot loop (high words of r_exact2 rounded up, reg_hi rounded down, cut_hi as is)
+    const int hi_lo = __builtin_amdgcn_readfirstlane(__double2hiint(r_exact2) + (__double2loint(r_exact2) != 0 ? 1 : 0));
+    const int hi_top = __builtin_amdgcn_readfirstlane(__double2hiint(reg_hi));
+    const unsigned hi_span = hi_top > hi_lo ? (unsigned)(hi_top - hi_lo) : 0u;
+    const int hi_cut = __builtin_amdgcn_readfirstlane(__double2hiint(cut_hi));
+    // r^2-indexed tables: record of the interval with key k starts at s_ew2 + (k - ew2_base) * STRIDE
+    const int ew2_off = EW2 ? __builtin_amdgcn_readfirstlane(-pc->ew2_base * (CEG_EW2_STRIDE * 8)) : 0;
+    int ew2_stride = CEG_EW2_STRIDE * 8;              // kept in a VGPR: v_mad_u32_u24 reads one scalar operand (ew2_off)
+    asm volatile("" : "+v"(ew2_stride));
+    const double two_alpha2 = pc->two_alpha2;
+    const int bk2_off = BK2 ? __builtin_amdgcn_readfirstlane(-pc->bk2_base * (CEG_BK2_STRIDE * 8)) : 0;
+    int bk2_stride = CEG_BK2_STRIDE * 8;
+    asm volatile("" : "+v"(bk2_stride));
+    const double bk_B = pc->bk_B, bk_C = pc->bk_C, bk_shift = pc->bk_shift;
 
     for (int rbase = 0; rbase < nrows; rbase += 64) {
         // -- one row per lane: image range [start, start+count)
@@ -623,7 +684,7 @@ __global__ __launch_bounds__(CEG_WG, culled_waves(MODE, VDWK, FASTEW)) void k_cu
                 if (MODE != MODE_COULOMB && kd >= 0) {
                     const int rb = rt.offset[kd];
                     hasvdw = rt.offset[kd + 1] > rb;
-                    if (FASTVDW && hasvdw && keep) {
+                    if (FASTVDW && VDWK != 3 && hasvdw && keep) {
                         const FastVdw F = pc->fastvdw[kd];          // class + parameters of this kind
                         LJ = make_double4(F.p0, F.p1, F.p2, F.shift);
                         vclass = F.cls;
@@ -646,14 +707,24 @@ __global__ __launch_bounds__(CEG_WG, culled_waves(MODE, VDWK, FASTEW)) void k_cu
                 meta = (kd & META_KINDMASK) | (simple ? META_SIMPLE : 0) | (hasvdw ? META_HASVDW : 0) |
                        (vclass == 2 ? META_BUCK : 0);
             }
-            const unsigned long long mask = __ballot(keep);
-            const int nkeep = __popcll(mask);
+            // Kept candidates are compacted into three consecutive groups, so that the hot loops below run without a
+            // per-candidate class test (no record flag to read, no scalar branch around the VdW part):
+            //   [0, nv)         image provably the wrapped one for the whole tile, kind has a VdW rule
+            //   [nv, nreg)      same, no VdW rule (fused mode only: Coulomb term alone)
+            //   [nreg, nkeep)   image near a cell-wrap boundary of this tile: every lane takes the exact path
+            const bool simple_c = (meta & META_SIMPLE) != 0;
+            const bool withv = MODE != MODE_COULOMB && (meta & META_HASVDW) != 0;
+            const unsigned long long mask_v = __builtin_amdgcn_ballot_w64(keep && simple_c && withv);
+            const unsigned long long mask_n = __builtin_amdgcn_ballot_w64(keep && simple_c && !withv);
+            const unsigned long long mask_x = __builtin_amdgcn_ballot_w64(keep && !simple_c);
+            const int nv = __popcll(mask_v), nreg = nv + __popcll(mask_n), nkeep = nreg + __popcll(mask_x);
             __builtin_amdgcn_wave_barrier();                   // previous chunk's readers are done
             if (keep) {
-                const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                           __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                const unsigned long long mine = !simple_c ? mask_x : (withv ? mask_v : mask_n);
+                const int slot = (!simple_c ? nreg : (withv ? 0 : nv)) +
+                                 __builtin_amdgcn_mbcnt_hi((unsigned)(mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mine, 0));
                 s_rec[slot].xyzq = Quad{P.x, P.y, P.z, P.w};
-                if (FASTVDW && MODE != MODE_COULOMB) s_rec[slot].lj = Quad{LJ.x, LJ.y, LJ.z, LJ.w};
+                if constexpr (HAS_LJ) s_rec[slot].lj = Quad{LJ.x, LJ.y, LJ.z, LJ.w};
                 s_rec[slot].meta = meta;
                 s_rec[slot].atom = aidx;
             }
@@ -665,35 +736,76 @@ __global__ __launch_bounds__(CEG_WG, culled_waves(MODE, VDWK, FASTEW)) void k_cu
             //    Anything else is recorded in a per-lane bit mask and redone after the loop with
             //    the reference's literal arithmetic (slow_pairs).
             unsigned long long slow = 0ull;     // wave-uniform: candidates with at least one odd lane
-            for (int q = 0; q < nkeep; ++q) {
+            auto pair_body = [&](const int q, auto with_vdw_tag) __attribute__((always_inline)) {
+                constexpr bool WITH_VDW = decltype(with_vdw_tag)::value;
                 const Quad A = s_rec[q].xyzq;
-                const int mt = __builtin_amdgcn_readfirstlane(s_rec[q].meta);
                 double dx = px - A.x, dy = py - A.y, dz = pz - A.z;
                 const double r2 = dx * dx + dy * dy + dz * dz;
                 // regular: R_EXACT2 <= r2 < min(cutoff2 - band, stale limit), image provably the
                 // wrapped one.  odd: anything else that could contribute.  (bitwise logic on
                 // purpose: no short-circuit branches in the hot loop)
-                const bool simple = (mt & META_SIMPLE) != 0;
-                const bool in = (r2 >= r_exact2) & (r2 < reg_hi) & simple;
-                const bool odd = (!in) & (r2 <= cut_hi);
-                const unsigned long long oddlanes = __ballot(odd);
+                // r2 >= 0, so doubles order like their bit patterns: the range tests look at the high word only
+                // (32-bit integer compares issue at twice the FP64 rate).  hi_lo / hi_lo + hi_span are rounded inwards,
+                // hi_cut outwards: a pair within 2^-20 relative of a threshold takes the exact path, which decides.
+                const int hi = __double2hiint(r2);
+                // lane masks straight out of the two compares (ICMP_ULT = 36, ICMP_SLE = 41)
+                const unsigned long long m_in = __builtin_amdgcn_uicmp((unsigned)(hi - hi_lo), hi_span, 36);
+                const unsigned long long oddlanes = __builtin_amdgcn_sicmp(hi, hi_cut, 41) & ~m_in;
                 if (oddlanes != 0ull) {              // scalar branch, rarely taken
                     slow |= 1ull << q;
                     if (lane == 0) s_odd[q] = oddlanes;
                 }
-                if (!in) continue;
+                if (!((unsigned)(hi - hi_lo) < hi_span)) return;
 
                 // ---- regular pair: 2 A <= r < cutoff
                 const double dxy = dx * dy, dxz = dx * dz, dyz = dy * dz;
                 const double dxyz = dxz * dy;
                 double rr = 0.0, rinv = 0.0, inv = 0.0;
-                if (FASTVDW || (FASTEW && MODE != MODE_VDW)) {
+                // sqrt(r2) is needed by Buckingham's exp(-B r) and by the erfcx form of the Ewald term; Lennard-Jones and the
+                // r^2-indexed Ewald tables only use 1/r2
+                constexpr bool NEED_SQRT = (VDWK >= 2 && MODE != MODE_COULOMB) || (EWK == 1 && MODE != MODE_VDW);
+                if (NEED_SQRT) {
                     fast_sqrt_rsqrt(r2, rr, rinv);
                     inv = rinv * rinv;
+                } else if (FASTVDW || EW2) {
+                    inv = fast_rcp(r2);
                 }
-                if (MODE != MODE_COULOMB && (mt & META_HASVDW)) {
+                // interval of s = r2 in the r^2-indexed tables: key = exponent + leading mantissa bits, t = s - start of the interval
+                int key = 0;
+                double t = 0.0;
+                if (EW2) {
+                    key = (int)((unsigned)hi >> CEG_EW2_SHIFT);
+                    t = r2 - __hiloint2double(hi & (int)(0xffffffffu << CEG_EW2_SHIFT), 0);
+                }
+                if constexpr (WITH_VDW) {
                     double v, p1, p2, p3;
-                    if (VDWK == 2 && (mt & META_BUCK)) {
+                    if constexpr (VDWK == 3) {
+                        // derivativesGrid, Buckingham branch (src/interactions.jl:447-457) with G0 = A exp(-B r) from the table,
+                        // u = G0/r, x6 = C/r^6 and D = (1/r) d/dr:  D G0 = -B u,  D u = -(B G0 + u)/r^2
+                        //   v = G0 - x6 - shift,  p1 = -B u + 6 x6/r^2,  p2 = B (B G0 + u)/r^2 - 48 x6/r^4,
+                        //   p3 = -B (B^2 u + 3 (B G0 + u)/r^2)/r^2 + 480 x6/r^6
+                        const int keyb = (int)((unsigned)hi >> CEG_BK2_SHIFT);
+                        const double tb = r2 - __hiloint2double(hi & (int)(0xffffffffu << CEG_BK2_SHIFT), 0);
+                        const double2* rec = reinterpret_cast<const double2*>(
+                            reinterpret_cast<const char*>(s_bk2) + mad_u24(keyb, bk2_stride, bk2_off));
+                        const double2 g01 = rec[0], g23 = rec[1], g45 = rec[2];
+                        double g0 = __builtin_fma(g45.y, tb, g45.x);
+                        g0 = __builtin_fma(g0, tb, g23.y);
+                        g0 = __builtin_fma(g0, tb, g23.x);
+                        g0 = __builtin_fma(g0, tb, g01.y);
+                        g0 = __builtin_fma(g0, tb, g01.x);
+                        const double u = g0 * rinv;
+                        const double inv2 = inv * inv, inv3 = inv2 * inv;
+                        const double x6 = mul_sc(inv3, bk_C);
+                        const double w = fma_vsv(g0, bk_B, u);                 // B G0 + u
+                        const double wi = w * inv;
+                        const double Bu = mul_sc(u, bk_B);
+                        v = add_sc(g0 - x6, -bk_shift);
+                        p1 = __builtin_fma(mul_sc(x6, 6.0), inv, -Bu);
+                        p2 = __builtin_fma(mul_sc(x6, -48.0), inv2, mul_sc(wi, bk_B));
+                        p3 = __builtin_fma(mul_sc(x6, 480.0), inv3, -(mul_sc(fma_vsv(Bu, bk_B, 3.0 * wi), bk_B) * inv));
+                    } else if constexpr (HAS_LJ) {
+                      if (VDWK == 2 && (__builtin_amdgcn_readfirstlane(s_rec[q].meta) & META_BUCK)) {
                         // derivativesGrid, Buckingham branch (src/interactions.jl:447-457); a hard
                         // sphere summed with it is 0 here (its radius lies inside the exact path)
                         const Quad L = s_rec[q].lj;            // A, B, C, shift
@@ -708,7 +820,7 @@ __global__ __launch_bounds__(CEG_WG, culled_waves(MODE, VDWK, FASTEW)) void k_cu
                         p2 = __builtin_fma(mul_sc(x6, -48.0), inv2, (Bxe * rinv3) * (1.0 + Br));
                         p3 = __builtin_fma(mul_sc(x6, 480.0), inv2 * inv,
                                            -((Bxe * rinv3) * inv) * __builtin_fma(Br, add_sc(Br, 3.0), 3.0));
-                    } else if (FASTVDW) {
+                      } else {
                         // derivativesGrid, LJ branch (src/interactions.jl:434-441), with 1/r2 shared
                         const Quad L = s_rec[q].lj;            // 4 eps, sigma^2, -, shift
                         const double sx = L.y * inv;
@@ -716,11 +828,15 @@ __global__ __launch_bounds__(CEG_WG, culled_waves(MODE, VDWK, FASTEW)) void k_cu
                         const double t1 = L.x * x6;                        // 4 eps x6
                         const double t1i = t1 * inv, t1ii = t1i * inv, inv2 = inv * inv;
                         v = __builtin_fma(t1, x6, -t1) - L.w;              // 4 eps x6 (x6 - 1) - shift
-                        p1 = mul_sc(t1i * (x6 - 0.5), -12.0);                                // 24 eps x6 (1 - 2 x6)/r^2
-                        p2 = mul_sc(t1ii * add_sc(x6, -2.0 / 7.0), 168.0);                   // 96 eps x6 (7 x6 - 2)/r^4
-                        p3 = mul_sc((t1ii * inv2) * add_sc(x6, -5.0 / 28.0), -2688.0);       // 384 eps x6 (5 - 28 x6)/r^8
+                        p1 = t1i * (x6 - 0.5);                                               // 24 eps x6 (1 - 2 x6)/r^2   / -12
+                        p2 = t1ii * add_sc(x6, -2.0 / 7.0);                                  // 96 eps x6 (7 x6 - 2)/r^4   / 168
+                        p3 = (t1ii * inv2) * add_sc(x6, -5.0 / 28.0);                        // 384 eps x6 (5 - 28 x6)/r^8 / -2688
+                        if (VDWK != 1) {     // mixed classes share the accumulators: scale per pair.  LJ-only plans scale once per tile
+                            p1 = mul_sc(p1, -12.0); p2 = mul_sc(p2, 168.0); p3 = mul_sc(p3, -2688.0);
+                        }
+                      }
                     } else {
-                        const int kd = mt & META_KINDMASK;
+                        const int kd = __builtin_amdgcn_readfirstlane(s_rec[q].meta) & META_KINDMASK;
                         vdw_terms(rt.rules, rt.offset[kd], rt.offset[kd + 1], r2, v, p1, p2, p3);
                     }
                     av.v += v;
@@ -735,7 +851,34 @@ __global__ __launch_bounds__(CEG_WG, culled_waves(MODE, VDWK, FASTEW)) void k_cu
                 if (MODE != MODE_VDW) {
                     // (regular pairs have r >= 2 A: they cannot trigger the smallest_d2 < 1 rule)
                     double v, p1, p2, p3;
-                    if (FASTEW) {
+                    if (EW2) {
+                        // derivatives_ewald (src/ewald.jl:299-312) as B_n(r) of the interval polynomials in s = r2:
+                        //   B0 = erfc(alpha r)/r,  C = (2 alpha/sqrt(pi)) exp(-alpha^2 s),
+                        //   B1 = (B0 + C)/s,  B2 = (3 B1 + 2 alpha^2 C)/s,  B3 = (5 B2 + 4 alpha^4 C)/s
+                        //   v = q B0,  p1 = -q B1,  p2 = q B2,  p3 = -q B3
+                        const double2* rec = reinterpret_cast<const double2*>(
+                            reinterpret_cast<const char*>(s_ew2) + mad_u24(key, ew2_stride, ew2_off));
+                        const double2 a01 = rec[0], a23 = rec[1], a45 = rec[2], a6c0 = rec[3], c12 = rec[4], c34 = rec[5], c56 = rec[6];
+                        double b0 = __builtin_fma(a6c0.x, t, a45.y);
+                        double cc = __builtin_fma(c56.y, t, c56.x);
+                        b0 = __builtin_fma(b0, t, a45.x);
+                        cc = __builtin_fma(cc, t, c34.y);
+                        b0 = __builtin_fma(b0, t, a23.y);
+                        cc = __builtin_fma(cc, t, c34.x);
+                        b0 = __builtin_fma(b0, t, a23.x);
+                        cc = __builtin_fma(cc, t, c12.y);
+                        b0 = __builtin_fma(b0, t, a01.y);
+                        cc = __builtin_fma(cc, t, c12.x);
+                        b0 = __builtin_fma(b0, t, a01.x);
+                        cc = __builtin_fma(cc, t, a6c0.y);
+                        const double qb0 = A.w * b0, qc = A.w * cc;
+                        const double b1 = (qb0 + qc) * inv;
+                        const double c2 = mul_sc(qc, two_alpha2);
+                        const double b2 = fma_vsv(b1, 3.0, c2) * inv;
+                        const double c3 = mul_sc(c2, two_alpha2);
+                        const double b3 = fma_vsv(b2, 5.0, c3) * inv;
+                        v = qb0; p1 = -b1; p2 = b2; p3 = -b3;
+                    } else if (FASTEW) {
                         // derivatives_ewald (src/ewald.jl:299-312): erfc(x) = exp(-x^2) erfcx(x)
                         // with E = exp(-x^2), g = erfcx(x), k = 2/sqrt(pi):  erfc = E g,  e = k x E, so
                         //   v  =  (q/r)   E  g
@@ -766,6 +909,22 @@ __global__ __launch_bounds__(CEG_WG, culled_waves(MODE, VDWK, FASTEW)) void k_cu
                     ac.d2yz = __builtin_fma(p2, dyz, ac.d2yz);
                     ac.d3 = __builtin_fma(p3, dxyz, ac.d3);
                 }
+            };
+            if (MODE != MODE_COULOMB)
+                for (int q = 0; q < nv; ++q) pair_body(q, std::true_type{});
+            if (MODE != MODE_VDW)
+                for (int q = (MODE == MODE_COULOMB ? 0 : nv); q < nreg; ++q) pair_body(q, std::false_type{});
+            // third group: the lanes within the cutoff of THIS image go to the exact path (which works from the atom and finds
+            // its nearest image itself -- two images of one atom are never both inside the cutoff of a point)
+            for (int q = nreg; q < nkeep; ++q) {
+                const Quad A = s_rec[q].xyzq;
+                const double dx = px - A.x, dy = py - A.y, dz = pz - A.z;
+                const double r2 = dx * dx + dy * dy + dz * dz;
+                const unsigned long long lanes = __builtin_amdgcn_sicmp(__double2hiint(r2), hi_cut, 41);
+                if (lanes != 0ull) {
+                    slow |= 1ull << q;
+                    if (lane == 0) s_odd[q] = lanes;
+                }
             }
             // -- the pairs set aside above, one per lane per round
             if (slow != 0ull) {
@@ -774,6 +933,11 @@ __global__ __launch_bounds__(CEG_WG, culled_waves(MODE, VDWK, FASTEW)) void k_cu
             }
         }
     }
+    if (VDWK == 1 && MODE != MODE_COULOMB) {      // constant factors of the LJ derivative channels, deferred out of the hot loop
+        av.d1x *= -12.0; av.d1y *= -12.0; av.d1z *= -12.0;
+        av.d2xy *= 168.0; av.d2xz *= 168.0; av.d2yz *= 168.0;
+        av.d3 *= -2688.0;
+    }
     if (POINTS) {
         if (valid) write_results<MODE>(g, out, true, pidx, i, j, k, av, ac, smallest_d2);
         return;
@@ -781,47 +945,55 @@ __global__ __launch_bounds__(CEG_WG, culled_waves(MODE, VDWK, FASTEW)) void k_cu
     // ---- grid mode: the NW tiles of a workgroup are consecutive along z (the fastest array
     // axis), so the workgroup transposes its results through LDS and writes rows of 4*NW
     // contiguous floats (64 B at NW = 4) per (channel, i, j) instead of 16-B fragments.
-    float* smv = reinterpret_cast<float*>(s_rec_all[wave]);      // 2 x 512 floats per wave (5120 B available), staging is done
-    float* smc = smv + 512;
-    __builtin_amdgcn_wave_barrier();
-    if (MODE != MODE_COULOMB) {
-        float r[8];
-        gridpoint8(r, g.delta, out.lambda_vdw, out.thr_vdw, av);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) smv[c * 64 + lane] = r[c];
-    }
-    if (MODE != MODE_VDW) {
-        ac.v = (smallest_d2 < 1.0) ? __builtin_huge_val() : ac.v;      // src/probes.jl:116
-        float r[8];
-        gridpoint8(r, g.delta, out.lambda_coulomb, out.thr_coulomb, ac);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) smc[c * 64 + lane] = r[c];
-    }
-    __syncthreads();
+    // Staging is done: the record slice of a wave (64 x 80 or 64 x 48 B) holds 512 floats per grid -- both grids at once
+    // when it is large enough, else one grid after the other.
+    constexpr bool TWO_PASS = MODE == MODE_FUSED && sizeof(Rec) * 64 < 2 * 512 * sizeof(float);
     const int64_t nz = g.dims[2] + 1, ny = g.dims[1] + 1;
     constexpr int NSEG = 8 * 16 * NW;                 // 16-byte segments per grid in this workgroup
-    for (int seg = threadIdx.x; seg < NSEG; seg += CEG_WG) {
-        const int w = seg % NW;
-        const int row = seg / NW;                     // (channel, li, lj)
-        const int c = row >> 4, li = (row >> 2) & 3, lj = row & 3;
-        const int oi = s_org[w][0];
-        if (oi < 0) continue;
-        const int gi = oi + li, gj = s_org[w][1] + lj, gk = s_org[w][2];
-        if (gi >= out.i_end || gj > g.dims[1] || gk > g.dims[2]) continue;
-        const int64_t idx = (int64_t)gk + nz * ((int64_t)gj + ny * (int64_t)(gi - out.i_origin)) + (int64_t)c * out.channel_stride;
-        const int so = c * 64 + li * 16 + lj * 4;
-        const int nvalid = (g.dims[2] + 1 - gk) < 4 ? (g.dims[2] + 1 - gk) : 4;
-        if (MODE != MODE_COULOMB) {
-            const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(s_rec_all[w]) + so);
-            float* dst = out.vdw + idx;
-            if (nvalid == 4) store_float4_unaligned(dst, v);
-            else { dst[0] = v.x; if (nvalid > 1) dst[1] = v.y; if (nvalid > 2) dst[2] = v.z; }
+    if (MODE != MODE_VDW) ac.v = (smallest_d2 < 1.0) ? __builtin_huge_val() : ac.v;      // src/probes.jl:116
+#pragma unroll
+    for (int pass = 0; pass < (TWO_PASS ? 2 : 1); ++pass) {
+        const bool do_v = MODE != MODE_COULOMB && (!TWO_PASS || pass == 0);
+        const bool do_c = MODE != MODE_VDW && (!TWO_PASS || pass == 1);
+        const int off_c = (MODE == MODE_FUSED && !TWO_PASS) ? 512 : 0;
+        float* sm = reinterpret_cast<float*>(s_rec_all[wave]);
+        if (pass == 0) __builtin_amdgcn_wave_barrier(); else __syncthreads();      // readers of the previous contents are done
+        if (do_v) {
+            float r[8];
+            gridpoint8(r, g.delta, out.lambda_vdw, out.thr_vdw, av);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) sm[c * 64 + lane] = r[c];
         }
-        if (MODE != MODE_VDW) {
-            const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(s_rec_all[w]) + 512 + so);
-            float* dst = out.coulomb + idx;
-            if (nvalid == 4) store_float4_unaligned(dst, v);
-            else { dst[0] = v.x; if (nvalid > 1) dst[1] = v.y; if (nvalid > 2) dst[2] = v.z; }
+        if (do_c) {
+            float r[8];
+            gridpoint8(r, g.delta, out.lambda_coulomb, out.thr_coulomb, ac);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) sm[off_c + c * 64 + lane] = r[c];
+        }
+        __syncthreads();
+        for (int seg = threadIdx.x; seg < NSEG; seg += WG) {
+            const int w = seg % NW;
+            const int row = seg / NW;                     // (channel, li, lj)
+            const int c = row >> 4, li = (row >> 2) & 3, lj = row & 3;
+            const int oi = s_org[w][0];
+            if (oi < 0) continue;
+            const int gi = oi + li, gj = s_org[w][1] + lj, gk = s_org[w][2];
+            if (gi >= out.i_end || gj > g.dims[1] || gk > g.dims[2]) continue;
+            const int64_t idx = (int64_t)gk + nz * ((int64_t)gj + ny * (int64_t)(gi - out.i_origin)) + (int64_t)c * out.channel_stride;
+            const int so = c * 64 + li * 16 + lj * 4;
+            const int nvalid = (g.dims[2] + 1 - gk) < 4 ? (g.dims[2] + 1 - gk) : 4;
+            if (do_v) {
+                const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(s_rec_all[w]) + so);
+                float* dst = out.vdw + idx;
+                if (nvalid == 4) store_float4_unaligned(dst, v);
+                else { dst[0] = v.x; if (nvalid > 1) dst[1] = v.y; if (nvalid > 2) dst[2] = v.z; }
+            }
+            if (do_c) {
+                const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(s_rec_all[w]) + off_c + so);
+                float* dst = out.coulomb + idx;
+                if (nvalid == 4) store_float4_unaligned(dst, v);
+                else { dst[0] = v.x; if (nvalid > 1) dst[1] = v.y; if (nvalid > 2) dst[2] = v.z; }
+            }
         }
     }
 }
@@ -858,46 +1030,49 @@ hipError_t launch_bruteforce(int mode, const Geom& g, const AtomTable& atoms, co
 }
 
 template <int MODE, bool POINTS>
-static void launch_cull_flags(int vdwk, bool fastew, dim3 grid, dim3 block, hipStream_t stream,
-                              const PlanConst* pc, const Output& out, const Points& pts, int tj, int tk,
-                              int64_t ntiles)
+static hipError_t launch_cull_flags(int vdwk, int ewk, hipStream_t stream, const PlanConst* pc, const Output& out, const Points& pts,
+                                    int tj, int tk, int64_t ntiles)
 {
     // flags that do not matter for a mode are normalised so fewer variants get instantiated
-    if (MODE == MODE_VDW) fastew = true;
+    if (MODE == MODE_VDW) ewk = 1;
     if (MODE == MODE_COULOMB) vdwk = 1;
+    if (ewk == 2 && vdwk == 0) ewk = 1;          // the generic rule interpreter keeps the erfcx variant
+    if (vdwk == 3 && MODE == MODE_FUSED && ewk != 2) vdwk = 2;     // the tabulated Buckingham class is instantiated beside EWK = 2 only
+    const int nw = culled_nw(MODE, vdwk, ewk);
+    const int64_t nblocks = (ntiles + nw - 1) / nw;
+    if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)nblocks), block(64 * nw);
 #define CEG_LAUNCH(V, F) hipLaunchKernelGGL((k_culled<MODE, POINTS, V, F>), grid, block, 0, stream, pc, out, pts, tj, tk, ntiles)
-    if (fastew) {
-        if (vdwk == 1) CEG_LAUNCH(1, true); else if (vdwk == 2) CEG_LAUNCH(2, true); else CEG_LAUNCH(0, true);
+    if (ewk == 2 && MODE != MODE_VDW) {
+        if (vdwk == 1) CEG_LAUNCH(1, 2); else if (vdwk == 3) CEG_LAUNCH(3, 2); else CEG_LAUNCH(2, 2);
+    } else if (ewk) {
+        if (vdwk == 1) CEG_LAUNCH(1, 1); else if (vdwk == 2) CEG_LAUNCH(2, 1); else if (vdwk == 3) CEG_LAUNCH(3, 1); else CEG_LAUNCH(0, 1);
     } else {
-        if (vdwk == 1) CEG_LAUNCH(1, false); else if (vdwk == 2) CEG_LAUNCH(2, false); else CEG_LAUNCH(0, false);
+        if (vdwk == 1) CEG_LAUNCH(1, 0); else if (vdwk == 2) CEG_LAUNCH(2, 0); else if (vdwk == 3) CEG_LAUNCH(2, 0); else CEG_LAUNCH(0, 0);
     }
 #undef CEG_LAUNCH
-}
-
-template <bool POINTS>
-static hipError_t launch_cull_t(int mode, const PlanConst* pc, int vdwk, bool fastew, const Output& out,
-                                const Points& pts, int64_t ntiles, int tj, int tk, hipStream_t stream)
-{
-    if (ntiles <= 0) return hipSuccess;
-    constexpr int NW = CEG_WG / 64;
-    const int64_t nblocks = (ntiles + NW - 1) / NW;
-    if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    dim3 grid((unsigned)nblocks), block(CEG_WG);
-    switch (mode) {
-    case MODE_VDW: launch_cull_flags<MODE_VDW, POINTS>(vdwk, fastew, grid, block, stream, pc, out, pts, tj, tk, ntiles); break;
-    case MODE_COULOMB: launch_cull_flags<MODE_COULOMB, POINTS>(vdwk, fastew, grid, block, stream, pc, out, pts, tj, tk, ntiles); break;
-    default: launch_cull_flags<MODE_FUSED, POINTS>(vdwk, fastew, grid, block, stream, pc, out, pts, tj, tk, ntiles); break;
-    }
     return hipGetLastError();
 }
 
-hipError_t launch_culled(int mode, const PlanConst* d_pc, const Geom& g, int vdwk, bool fastew,
+template <bool POINTS>
+static hipError_t launch_cull_t(int mode, const PlanConst* pc, int vdwk, int ewk, const Output& out,
+                                const Points& pts, int64_t ntiles, int tj, int tk, hipStream_t stream)
+{
+    if (ntiles <= 0) return hipSuccess;
+    switch (mode) {
+    case MODE_VDW: return launch_cull_flags<MODE_VDW, POINTS>(vdwk, ewk, stream, pc, out, pts, tj, tk, ntiles);
+    case MODE_COULOMB: return launch_cull_flags<MODE_COULOMB, POINTS>(vdwk, ewk, stream, pc, out, pts, tj, tk, ntiles);
+    default: return launch_cull_flags<MODE_FUSED, POINTS>(vdwk, ewk, stream, pc, out, pts, tj, tk, ntiles);
+    }
+}
+
+hipError_t launch_culled(int mode, const PlanConst* d_pc, const Geom& g, int vdwk, int ewk,
                          const Output& out, const Points& pts, hipStream_t stream)
 {
-    if (pts.xyz) return launch_cull_t<true>(mode, d_pc, vdwk, fastew, out, pts, (pts.n + 63) / 64, 1, 1, stream);
+    if (pts.xyz) return launch_cull_t<true>(mode, d_pc, vdwk, ewk, out, pts, (pts.n + 63) / 64, 1, 1, stream);
     const int ni = out.i_end - out.i_begin;
     const int ti = (ni + 3) / 4, tj = (g.dims[1] + 1 + 3) / 4, tk = (g.dims[2] + 1 + 3) / 4;
-    return launch_cull_t<false>(mode, d_pc, vdwk, fastew, out, pts, (int64_t)ti * tj * tk, tj, tk, stream);
+    return launch_cull_t<false>(mode, d_pc, vdwk, ewk, out, pts, (int64_t)ti * tj * tk, tj, tk, stream);
 }
 
 }  // namespace ceg

@@ -217,8 +217,8 @@ def test_kernel_variants_off_the_fast_path(hip_lib, oracle, variant):
 
 def test_fast_math_accuracy_single_pair(hip_lib, oracle):
     """One atom, points at r in [2, 12) A in random directions: the culled kernel's hot-loop
-    arithmetic (v_rsq/v_rcp Newton steps, table exp, erfcx table, csrc/ceg_math.h) against the
-    oracle's libm, no cancellation between atoms -> 1e-12 relative on all 8 FP64 outputs."""
+    arithmetic (v_rsq/v_rcp Newton steps, table exp, r^2-indexed Ewald tables, csrc/ceg_math.h) against the
+    oracle's libm, no cancellation between atoms -> 1e-12 relative on all 8 FP64 outputs (Coulomb beyond 5.6 A: see below)."""
     L = 40.0
     mat = np.diag([L, L, L])
     cset = W.grid_setup_with_dims(mat, (15, 15, 15))
@@ -229,7 +229,7 @@ def test_fast_math_accuracy_single_pair(hip_lib, oracle):
     u /= np.linalg.norm(u, axis=1)[:, None]
     pts = centre + r[:, None] * u
     from scipy.ndimage import maximum_filter1d
-    for kind in (1, 4):
+    for kind in (1, 4, 2):          # LJ, LJ, Buckingham + hard sphere (the single tabulated Buckingham class of the culled kernel)
         pv, pc = synthetic_probes(mat, [centre], [kind], [0.9094])
         plan = GridPlan(cset, pv, pc, 0.26505830360350674)
         for which, ref in (("vdw", oracle.points_vdw(pv, pts)), ("coulomb", oracle.points_coulomb(pc, 0.26505830360350674, pts))):
@@ -239,8 +239,21 @@ def test_fast_math_accuracy_single_pair(hip_lib, oracle):
             # local magnitude of its column (+-0.1 A window along r), not against a zero crossing
             env = maximum_filter1d(np.abs(ref), size=81, axis=0, mode="nearest")
             rel = np.abs(got - ref) / env
-            print(f"fast-math max rel err {which} kind {kind}: {rel.max():.2e}")
-            assert rel.max() < 1e-12, (which, kind, float(rel.max()), int(np.argmax(rel.max(axis=1))))
+            # the same errors against a floor of 1 % of the column's largest magnitude: what a pair term can add to a sum
+            rel_sum = np.abs(got - ref) / np.maximum(env, 1e-2 * np.abs(ref).max(axis=0))
+            print(f"fast-math max rel err {which} kind {kind}: local {rel.max():.2e} (r < 8 A: {rel[r < 8.0].max():.2e}), "
+                  f"vs column scale {rel_sum.max():.2e}")
+            # VdW: 1e-12 everywhere.  Coulomb (r^2-indexed degree-6 tables, 32 intervals per octave of r^2): 1e-12 up to 8 A and
+            # against the column scale; the interpolation error grows to 1e-11 of the term itself at the cutoff, where the
+            # term is 1e-5 of its value at 2 A
+            if which == "vdw" and kind == 2:
+                # A exp(-B r) from an r^2-indexed degree-5 table: 2e-11 of the pair energy (the polynomial's error relative to
+                # exp(-B r) + C/r^6); the derivative columns pick up a few times that where the two parts cancel
+                assert rel.max() < 2e-10, (which, kind, float(rel.max()))
+                continue
+            tol_local = 1e-12 if which == "vdw" else 3e-11
+            assert rel.max() < tol_local, (which, kind, float(rel.max()), int(np.argmax(rel.max(axis=1))))
+            assert rel[r < 5.6].max() < 1.5e-12 and rel_sum.max() < 5e-12, (which, kind, float(rel_sum.max()))
         plan.close()
 
 

@@ -314,3 +314,21 @@ def test_grid_file_headers_match_committed_fixture(tmp_path):
         assert len(raw) == nh + 72
         assert raw[:nh].hex() == rec["header_hex"] and raw[nh:].hex() == rec["trailer_hex"], key
         assert rec["payload_bytes"] == 32 * int(np.prod(np.asarray(cset.dims) + 1))
+
+
+def test_scripts_compile_and_pair_work_count():
+    """bench.py / scripts only run on the GPU box: at least their syntax is checked here (Python 3.10).  The counted
+    minimum work of the roofline workload (bench.py's flop count) is reproducible: CHA density x cutoff sphere."""
+    import py_compile
+    root = Path(__file__).resolve().parent.parent
+    for f in [root / "bench.py", root / "__graft_entry__.py", *sorted((root / "scripts").glob("*.py")), *sorted((root / "tests" / "perf").glob("*.py"))]:
+        py_compile.compile(str(f), doraise=True)
+    from ceg_hip import workloads as W
+    w = W.roofline_workload("Ar", 255)
+    pw = W.count_pair_work(w, planes=3, stride=16)
+    rho = 972 / 22669.1405
+    assert abs(pw["in_cutoff_per_point"] - rho * 4 / 3 * math.pi * 12 ** 3) < 3.0          # SURVEY 8d: ~310
+    assert abs(pw["lj_per_point"] / pw["in_cutoff_per_point"] - 648 / 972) < 0.01            # only the O atoms carry an Ar rule
+    assert pw["buckingham_per_point"] == 0.0
+    pn = W.count_pair_work(W.roofline_workload("Na", 255), planes=3, stride=16)
+    assert pn["lj_per_point"] == 0.0 and abs(pn["buckingham_per_point"] - pw["lj_per_point"]) < 1e-9
