@@ -51,7 +51,8 @@ def parse_args():
     ap.add_argument("--probe", default="Ar", help="probe atom of the VdW grid (Ar: LJ; Na: Buckingham + hard sphere)")
     ap.add_argument("--algo", choices=("auto", "bruteforce", "culled"), default="auto")
     ap.add_argument("--gather", choices=("staged", "inplace", "p2p"), default="staged", help="how a gathered chunk is placed (N > 1)")
-    ap.add_argument("--chunks", type=int, default=4, help="x-chunks per rank pipelined with the all-gather (N > 1)")
+    ap.add_argument("--chunks", type=int, default=8,
+                    help="x-chunks per rank pipelined with the all-gather (N > 1); 8 from the exchange model of profiles/r02_rank_emulation.txt")
     ap.add_argument("--n", "--dims", dest="n", type=int, default=255, help="dims per axis (odd); grid has (n+1)^3 points")
     ap.add_argument("--cpu-rows", type=int, default=-1, help="y-rows per x-plane the CPU baseline times, one plane per thread (-1 = auto ~12 s, 0 = skip)")
     ap.add_argument("--no-check", action="store_true", help="skip the built-in oracle spot check")
@@ -247,19 +248,37 @@ def main():
         from oracle import oracle as O
         from oracle.compare import compare_grids
         from ceg_hip import grids as G
-        T = min(O.max_threads(), 16, nx)
-        i0, j0 = nx // 2 - T // 2, ny // 2
-        i1, j1 = i0 + T, min(ny, j0 + 2)
+        # x-planes to check: N = 1 -> a block in the middle; N > 1 -> one plane out of every rank's piece of the first and
+        # of the last chunk (a misplaced block of ANY rank shows), then both compared over two y-rows
+        if multi and cyc is not None:
+            planes = sorted({cyclic_plan(nx, world, r, nchunks=cyc.nchunks).chunk(j)[0] + (r % cyc.m) for r in range(world) for j in (0, cyc.nchunks - 1)})
+        elif multi:
+            planes = sorted({min(nx - 1, slab_range(nx, world, r)[0] + k) for r in range(world) for k in (0, 1)})
+        else:
+            T = min(O.usable_cpus(), 16, nx)
+            planes = list(range(nx // 2 - T // 2, nx // 2 - T // 2 + T))
+        planes = planes[:32]
+        j0 = ny // 2
+        j1 = min(ny, j0 + 2)
+        runs = []                                  # consecutive planes -> one oracle call each
+        for i in planes:
+            if runs and runs[-1][1] == i:
+                runs[-1][1] = i + 1
+            else:
+                runs.append([i, i + 1])
         worst = 0.0
-        if need_v:
-            lam, thr = G.vdw_scaling()
-            ref, _ = O.grid_vdw(w.probe_vdw, w.cset, lam, thr, i0, i1, j_begin=j0, j_end=j1)
-            worst = max(worst, compare_grids(full_v[:, i0:i1, j0:j1].cpu().numpy(), ref[:, i0:i1, j0:j1], "bench/vdw"))
-        if need_c:
-            lam, thr = G.coulomb_scaling()
-            ref, _ = O.grid_coulomb(w.probe_coulomb, w.alpha, w.cset, lam, thr, i0, i1, j_begin=j0, j_end=j1)
-            worst = max(worst, compare_grids(full_c[:, i0:i1, j0:j1].cpu().numpy(), ref[:, i0:i1, j0:j1], "bench/coulomb"))
-        check = {"points": (i1 - i0) * (j1 - j0) * nz, "max_rel_err": worst, "tol": 1e-6}
+        scratch = np.empty((8, nx, ny, nz), dtype=np.float32)
+        for i0, i1 in runs:
+            if need_v:
+                lam, thr = G.vdw_scaling()
+                ref, _ = O.grid_vdw(w.probe_vdw, w.cset, lam, thr, i0, i1, j_begin=j0, j_end=j1, out=scratch)
+                worst = max(worst, compare_grids(full_v[:, i0:i1, j0:j1].cpu().numpy(), ref[:, i0:i1, j0:j1], f"bench/vdw planes {i0}:{i1}"))
+            if need_c:
+                lam, thr = G.coulomb_scaling()
+                ref, _ = O.grid_coulomb(w.probe_coulomb, w.alpha, w.cset, lam, thr, i0, i1, j_begin=j0, j_end=j1, out=scratch)
+                worst = max(worst, compare_grids(full_c[:, i0:i1, j0:j1].cpu().numpy(), ref[:, i0:i1, j0:j1], f"bench/coulomb planes {i0}:{i1}"))
+        i0, i1 = 0, len(planes)
+        check = {"points": (i1 - i0) * (j1 - j0) * nz, "x_planes": planes, "max_rel_err": worst, "tol": 1e-6}
 
     if rank == 0:
         ms = elapsed / max(args.steps, 1) * 1e3

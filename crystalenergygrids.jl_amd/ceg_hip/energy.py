@@ -238,3 +238,94 @@ class GpuMonteCarloEnergy:
         if self.recip is not None:
             self.recip.close()
         self.pairs.close()
+
+
+class DeviceMonteCarlo:
+    """Device-resident energy state of a :class:`ceg_hip.montecarlo.MonteCarloSetup` (``ceg_mc_*``, BASELINE config 5):
+    ``movement_energy`` (montecarlo.jl:563-579) of a batch of trial placements in ONE launch, ``update_mc!``
+    (montecarlo.jl:615-628) applied on the device.  The MC driver (proposals, acceptance) stays with the caller."""
+
+    def __init__(self, mc, device: int = 0):
+        from .constants import COULOMBIC_CONVERSION_FACTOR
+        self._lib = _abi.load_library()
+        self.mc = mc
+        ff = mc.ff
+        nk = ff.nkinds
+        self.interp = [GridInterpolator(g, device) if (g is not None and g.ewald_precision == math.inf) else None
+                       for g in (mc.grids if mc.grids else [None] * nk)]
+        has_coulomb = bool(mc.grids) and mc.coulomb.ewald_precision != -math.inf
+        self.coulomb = GridInterpolator(mc.coulomb, device) if has_coulomb else None
+        handles = (C.c_void_p * nk)(*[it._h if it is not None else None for it in self.interp])
+        charge = np.ascontiguousarray([0.0 if (k + 1 >= len(mc.charges) or np.isnan(mc.charges[k + 1])) else float(mc.charges[k + 1])
+                                       for k in range(nk)], dtype=np.float64)
+        rules, offsets = ff.pair_table()
+        self._keep = (rules, offsets, handles, charge)
+        ef = mc.ewald
+        if ef.alpha != 0.0:
+            ijk = np.ascontiguousarray(ef.kvec_ijk, dtype=np.int32).reshape(-1)
+            kf = np.ascontiguousarray(ef.kfactors, dtype=np.float64)
+            re = np.ascontiguousarray(ef.StoreRigidChargeFramework.real, dtype=np.float64)
+            im = np.ascontiguousarray(ef.StoreRigidChargeFramework.imag, dtype=np.float64)
+            ks = np.asarray(ef.kspace.ks, dtype=np.int32)
+            einv = _matT(ef.invmat)
+            kargs = (_abi.i32ptr(ijk), _abi.dptr(kf), _abi.dptr(re), _abi.dptr(im), len(kf), _abi.i32ptr(ks), _abi.dptr(einv))
+        else:
+            kargs = (None, None, None, None, 0, None, None)
+        h = C.c_void_p()
+        rc = self._lib.ceg_mc_create(C.byref(h), device, handles, self.coulomb._h if self.coulomb is not None else None, _abi.dptr(charge), nk,
+                                     _abi.dptr(_matT(mc.mat)), _abi.dptr(_matT(mc.invmat)), ff.cutoff ** 2, rules.ctypes.data,
+                                     _abi.i32ptr(offsets), COULOMBIC_CONVERSION_FACTOR, *kargs)
+        _abi.check(self._lib, rc)
+        self._h = h
+        self.refresh()
+
+    def refresh(self) -> None:
+        """Upload the guests of ``self.mc`` (initial state, or after an insertion / deletion on the host side)."""
+        pos, kinds, first = [], [], [0]
+        for i, j, ids, p in self.mc.molecules():
+            pos.append(np.asarray(p, dtype=np.float64).reshape(-1, 3))
+            kinds += [k - 1 for k in ids]
+            first.append(first[-1] + len(ids))
+        pos = np.ascontiguousarray(np.concatenate(pos) if pos else np.empty((0, 3)), dtype=np.float64)
+        kinds = np.ascontiguousarray(kinds, dtype=np.int32)
+        first = np.ascontiguousarray(first, dtype=np.int32)
+        _abi.check(self._lib, self._lib.ceg_mc_set_guests(self._h, _abi.dptr(pos.reshape(-1)), _abi.i32ptr(kinds), _abi.i32ptr(first), len(first) - 1))
+
+    def trial(self, idx, positions) -> np.ndarray:
+        """-> float64[n + 1, 4]: row 0 movement_energy of molecule ``idx`` (0-based (kind, molecule)) where it is now, row 1 + t at
+        ``positions[t]``; columns (framework vdw, framework direct, inter, reciprocal)."""
+        mol = self.mc.flat_index(*idx)
+        m = len(self.mc.ffidx[idx[0]])
+        t = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, m, 3)
+        out = np.empty((len(t) + 1, 4), dtype=np.float64)
+        _abi.check(self._lib, self._lib.ceg_mc_trial(self._h, mol, _abi.dptr(t.reshape(-1)) if len(t) else None, len(t), _abi.dptr(out.reshape(-1))))
+        return out
+
+    def accept(self, idx, positions) -> None:
+        """update_mc!(mc, idx, positions) on the device (asynchronous).  The host-side ``mc`` is NOT touched."""
+        p = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1)
+        _abi.check(self._lib, self._lib.ceg_mc_accept(self._h, self.mc.flat_index(*idx), _abi.dptr(p)))
+
+    def state(self):
+        """(positions[natoms, 3], total guest structure factor complex[nk]) read back from the device."""
+        natoms = sum(len(ids) for _i, _j, ids, _p in self.mc.molecules())
+        nk = len(self.mc.ewald.kfactors) if self.mc.ewald.alpha != 0.0 else 0
+        pos = np.empty((natoms, 3)); re = np.empty(max(nk, 1)); im = np.empty(max(nk, 1))
+        _abi.check(self._lib, self._lib.ceg_mc_get_state(self._h, _abi.dptr(pos.reshape(-1)) if natoms else None, _abi.dptr(re), _abi.dptr(im)))
+        return pos, (re[:nk] + 1j * im[:nk])
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.ceg_mc_destroy(self._h)
+            self._h = None
+        for it in self.interp:
+            if it is not None:
+                it.close()
+        if self.coulomb is not None:
+            self.coulomb.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -273,6 +273,20 @@ def movement_energy(mc: MonteCarloSetup, idx: Tuple[int, int], positions=None) -
     return MCEnergyReport(fv, fd, single_contribution_vdw(mc, idx, poss), rec)
 
 
+def update_mc(mc: MonteCarloSetup, idx: Tuple[int, int], positions) -> None:
+    """update_mc! for a displacement (montecarlo.jl:615-628) with update_ewald_context! (ewald.jl:757-773): molecule ``idx``
+    now sits at ``positions``; sums[:, 1] += new - sums[:, ij+1]; sums[:, ij+1] = new."""
+    i, j = idx
+    pos = np.array(positions, dtype=np.float64).reshape(-1, 3)
+    if mc.ewald.alpha != 0.0:
+        assert mc.sums is not None, "Please call baseline_energy(mc) first"
+        col = 1 + mc.flat_index(i, j)
+        new = _molecule_sf(mc, mc.ffidx[i], pos)
+        mc.sums[:, 0] += new - mc.sums[:, col]
+        mc.sums[:, col] = new
+    mc.positions[i][j] = pos
+
+
 def setup_montecarlo(framework, pff, systems: Sequence[RASPASystem], *, blockfiles=None, gridstep: float = 0.15,
                      supercell=None, new: bool = False, cutoff: float = 12.0, ngpus: int = 1) -> MonteCarloSetup:
     """montecarlo.jl:266-323 + :70-216 for explicit rigid molecules (one entry of ``systems`` per

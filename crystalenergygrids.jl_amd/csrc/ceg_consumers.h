@@ -1,0 +1,195 @@
+// ceg_consumers.h -- device code shared by the grid-consumer kernels (rows f1-f3 of SURVEY 8f: ceg_interp.hip,
+// ceg_pairs.hip) and the fused Monte-Carlo trial kernel (ceg_mc.hip).  Not installed.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "../../include/ceg_hip.h"
+#include "ceg_internal.h"
+#include "ceg_math.h"
+
+namespace ceg_consumers {
+
+using ceg::DevRule;
+
+// ------------------------------------------------------------------ f1: tricubic interpolation
+struct InterpGeom {
+    double mat[9], invmat[9];
+    double size[3], shift[3];
+    int32_t dims[3];
+    int32_t is_vdw;
+};
+
+// 1-D cubic Hermite basis on [0,1]: value at 0, value at 1, slope at 0, slope at 1
+__device__ __forceinline__ void hermite(double t, double w[2][2])
+{
+    const double t2 = t * t, t3 = t2 * t;
+    w[0][0] = 2.0 * t3 - 3.0 * t2 + 1.0;     // f(0)
+    w[0][1] = -2.0 * t3 + 3.0 * t2;          // f(1)
+    w[1][0] = t3 - 2.0 * t2 + t;             // f'(0)
+    w[1][1] = t3 - t2;                       // f'(1)
+}
+
+// interpolate_grid (src/grids.jl:212-273) at one point of a node-major grid [x][y][z][8]
+__device__ __forceinline__ double interp_point(const InterpGeom& g, const float* __restrict__ grid, double px, double py, double pz)
+{
+    double sh[3];
+    {
+#pragma clang fp contract(off)
+        // wrap_atom: abc = invmat * p;  newpoint = mat * (abc - floor(abc))      coordinates.jl:58-61
+        const double* I = g.invmat;
+        const double* M = g.mat;
+        double a0 = (I[0] * px + I[3] * py) + I[6] * pz;
+        double a1 = (I[1] * px + I[4] * py) + I[7] * pz;
+        double a2 = (I[2] * px + I[5] * py) + I[8] * pz;
+        a0 -= floor(a0); a1 -= floor(a1); a2 -= floor(a2);
+        const double q0 = (M[0] * a0 + M[3] * a1) + M[6] * a2;
+        const double q1 = (M[1] * a0 + M[4] * a1) + M[7] * a2;
+        const double q2 = (M[2] * a0 + M[5] * a1) + M[8] * a2;
+        // offsetpoint: (newpoint - shift)*dims/size + 1                           coordinates.jl:63-66
+        sh[0] = (q0 - g.shift[0]) * (double)g.dims[0] / g.size[0] + 1.0;
+        sh[1] = (q1 - g.shift[1]) * (double)g.dims[1] / g.size[1] + 1.0;
+        sh[2] = (q2 - g.shift[2]) * (double)g.dims[2] / g.size[2] + 1.0;
+    }
+    const int nx = g.dims[0] + 1, ny = g.dims[1] + 1, nz = g.dims[2] + 1;
+    // p0 = floor.(Int, shifted);  p1 = p0 .+ (p0 != extent)   (1-based)           grids.jl:216-218
+    int p0[3], p1[3];
+    double r[3];
+    const int ext[3] = {nx, ny, nz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double f = floor(sh[a]);
+        int i0 = (int)f;
+        r[a] = sh[a] - f;
+        // memory safety only: a wrapped point always lands in [1, extent]
+        i0 = i0 < 1 ? 1 : (i0 > ext[a] ? ext[a] : i0);
+        p0[a] = i0;
+        p1[a] = i0 + (i0 != ext[a] ? 1 : 0);
+    }
+    // node-major layout [x][y][z][8 channels]: the 8 channels of a corner are 32 contiguous bytes and
+    // the two z neighbours of an (x, y) row 64 contiguous bytes
+    const int64_t sx = (int64_t)ny * nz, sy = nz;
+    const int64_t bx[2] = {(int64_t)(p0[0] - 1) * sx, (int64_t)(p1[0] - 1) * sx};
+    const int64_t by[2] = {(int64_t)(p0[1] - 1) * sy, (int64_t)(p1[1] - 1) * sy};
+    const int z0 = p0[2] - 1, z1 = p1[2] - 1;
+
+    double wx[2][2], wy[2][2], wz[2][2];
+    hermite(r[0], wx);
+    hermite(r[1], wy);
+    hermite(r[2], wz);
+
+    double ret = 0.0;
+    bool blocked = false;
+    const float4* g4 = reinterpret_cast<const float4*>(grid);
+#pragma unroll
+    for (int ax = 0; ax < 2; ++ax)
+#pragma unroll
+        for (int ay = 0; ay < 2; ++ay) {
+            const int64_t node0 = bx[ax] + by[ay] + z0, node1 = bx[ax] + by[ay] + z1;
+            const float4 a0 = g4[2 * node0], b0 = g4[2 * node0 + 1];      // channels 0-3, 4-7 at z0
+            const float4 a1 = g4[2 * node1], b1 = g4[2 * node1 + 1];      // ... at z1
+            blocked = blocked || (a0.x > 5e6f) || (a1.x > 5e6f);
+            // channels: value, dx, dy, dz, dxy, dxz, dyz, dxyz (derivatives pre-scaled by the grid step)
+            const double v0[8] = {a0.x, a0.y, a0.z, a0.w, b0.x, b0.y, b0.z, b0.w};
+            const double v1[8] = {a1.x, a1.y, a1.z, a1.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int ox = (c == 1 || c == 4 || c == 5 || c == 7) ? 1 : 0;
+                const int oy = (c == 2 || c == 4 || c == 6 || c == 7) ? 1 : 0;
+                const int oz = (c == 3 || c == 5 || c == 6 || c == 7) ? 1 : 0;
+                const double wxy = wx[ox][ax] * wy[oy][ay];
+                ret += wxy * (v0[c] * wz[oz][0] + v1[c] * wz[oz][1]);
+            }
+        }
+    // VdW grid with any corner value > 5e6 -> 1e100 K                             grids.jl:245-248
+    return (g.is_vdw && blocked) ? 1e100 : ret;
+}
+
+// ------------------------------------------------------------------ f3: pair rule energies
+// (rule::InteractionRule)(r2) -- src/interactions.jl:392-406 (r2 forms) and :367-390 (r forms)
+__device__ __forceinline__ double rule_energy(const DevRule& R, double r2, double coulombic)
+{
+#pragma clang fp contract(off)
+    double v;
+    switch (R.kind) {
+    case CEG_LENNARDJONES: {
+        const double s2 = R.p1 * R.p1;
+        const double q = s2 / r2;
+        const double x6 = q * q * q;
+        v = 4.0 * R.p0 * x6 * (x6 - 1.0);
+        break;
+    }
+    case CEG_HARDSPHERE: {
+        const double s = R.p0 + R.p1;
+        v = (r2 < s * s) ? __builtin_huge_val() : 0.0;
+        break;
+    }
+    case CEG_NOINTERACTION: v = 0.0; break;
+    case CEG_MONOMIAL: v = R.p0 / pow(r2, R.p1 / 2.0); break;
+    case CEG_COULOMB_EWALD_DIRECT: {
+        const double r = sqrt(r2);
+        v = coulombic * R.p1 * R.p2 * erfc(R.p0 * r) / r;
+        break;
+    }
+    case CEG_COULOMB: v = coulombic * R.p0 * R.p1 / sqrt(r2); break;
+    case CEG_BUCKINGHAM: {
+        const double r = sqrt(r2);
+        const double r3 = r * r * r;
+        v = R.p0 * exp(-R.p1 * r) - R.p2 / (r3 * r3);
+        break;
+    }
+    case CEG_EXPONENTIAL: v = R.p0 * exp(-R.p1 * sqrt(r2)); break;
+    default: v = __builtin_nan(""); break;          // UndefinedInteraction is refused at create time
+    }
+    return v - R.shift;
+}
+
+// Same energies with the shared sqrt / 1/r of the pair and the ceg_math.h functions (each <= 1.3e-13 relative):
+// valid for 0.25 A^2 <= r2 and alpha*r <= ERFCX_XMAX for every CoulombEwaldDirect rule (checked by the host);
+// closer pairs take rule_energy so that r -> 0 gives the reference's Inf / NaN.
+__device__ __forceinline__ double rule_energy_fast(const DevRule& R, double r2, double r, double rinv, double coulombic)
+{
+    double v;
+    switch (R.kind) {
+    case CEG_LENNARDJONES: {
+        const double q = (R.p1 * R.p1) * (rinv * rinv);
+        const double x6 = q * q * q;
+        v = 4.0 * R.p0 * x6 * (x6 - 1.0);
+        break;
+    }
+    case CEG_HARDSPHERE: {
+        const double s = R.p0 + R.p1;
+        v = (r2 < s * s) ? __builtin_huge_val() : 0.0;
+        break;
+    }
+    case CEG_NOINTERACTION: v = 0.0; break;
+    case CEG_COULOMB_EWALD_DIRECT: {
+        const double x = R.p0 * r;
+        v = (coulombic * R.p1 * R.p2) * (ceg::fast_exp_neg(-(x * x)) * ceg::erfcx_poly(x)) * rinv;
+        break;
+    }
+    case CEG_COULOMB: v = coulombic * R.p0 * R.p1 * rinv; break;
+    case CEG_BUCKINGHAM: {
+        const double i2 = rinv * rinv;
+        v = R.p0 * ceg::fast_exp_neg(-(R.p1 * r)) - R.p2 * (i2 * i2 * i2);
+        break;
+    }
+    case CEG_EXPONENTIAL: v = R.p0 * ceg::fast_exp_neg(-(R.p1 * r)); break;
+    default: return rule_energy(R, r2, coulombic);      // Monomial (pow) and anything else
+    }
+    return v - R.shift;
+}
+
+
+}  // namespace ceg_consumers
+
+// the interpolation handle (ceg_interp.hip owns its life cycle; ceg_mc.hip reads geometry and grid pointer)
+struct ceg_interp {
+    int device = 0;
+    ceg_consumers::InterpGeom g{};
+    const float* d_grid = nullptr;
+    float* owned = nullptr;
+};
+

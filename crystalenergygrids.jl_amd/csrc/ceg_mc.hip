@@ -1,0 +1,613 @@
+// ceg_mc.hip -- device-resident energy state of a Monte-Carlo run (BASELINE config 5; SURVEY 8f rows f1 + f2 + f3 fused):
+//
+//   movement_energy            src/montecarlo.jl:563-579   one launch per batch of trial placements of one molecule:
+//     framework_interactions     :490-504                     tricubic interpolation of the VdW grid of every atom + charge x Coulomb grid
+//     single_contribution_vdw    src/energy.jl:397-427        guest-guest pair rules against all other molecules
+//     single_contribution_ewald  src/ewald.jl:704-738         2 sum kf Re(conj(rest) S) + sum kf |S|^2, rest = framework + all guests - this one
+//   update_mc! / update_ewald_context!   src/montecarlo.jl:615-628, src/ewald.jl:757-773
+//                                                            on acceptance: positions, per-molecule and total structure factors
+//                                                            updated ON THE DEVICE (no host-built `rest`, no upload between moves)
+//   compute_ewald(::IncrementalEwaldContext) structure factors   src/ewald.jl:630-652 (sums[:,1], sums[:,ij+1])
+//
+// The guest atoms, the pair table, the k-space tables, the framework structure factor, the per-molecule structure
+// factors sums[:, ij+1] and their total sums[:, 1] live in device memory.  One workgroup (4 waves) evaluates one
+// placement: wave lanes 0..2m-1 interpolate, all threads fill the e^{2 pi i m f} tables and stride over the k-vectors,
+// all threads stride over the guest atoms for the pair sum; block 0 evaluates the molecule where it currently is
+// (with its stored structure factor, like the reference's `positions === nothing` branch).  Small batches travel
+// through a pinned, device-mapped host buffer: a batch-1 trial is ONE kernel launch and one stream synchronisation.
+// The MC driver (move proposal, acceptance rule, GCMC swaps) stays on the host, as in SURVEY 8f.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "../../include/ceg_hip.h"
+#include "ceg_consumers.h"
+
+using ceg::DevRule;
+using ceg_consumers::InterpGeom;
+using ceg_consumers::interp_point;
+using ceg_consumers::rule_energy;
+using ceg_consumers::rule_energy_fast;
+
+extern "C" void ceg_set_last_error_(const char* msg);
+
+namespace {
+
+constexpr int MC_MAX_ATOMS = 16;
+constexpr int MC_THREADS = 256;
+constexpr int MC_MAX_TAB = 400;                // (kx+1) + (2ky+1) + (2kz+1)
+constexpr size_t MC_MAPPED_BYTES = 1 << 20;    // batches up to this size go through the pinned, device-mapped buffers
+
+struct McGrid {
+    InterpGeom g;
+    const float* grid;        // node-major [x][y][z][8] in K; nullptr: zero grid (interpolate_grid returns 0, grids.jl:213)
+};
+
+// everything a kernel needs, by value (kernarg)
+struct McView {
+    double mat[9], invmat[9];                  // MC cell (pair distances, src/utils.jl:294-302)
+    double ew_invmat[9];                       // inverse of the Ewald supercell matrix
+    double cutoff2, coulombic;
+    int32_t nkinds, nrules, fast, table_in_lds;
+    int32_t ks[3], nk;
+    int32_t natoms, nmol;
+    const McGrid* vdw;                         // [nkinds]
+    McGrid coulomb;
+    const double* kind_charge;                 // [nkinds]
+    const DevRule* rules;
+    const int32_t* rule_offset;                // [nkinds*nkinds + 1]
+    const int32_t* ijk;                        // [3 nk]
+    const double* kf;                          // [nk]
+    const double2* sf_fw;                      // [nk] StoreRigidChargeFramework
+    double2* sf_tot;                           // [nk] sums[:, 1]
+    double2* sf_mol;                           // [nmol][nk] sums[:, ij+1]
+    double4* atoms;                            // x, y, z, (molecule << 32 | kind)
+    const int32_t* mol_first;                  // [nmol + 1] atoms of molecule j: [mol_first[j], mol_first[j+1])
+};
+
+struct McPositions { double xyz[MC_MAX_ATOMS * 3]; };
+
+__device__ __forceinline__ void unpack(double w, int& kind, int& mol)
+{
+    const long long bits = __double_as_longlong(w);
+    kind = (int)(bits & 0xffffffffll);
+    mol = (int)(bits >> 32);
+}
+
+// e^{2 pi i m f} tables of `m_atoms` atoms at s_pos (setup_Eik / move_one_system!, src/ewald.jl:109-146,352-366),
+// by sincospi of the exact angle; entry t of atom a at tab[a * stride + t]: t in [0, kx] -> x, then y (m = -ky..ky), then z
+__device__ __forceinline__ void fill_tables(const McView& v, const double* s_pos, int m_atoms, double2* tab, int stride, int tid, int nthreads)
+{
+    const int kx = v.ks[0], ky = v.ks[1], kz = v.ks[2];
+    const int nxp = kx + 1, nyp = 2 * ky + 1;
+    const double* I = v.ew_invmat;
+    for (int e = tid; e < m_atoms * stride; e += nthreads) {
+        const int a = e / stride, t = e - a * stride;
+        const double x = s_pos[3 * a], y = s_pos[3 * a + 1], z = s_pos[3 * a + 2];
+        double f;
+        int mm;
+        if (t < nxp) { f = I[0] * x + I[3] * y + I[6] * z; mm = t; }
+        else if (t < nxp + nyp) { f = I[1] * x + I[4] * y + I[7] * z; mm = t - nxp - ky; }
+        else { f = I[2] * x + I[5] * y + I[8] * z; mm = t - nxp - nyp - kz; }
+        const double ff = f - rint(f);
+        double s, c;
+        sincospi(2.0 * (double)mm * ff, &s, &c);
+        tab[e] = make_double2(c, s);
+    }
+}
+
+// structure factor of the molecule at k-vector q from the tables: sum_a q_a Ex[i] Ey[j] Ez[k]   (src/ewald.jl:148-185)
+__device__ __forceinline__ double2 molecule_sf(const McView& v, const double2* tab, int stride, const double* s_q, int m_atoms, int64_t q)
+{
+    const int ky = v.ks[1], kz = v.ks[2];
+    const int nxp = v.ks[0] + 1, nyp = 2 * ky + 1;
+    const int i = v.ijk[3 * q], j = v.ijk[3 * q + 1], k = v.ijk[3 * q + 2];
+    double sr = 0.0, si = 0.0;
+    for (int a = 0; a < m_atoms; ++a) {
+        const double2 ex = tab[a * stride + i];
+        const double2 ey = tab[a * stride + nxp + ky + j];
+        const double2 ez = tab[a * stride + nxp + nyp + kz + k];
+        const double yr = ey.x * ez.x - ey.y * ez.y, yi = ey.x * ez.y + ey.y * ez.x;
+        const double cr = s_q[a] * yr, ci = s_q[a] * yi;
+        sr += ex.x * cr - ex.y * ci;
+        si += ex.x * ci + ex.y * cr;
+    }
+    return make_double2(sr, si);
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(MC_THREADS) void k_mc_trial(McView v, int32_t molecule, const double* __restrict__ trial, int64_t n,
+                                                          double* __restrict__ out, int stride)
+{
+    // dynamic LDS: [m][stride] double2 tables, then (table_in_lds) the pair table
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    __shared__ double s_pos[MC_MAX_ATOMS * 3];
+    __shared__ double s_q[MC_MAX_ATOMS];
+    __shared__ int32_t s_kind[MC_MAX_ATOMS];
+    __shared__ double s_red[MC_THREADS / 64][5];
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x;                        // 0: where the molecule is now; b >= 1: trial b - 1
+    const int first = v.mol_first[molecule], m = v.mol_first[molecule + 1] - first;
+    double2* tab = reinterpret_cast<double2*>(s_raw);
+    const DevRule* rules = v.rules;
+    const int32_t* offset = v.rule_offset;
+    if (v.table_in_lds) {
+        DevRule* lr = reinterpret_cast<DevRule*>(s_raw + sizeof(double2) * (size_t)m * stride);
+        int32_t* lo = reinterpret_cast<int32_t*>(lr + (v.nrules > 0 ? v.nrules : 1));
+        for (int t = tid; t < v.nrules; t += MC_THREADS) lr[t] = v.rules[t];
+        for (int t = tid; t < v.nkinds * v.nkinds + 1; t += MC_THREADS) lo[t] = v.rule_offset[t];
+        rules = lr;
+        offset = lo;
+    }
+    if (tid < 3 * m) {
+        if (b == 0) {
+            const double4 A = v.atoms[first + tid / 3];
+            s_pos[tid] = (tid % 3 == 0) ? A.x : ((tid % 3 == 1) ? A.y : A.z);
+        } else {
+            s_pos[tid] = trial[(size_t)(b - 1) * m * 3 + tid];
+        }
+    }
+    if (tid < m) {
+        int kind, mol;
+        unpack(v.atoms[first + tid].w, kind, mol);
+        s_kind[tid] = kind;
+        s_q[tid] = v.kind_charge[kind];
+    }
+    __syncthreads();
+
+    double fv = 0.0, fd = 0.0, inter = 0.0, rs = 0.0, ss = 0.0;
+    // ---- framework_interactions (montecarlo.jl:490-504): thread 2a -> VdW grid of atom a, thread 2a+1 -> Coulomb grid
+    if (tid < 2 * m) {
+        const int a = tid >> 1;
+        const double px = s_pos[3 * a], py = s_pos[3 * a + 1], pz = s_pos[3 * a + 2];
+        if ((tid & 1) == 0) {
+            const McGrid G = v.vdw[s_kind[a]];
+            if (G.grid) fv = interp_point(G.g, G.grid, px, py, pz);
+        } else if (v.coulomb.grid) {
+            const double c = interp_point(v.coulomb.g, v.coulomb.grid, px, py, pz);
+            fd = (c == 1e100) ? c : s_q[a] * c;                       // :500
+        }
+    }
+    // ---- single_contribution_ewald (ewald.jl:704-738)
+    if (v.nk > 0) {
+        if (b != 0) fill_tables(v, s_pos, m, tab, stride, tid, MC_THREADS);
+        __syncthreads();
+        const double2* mine = v.sf_mol + (size_t)molecule * v.nk;
+        for (int64_t q = tid; q < v.nk; q += MC_THREADS) {
+            const double2 old = mine[q];
+            const double2 S = (b == 0) ? old : molecule_sf(v, tab, stride, s_q, m, q);
+            const double2 f = v.sf_fw[q], t = v.sf_tot[q];
+            const double rr = f.x + (t.x - old.x), ri = f.y + (t.y - old.y);      // rest = framework + (sums[:,1] - sums[:,ij+1])
+            const double kf = v.kf[q];
+            rs += kf * (rr * S.x + ri * S.y);
+            ss += kf * (S.x * S.x + S.y * S.y);
+        }
+    }
+    // ---- single_contribution_vdw (energy.jl:407-427)
+    if (v.table_in_lds) __syncthreads();
+    {
+        const double* M = v.mat;
+        const double* I = v.invmat;
+        for (int l = tid; l < v.natoms; l += MC_THREADS) {
+            const double4 A = v.atoms[l];
+            int kind1, mol;
+            unpack(A.w, kind1, mol);
+            if (mol == molecule) continue;                                  // :419
+            for (int a = 0; a < m; ++a) {
+                double r2;
+                {
+#pragma clang fp contract(off)
+                    const double dx = s_pos[3 * a] - A.x, dy = s_pos[3 * a + 1] - A.y, dz = s_pos[3 * a + 2] - A.z;
+                    double f0 = I[0] * dx + I[3] * dy + I[6] * dz;
+                    double f1 = I[1] * dx + I[4] * dy + I[7] * dz;
+                    double f2 = I[2] * dx + I[5] * dy + I[8] * dz;
+                    f0 = ((f0 + 0.5) - floor(f0 + 0.5)) - 0.5;
+                    f1 = ((f1 + 0.5) - floor(f1 + 0.5)) - 0.5;
+                    f2 = ((f2 + 0.5) - floor(f2 + 0.5)) - 0.5;
+                    const double vx = M[0] * f0 + M[3] * f1 + M[6] * f2;
+                    const double vy = M[1] * f0 + M[4] * f1 + M[7] * f2;
+                    const double vz = M[2] * f0 + M[5] * f1 + M[8] * f2;
+                    r2 = vx * vx + vy * vy + vz * vz;
+                }
+                if (!(r2 < v.cutoff2)) continue;                            // :422
+                const int t = kind1 * v.nkinds + s_kind[a];
+                if (FAST && r2 >= 0.25) {
+                    double r, rinv;
+                    ceg::fast_sqrt_rsqrt(r2, r, rinv);
+                    for (int q = offset[t]; q < offset[t + 1]; ++q) inter += rule_energy_fast(rules[q], r2, r, rinv, v.coulombic);
+                } else {
+                    for (int q = offset[t]; q < offset[t + 1]; ++q) inter += rule_energy(rules[q], r2, v.coulombic);
+                }
+            }
+        }
+    }
+    // ---- block reduction
+    double vals[5] = {fv, fd, inter, rs, ss};
+#pragma unroll
+    for (int c = 0; c < 5; ++c)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vals[c] += __shfl_xor(vals[c], o);
+    const int wave = tid >> 6, lane = tid & 63;
+    if (lane == 0)
+        for (int c = 0; c < 5; ++c) s_red[wave][c] = vals[c];
+    __syncthreads();
+    if (tid == 0) {
+        double tot[5] = {0, 0, 0, 0, 0};
+        for (int w = 0; w < MC_THREADS / 64; ++w)
+            for (int c = 0; c < 5; ++c) tot[c] += s_red[w][c];
+        out[4 * b + 0] = tot[0];
+        out[4 * b + 1] = tot[1];
+        out[4 * b + 2] = tot[2];
+        out[4 * b + 3] = 2.0 * tot[3] + tot[4];
+    }
+}
+
+// update_mc! for a displacement (montecarlo.jl:615-628): positions; sums[:,1] += new - sums[:,ij+1]; sums[:,ij+1] = new
+__global__ __launch_bounds__(MC_THREADS) void k_mc_accept(McView v, int32_t molecule, McPositions np, int stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    __shared__ double s_pos[MC_MAX_ATOMS * 3];
+    __shared__ double s_q[MC_MAX_ATOMS];
+    const int tid = threadIdx.x;
+    const int first = v.mol_first[molecule], m = v.mol_first[molecule + 1] - first;
+    if (tid < 3 * m) s_pos[tid] = np.xyz[tid];
+    if (tid < m) {
+        double4 A = v.atoms[first + tid];
+        int kind, mol;
+        unpack(A.w, kind, mol);
+        s_q[tid] = v.kind_charge[kind];
+        A.x = np.xyz[3 * tid]; A.y = np.xyz[3 * tid + 1]; A.z = np.xyz[3 * tid + 2];
+        v.atoms[first + tid] = A;
+    }
+    __syncthreads();
+    if (v.nk == 0) return;
+    double2* tab = reinterpret_cast<double2*>(s_raw);
+    fill_tables(v, s_pos, m, tab, stride, tid, MC_THREADS);
+    __syncthreads();
+    double2* mine = v.sf_mol + (size_t)molecule * v.nk;
+    for (int64_t q = tid; q < v.nk; q += MC_THREADS) {
+        const double2 S = molecule_sf(v, tab, stride, s_q, m, q);
+        const double2 old = mine[q];
+        double2 t = v.sf_tot[q];
+        t.x += S.x - old.x;
+        t.y += S.y - old.y;
+        v.sf_tot[q] = t;
+        mine[q] = S;
+    }
+}
+
+// sums[:, ij+1] of every molecule from its current positions (one workgroup per molecule)
+__global__ __launch_bounds__(MC_THREADS) void k_mc_sf_molecules(McView v, int stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    __shared__ double s_pos[MC_MAX_ATOMS * 3];
+    __shared__ double s_q[MC_MAX_ATOMS];
+    const int tid = threadIdx.x, molecule = blockIdx.x;
+    const int first = v.mol_first[molecule], m = v.mol_first[molecule + 1] - first;
+    if (tid < m) {
+        const double4 A = v.atoms[first + tid];
+        int kind, mol;
+        unpack(A.w, kind, mol);
+        s_q[tid] = v.kind_charge[kind];
+        s_pos[3 * tid] = A.x; s_pos[3 * tid + 1] = A.y; s_pos[3 * tid + 2] = A.z;
+    }
+    __syncthreads();
+    double2* tab = reinterpret_cast<double2*>(s_raw);
+    fill_tables(v, s_pos, m, tab, stride, tid, MC_THREADS);
+    __syncthreads();
+    double2* mine = v.sf_mol + (size_t)molecule * v.nk;
+    for (int64_t q = tid; q < v.nk; q += MC_THREADS) mine[q] = molecule_sf(v, tab, stride, s_q, m, q);
+}
+
+// sums[:, 1] = sum over the molecules, in molecule order
+__global__ void k_mc_sf_total(McView v)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= v.nk) return;
+    double sr = 0.0, si = 0.0;
+    for (int j = 0; j < v.nmol; ++j) {
+        const double2 s = v.sf_mol[(size_t)j * v.nk + q];
+        sr += s.x;
+        si += s.y;
+    }
+    v.sf_tot[q] = make_double2(sr, si);
+}
+
+int merr(int code, const char* msg)
+{
+    ceg_set_last_error_(msg);
+    return code;
+}
+
+struct Guard {
+    int prev = -1;
+    bool ok;
+    explicit Guard(int device)
+    {
+        (void)hipGetDevice(&prev);
+        ok = hipSetDevice(device) == hipSuccess;
+    }
+    ~Guard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+template <typename T>
+bool upload(T** dst, const T* src, size_t n)
+{
+    const size_t m = n > 0 ? n : 1;
+    if (hipMalloc((void**)dst, m * sizeof(T)) != hipSuccess) return false;
+    return n == 0 || hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice) == hipSuccess;
+}
+
+}  // namespace
+
+struct ceg_mc {
+    int device = 0;
+    McView v{};
+    hipStream_t stream = nullptr;
+    // owned device arrays
+    McGrid* d_vdw = nullptr;
+    double* d_charge = nullptr;
+    DevRule* d_rules = nullptr;
+    int32_t* d_offset = nullptr;
+    int32_t* d_ijk = nullptr;
+    double* d_kf = nullptr;
+    double2 *d_fw = nullptr, *d_tot = nullptr, *d_mol = nullptr;
+    double4* d_atoms = nullptr;
+    int32_t* d_first = nullptr;
+    int64_t atoms_cap = 0, mol_cap = 0;
+    std::vector<int32_t> h_first;
+    int stride = 0, max_m = 1;
+    // pinned, device-mapped staging for small batches; device scratch for large ones
+    double *h_in = nullptr, *h_out = nullptr, *dm_in = nullptr, *dm_out = nullptr;
+    double *d_in = nullptr, *d_out = nullptr;
+    size_t d_in_cap = 0, d_out_cap = 0;
+};
+
+extern "C" int ceg_mc_create(ceg_mc_t** handle, int32_t device, ceg_interp_t* const* vdw_grids, ceg_interp_t* coulomb_grid,
+                             const double* kind_charge, int32_t nkinds, const double mat[9], const double invmat[9], double cutoff2,
+                             const ceg_rule_t* rules, const int32_t* rule_offset, double coulombic, const int32_t* kvec_ijk,
+                             const double* kfactors, const double* sf_re, const double* sf_im, int64_t nk, const int32_t ks[3],
+                             const double ewald_invmat[9])
+{
+    if (!handle || !kind_charge || nkinds < 1 || nkinds > 4096 || !mat || !invmat || !rule_offset || !(cutoff2 > 0.0) || nk < 0)
+        return merr(CEG_ERR_INVALID, "bad argument");
+    *handle = nullptr;
+    if (nk > 0 && (!kvec_ijk || !kfactors || !sf_re || !sf_im || !ks || !ewald_invmat)) return merr(CEG_ERR_INVALID, "k-space tables missing");
+    if (nk > 0 && (ks[0] < 0 || ks[1] < 0 || ks[2] < 0 || ks[0] + 1 + 2 * ks[1] + 1 + 2 * ks[2] + 1 > MC_MAX_TAB))
+        return merr(CEG_ERR_UNSUPPORTED, "k-space box too large for the LDS tables");
+    for (int64_t q = 0; q < nk; ++q)
+        if (kvec_ijk[3 * q] < 0 || kvec_ijk[3 * q] > ks[0] || abs(kvec_ijk[3 * q + 1]) > ks[1] || abs(kvec_ijk[3 * q + 2]) > ks[2])
+            return merr(CEG_ERR_INVALID, "k-vector outside the (kx, ky, kz) box");
+    const int64_t nt = (int64_t)nkinds * nkinds;
+    if (rule_offset[0] != 0) return merr(CEG_ERR_INVALID, "rule_offset[0] must be 0");
+    for (int64_t t = 0; t < nt; ++t)
+        if (rule_offset[t + 1] < rule_offset[t]) return merr(CEG_ERR_INVALID, "rule_offset must be non-decreasing");
+    const int32_t nr = rule_offset[nt];
+    if (nr > 0 && !rules) return merr(CEG_ERR_INVALID, "rules missing");
+    std::vector<DevRule> dr((size_t)(nr > 0 ? nr : 1));
+    bool fast = true;
+    const double cutoff = std::sqrt(cutoff2);
+    for (int32_t q = 0; q < nr; ++q) {
+        const ceg_rule_t& r = rules[q];
+        if (r.kind < CEG_HARDSPHERE || r.kind > CEG_NOINTERACTION) return merr(CEG_ERR_INVALID, "unknown rule kind");
+        if (r.kind == CEG_UNDEFINED_INTERACTION) return merr(CEG_ERR_RULE, "Undefined interaction");
+        dr[q].kind = r.kind; dr[q]._pad = 0;
+        dr[q].p0 = r.p[0]; dr[q].p1 = r.p[1]; dr[q].p2 = r.p[2]; dr[q].shift = r.shift;
+        if (r.kind == CEG_COULOMB_EWALD_DIRECT && !(r.p[0] >= 0.0 && r.p[0] * cutoff <= 5.0 * (1.0 - 1e-9))) fast = false;
+        if ((r.kind == CEG_BUCKINGHAM || r.kind == CEG_EXPONENTIAL) && !(r.p[1] >= 0.0 && r.p[1] * cutoff <= 700.0)) fast = false;
+    }
+    if (ceg_device_count() <= 0) return merr(CEG_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= ceg_device_count()) return merr(CEG_ERR_NO_DEVICE, "device not present");
+    Guard guard(device);
+    if (!guard.ok) return merr(CEG_ERR_HIP, "hipSetDevice failed");
+    ceg_mc* h = new ceg_mc();
+    h->device = device;
+    McView& v = h->v;
+    for (int a = 0; a < 9; ++a) { v.mat[a] = mat[a]; v.invmat[a] = invmat[a]; v.ew_invmat[a] = nk > 0 ? ewald_invmat[a] : 0.0; }
+    v.cutoff2 = cutoff2; v.coulombic = coulombic; v.nkinds = nkinds; v.nrules = nr; v.fast = fast ? 1 : 0;
+    v.nk = (int32_t)nk;
+    for (int a = 0; a < 3; ++a) v.ks[a] = nk > 0 ? ks[a] : 0;
+    h->stride = nk > 0 ? ks[0] + 1 + 2 * ks[1] + 1 + 2 * ks[2] + 1 : 1;
+    std::vector<McGrid> grids((size_t)nkinds);
+    for (int32_t k = 0; k < nkinds; ++k) {
+        grids[k] = McGrid{};
+        if (vdw_grids && vdw_grids[k]) {
+            if (vdw_grids[k]->device != device) { delete h; return merr(CEG_ERR_INVALID, "grid handle lives on another device"); }
+            grids[k].g = vdw_grids[k]->g;
+            grids[k].grid = vdw_grids[k]->d_grid;
+        }
+    }
+    v.coulomb = McGrid{};
+    if (coulomb_grid) {
+        if (coulomb_grid->device != device) { delete h; return merr(CEG_ERR_INVALID, "grid handle lives on another device"); }
+        v.coulomb.g = coulomb_grid->g;
+        v.coulomb.grid = coulomb_grid->d_grid;
+    }
+    std::vector<double2> fw((size_t)(nk > 0 ? nk : 1));
+    for (int64_t q = 0; q < nk; ++q) fw[q] = make_double2(sf_re[q], sf_im[q]);
+    const size_t table_bytes = sizeof(DevRule) * dr.size() + sizeof(int32_t) * (size_t)(nt + 1);
+    v.table_in_lds = table_bytes <= 32 * 1024 ? 1 : 0;
+    bool ok = upload(&h->d_vdw, grids.data(), grids.size()) && upload(&h->d_charge, kind_charge, (size_t)nkinds) &&
+              upload(&h->d_rules, dr.data(), dr.size()) && upload(&h->d_offset, rule_offset, (size_t)(nt + 1)) &&
+              upload(&h->d_ijk, kvec_ijk, (size_t)(3 * nk)) && upload(&h->d_kf, kfactors, (size_t)nk) &&
+              upload(&h->d_fw, fw.data(), (size_t)nk) && upload(&h->d_tot, fw.data(), (size_t)nk);
+    ok = ok && hipMemset(h->d_tot, 0, sizeof(double2) * (size_t)(nk > 0 ? nk : 1)) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&h->h_in, MC_MAPPED_BYTES, hipHostMallocMapped) == hipSuccess &&
+         hipHostMalloc((void**)&h->h_out, MC_MAPPED_BYTES, hipHostMallocMapped) == hipSuccess &&
+         hipHostGetDevicePointer((void**)&h->dm_in, h->h_in, 0) == hipSuccess &&
+         hipHostGetDevicePointer((void**)&h->dm_out, h->h_out, 0) == hipSuccess;
+    if (!ok) {
+        ceg_mc_destroy(h);
+        return merr(CEG_ERR_HIP, "could not allocate the Monte-Carlo state on the device");
+    }
+    v.vdw = h->d_vdw; v.kind_charge = h->d_charge; v.rules = h->d_rules; v.rule_offset = h->d_offset;
+    v.ijk = h->d_ijk; v.kf = h->d_kf; v.sf_fw = h->d_fw; v.sf_tot = h->d_tot;
+    *handle = h;
+    return CEG_OK;
+}
+
+extern "C" int ceg_mc_destroy(ceg_mc_t* h)
+{
+    if (!h) return CEG_OK;
+    Guard guard(h->device);
+    if (guard.ok) {
+        if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+        for (void* p : {(void*)h->d_vdw, (void*)h->d_charge, (void*)h->d_rules, (void*)h->d_offset, (void*)h->d_ijk, (void*)h->d_kf,
+                        (void*)h->d_fw, (void*)h->d_tot, (void*)h->d_mol, (void*)h->d_atoms, (void*)h->d_first, (void*)h->d_in, (void*)h->d_out})
+            if (p) (void)hipFree(p);
+        if (h->h_in) (void)hipHostFree(h->h_in);
+        if (h->h_out) (void)hipHostFree(h->h_out);
+    }
+    delete h;
+    return CEG_OK;
+}
+
+extern "C" int ceg_mc_set_guests(ceg_mc_t* h, const double* positions, const int32_t* kinds, const int32_t* mol_first, int32_t nmol)
+{
+    if (!h || nmol < 0 || !mol_first || mol_first[0] != 0) return merr(CEG_ERR_INVALID, "bad argument");
+    for (int32_t j = 0; j < nmol; ++j) {
+        const int32_t m = mol_first[j + 1] - mol_first[j];
+        if (m < 1) return merr(CEG_ERR_INVALID, "empty molecule");
+        if (m > MC_MAX_ATOMS) return merr(CEG_ERR_UNSUPPORTED, "molecule has more atoms than the kernels hold in LDS (16)");
+    }
+    const int64_t natoms = mol_first[nmol];
+    if (natoms > 0 && (!positions || !kinds)) return merr(CEG_ERR_INVALID, "bad argument");
+    std::vector<double4> host((size_t)(natoms > 0 ? natoms : 1));
+    for (int32_t j = 0; j < nmol; ++j)
+        for (int32_t l = mol_first[j]; l < mol_first[j + 1]; ++l) {
+            if (kinds[l] < 0 || kinds[l] >= h->v.nkinds) return merr(CEG_ERR_INVALID, "atom kind outside the pair table");
+            const long long bits = ((long long)j << 32) | (long long)(uint32_t)kinds[l];
+            double w;
+            memcpy(&w, &bits, sizeof(w));
+            host[l] = make_double4(positions[3 * l], positions[3 * l + 1], positions[3 * l + 2], w);
+        }
+    Guard guard(h->device);
+    if (!guard.ok) return merr(CEG_ERR_HIP, "hipSetDevice failed");
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return merr(CEG_ERR_HIP, "stream synchronisation failed");
+    bool ok = true;
+    if (natoms > h->atoms_cap) {
+        if (h->d_atoms) (void)hipFree(h->d_atoms);
+        h->d_atoms = nullptr;
+        h->atoms_cap = natoms + natoms / 2 + 64;
+        ok = hipMalloc((void**)&h->d_atoms, sizeof(double4) * (size_t)h->atoms_cap) == hipSuccess;
+    }
+    if (ok && nmol > h->mol_cap) {
+        if (h->d_mol) (void)hipFree(h->d_mol);
+        if (h->d_first) (void)hipFree(h->d_first);
+        h->d_mol = nullptr; h->d_first = nullptr;
+        h->mol_cap = nmol + nmol / 2 + 16;
+        ok = hipMalloc((void**)&h->d_mol, sizeof(double2) * (size_t)h->mol_cap * (size_t)(h->v.nk > 0 ? h->v.nk : 1)) == hipSuccess &&
+             hipMalloc((void**)&h->d_first, sizeof(int32_t) * (size_t)(h->mol_cap + 1)) == hipSuccess;
+    }
+    if (!ok) { h->atoms_cap = 0; h->mol_cap = 0; return merr(CEG_ERR_HIP, "could not allocate the guest arrays"); }
+    if (natoms > 0) ok = hipMemcpy(h->d_atoms, host.data(), sizeof(double4) * (size_t)natoms, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(h->d_first, mol_first, sizeof(int32_t) * (size_t)(nmol + 1), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) return merr(CEG_ERR_HIP, "could not upload the guest atoms");
+    h->h_first.assign(mol_first, mol_first + nmol + 1);
+    h->max_m = 1;
+    for (int32_t j = 0; j < nmol; ++j) h->max_m = std::max(h->max_m, mol_first[j + 1] - mol_first[j]);
+    if (sizeof(double2) * (size_t)h->max_m * (size_t)h->stride > 64 * 1024) return merr(CEG_ERR_UNSUPPORTED, "k-space tables of a molecule do not fit in LDS");
+    McView& v = h->v;
+    v.atoms = h->d_atoms; v.mol_first = h->d_first; v.sf_mol = h->d_mol; v.natoms = (int32_t)natoms; v.nmol = nmol;
+    if (v.nk > 0) {
+        if (nmol > 0)
+            hipLaunchKernelGGL(k_mc_sf_molecules, dim3((unsigned)nmol), dim3(MC_THREADS), sizeof(double2) * (size_t)h->max_m * (size_t)h->stride,
+                               h->stream, v, h->stride);
+        hipLaunchKernelGGL(k_mc_sf_total, dim3((unsigned)((v.nk + 255) / 256)), dim3(256), 0, h->stream, v);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
+            return merr(CEG_ERR_HIP, "structure-factor kernels failed");
+    }
+    return CEG_OK;
+}
+
+extern "C" int ceg_mc_trial(ceg_mc_t* h, int32_t molecule, const double* trial, int64_t n, double* out)
+{
+    if (!h || n < 0 || !out || (n > 0 && !trial)) return merr(CEG_ERR_INVALID, "bad argument");
+    if (molecule < 0 || molecule >= h->v.nmol) return merr(CEG_ERR_INVALID, "no such molecule");
+    const int m = h->h_first[molecule + 1] - h->h_first[molecule];
+    const size_t in_bytes = sizeof(double) * 3 * (size_t)m * (size_t)n, out_bytes = sizeof(double) * 4 * (size_t)(n + 1);
+    if (n + 1 > 0x7fffffffLL) return merr(CEG_ERR_INVALID, "too many placements");
+    Guard guard(h->device);
+    if (!guard.ok) return merr(CEG_ERR_HIP, "hipSetDevice failed");
+    const bool mapped = in_bytes <= MC_MAPPED_BYTES && out_bytes <= MC_MAPPED_BYTES;
+    const double* d_in;
+    double* d_out;
+    if (mapped) {
+        if (n > 0) memcpy(h->h_in, trial, in_bytes);
+        d_in = h->dm_in;
+        d_out = h->dm_out;
+    } else {
+        if (in_bytes > h->d_in_cap) {
+            if (h->d_in) (void)hipFree(h->d_in);
+            h->d_in = nullptr; h->d_in_cap = 0;
+            if (hipMalloc((void**)&h->d_in, in_bytes) != hipSuccess) return merr(CEG_ERR_HIP, "hipMalloc failed");
+            h->d_in_cap = in_bytes;
+        }
+        if (out_bytes > h->d_out_cap) {
+            if (h->d_out) (void)hipFree(h->d_out);
+            h->d_out = nullptr; h->d_out_cap = 0;
+            if (hipMalloc((void**)&h->d_out, out_bytes) != hipSuccess) return merr(CEG_ERR_HIP, "hipMalloc failed");
+            h->d_out_cap = out_bytes;
+        }
+        if (hipMemcpyAsync(h->d_in, trial, in_bytes, hipMemcpyHostToDevice, h->stream) != hipSuccess) return merr(CEG_ERR_HIP, "H2D failed");
+        d_in = h->d_in;
+        d_out = h->d_out;
+    }
+    McView v = h->v;
+    size_t table_bytes = v.table_in_lds ? sizeof(DevRule) * (size_t)(v.nrules > 0 ? v.nrules : 1) + sizeof(int32_t) * ((size_t)v.nkinds * v.nkinds + 1) : 0;
+    if (sizeof(double2) * (size_t)m * (size_t)h->stride + table_bytes > 64 * 1024) { v.table_in_lds = 0; table_bytes = 0; }   // pair table from global memory then
+    const size_t lds = sizeof(double2) * (size_t)m * (size_t)h->stride + table_bytes;
+    const dim3 grid((unsigned)(n + 1)), block(MC_THREADS);
+    if (v.fast)
+        hipLaunchKernelGGL((k_mc_trial<true>), grid, block, lds, h->stream, v, molecule, d_in, n, d_out, h->stride);
+    else
+        hipLaunchKernelGGL((k_mc_trial<false>), grid, block, lds, h->stream, v, molecule, d_in, n, d_out, h->stride);
+    if (hipGetLastError() != hipSuccess) return merr(CEG_ERR_HIP, "trial kernel launch failed");
+    if (!mapped && hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return merr(CEG_ERR_HIP, "D2H failed");
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return merr(CEG_ERR_HIP, "trial kernel failed");
+    if (mapped) memcpy(out, h->h_out, out_bytes);
+    return CEG_OK;
+}
+
+extern "C" int ceg_mc_accept(ceg_mc_t* h, int32_t molecule, const double* positions)
+{
+    if (!h || !positions) return merr(CEG_ERR_INVALID, "bad argument");
+    if (molecule < 0 || molecule >= h->v.nmol) return merr(CEG_ERR_INVALID, "no such molecule");
+    const int m = h->h_first[molecule + 1] - h->h_first[molecule];
+    McPositions np{};
+    for (int t = 0; t < 3 * m; ++t) np.xyz[t] = positions[t];
+    Guard guard(h->device);
+    if (!guard.ok) return merr(CEG_ERR_HIP, "hipSetDevice failed");
+    hipLaunchKernelGGL(k_mc_accept, dim3(1), dim3(MC_THREADS), sizeof(double2) * (size_t)m * (size_t)h->stride, h->stream, h->v, molecule, np,
+                       h->stride);
+    if (hipGetLastError() != hipSuccess) return merr(CEG_ERR_HIP, "accept kernel launch failed");
+    return CEG_OK;                      // asynchronous: the next ceg_mc_trial on this handle is ordered behind it
+}
+
+extern "C" int ceg_mc_get_state(ceg_mc_t* h, double* positions, double* sf_total_re, double* sf_total_im)
+{
+    if (!h) return merr(CEG_ERR_INVALID, "bad argument");
+    Guard guard(h->device);
+    if (!guard.ok) return merr(CEG_ERR_HIP, "hipSetDevice failed");
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return merr(CEG_ERR_HIP, "stream synchronisation failed");
+    if (positions && h->v.natoms > 0) {
+        std::vector<double4> host((size_t)h->v.natoms);
+        if (hipMemcpy(host.data(), h->d_atoms, sizeof(double4) * host.size(), hipMemcpyDeviceToHost) != hipSuccess) return merr(CEG_ERR_HIP, "D2H failed");
+        for (size_t l = 0; l < host.size(); ++l) { positions[3 * l] = host[l].x; positions[3 * l + 1] = host[l].y; positions[3 * l + 2] = host[l].z; }
+    }
+    if ((sf_total_re || sf_total_im) && h->v.nk > 0) {
+        std::vector<double2> t((size_t)h->v.nk);
+        if (hipMemcpy(t.data(), h->d_tot, sizeof(double2) * t.size(), hipMemcpyDeviceToHost) != hipSuccess) return merr(CEG_ERR_HIP, "D2H failed");
+        for (size_t q = 0; q < t.size(); ++q) {
+            if (sf_total_re) sf_total_re[q] = t[q].x;
+            if (sf_total_im) sf_total_im[q] = t[q].y;
+        }
+    }
+    return CEG_OK;
+}

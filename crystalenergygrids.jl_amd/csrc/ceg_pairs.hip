@@ -16,8 +16,11 @@
 #include "../../include/ceg_hip.h"
 #include "ceg_internal.h"
 #include "ceg_math.h"
+#include "ceg_consumers.h"
 
 using ceg::DevRule;
+using ceg_consumers::rule_energy;
+using ceg_consumers::rule_energy_fast;
 
 extern "C" void ceg_set_last_error_(const char* msg);
 
@@ -32,80 +35,6 @@ struct PairsGeom {
     int32_t nkinds, m, exclude;
     int32_t kinds[PAIRS_MAX_ATOMS];
 };
-
-// (rule::InteractionRule)(r2) -- src/interactions.jl:392-406 (r2 forms) and :367-390 (r forms)
-__device__ __forceinline__ double rule_energy(const DevRule& R, double r2, double coulombic)
-{
-#pragma clang fp contract(off)
-    double v;
-    switch (R.kind) {
-    case CEG_LENNARDJONES: {
-        const double s2 = R.p1 * R.p1;
-        const double q = s2 / r2;
-        const double x6 = q * q * q;
-        v = 4.0 * R.p0 * x6 * (x6 - 1.0);
-        break;
-    }
-    case CEG_HARDSPHERE: {
-        const double s = R.p0 + R.p1;
-        v = (r2 < s * s) ? __builtin_huge_val() : 0.0;
-        break;
-    }
-    case CEG_NOINTERACTION: v = 0.0; break;
-    case CEG_MONOMIAL: v = R.p0 / pow(r2, R.p1 / 2.0); break;
-    case CEG_COULOMB_EWALD_DIRECT: {
-        const double r = sqrt(r2);
-        v = coulombic * R.p1 * R.p2 * erfc(R.p0 * r) / r;
-        break;
-    }
-    case CEG_COULOMB: v = coulombic * R.p0 * R.p1 / sqrt(r2); break;
-    case CEG_BUCKINGHAM: {
-        const double r = sqrt(r2);
-        const double r3 = r * r * r;
-        v = R.p0 * exp(-R.p1 * r) - R.p2 / (r3 * r3);
-        break;
-    }
-    case CEG_EXPONENTIAL: v = R.p0 * exp(-R.p1 * sqrt(r2)); break;
-    default: v = __builtin_nan(""); break;          // UndefinedInteraction is refused at create time
-    }
-    return v - R.shift;
-}
-
-// Same energies with the shared sqrt / 1/r of the pair and the ceg_math.h functions (each <= 1.3e-13 relative):
-// valid for 0.25 A^2 <= r2 and alpha*r <= ERFCX_XMAX for every CoulombEwaldDirect rule (checked by the host);
-// closer pairs take rule_energy so that r -> 0 gives the reference's Inf / NaN.
-__device__ __forceinline__ double rule_energy_fast(const DevRule& R, double r2, double r, double rinv, double coulombic)
-{
-    double v;
-    switch (R.kind) {
-    case CEG_LENNARDJONES: {
-        const double q = (R.p1 * R.p1) * (rinv * rinv);
-        const double x6 = q * q * q;
-        v = 4.0 * R.p0 * x6 * (x6 - 1.0);
-        break;
-    }
-    case CEG_HARDSPHERE: {
-        const double s = R.p0 + R.p1;
-        v = (r2 < s * s) ? __builtin_huge_val() : 0.0;
-        break;
-    }
-    case CEG_NOINTERACTION: v = 0.0; break;
-    case CEG_COULOMB_EWALD_DIRECT: {
-        const double x = R.p0 * r;
-        v = (coulombic * R.p1 * R.p2) * (ceg::fast_exp_neg(-(x * x)) * ceg::erfcx_poly(x)) * rinv;
-        break;
-    }
-    case CEG_COULOMB: v = coulombic * R.p0 * R.p1 * rinv; break;
-    case CEG_BUCKINGHAM: {
-        const double i2 = rinv * rinv;
-        v = R.p0 * ceg::fast_exp_neg(-(R.p1 * r)) - R.p2 * (i2 * i2 * i2);
-        break;
-    }
-    case CEG_EXPONENTIAL: v = R.p0 * ceg::fast_exp_neg(-(R.p1 * r)); break;
-    default: return rule_energy(R, r2, coulombic);      // Monomial (pow) and anything else
-    }
-    return v - R.shift;
-}
 
 template <bool FAST, bool TABLE_IN_LDS>
 __global__ __launch_bounds__(64 * PAIRS_WAVES) void k_pairs(PairsGeom g, const DevRule* __restrict__ g_rules,

@@ -331,6 +331,50 @@ CEG_API int ceg_pairs_energy(ceg_pairs_t* handle, const double* trial, const int
 CEG_API int ceg_pairs_energy_device(ceg_pairs_t* handle, const double* d_trial, const int32_t* trial_kinds,
                                     int32_t m, int64_t n, int32_t exclude_molecule, double* d_out, void* stream);
 
+/* ---- device-resident Monte-Carlo energy state (BASELINE config 5: f1 + f2 + f3 in one launch) ---- */
+/*
+ * movement_energy (src/montecarlo.jl:563-579) of one rigid molecule of a MonteCarloSetup for a batch of trial
+ * placements, from state that lives on the device: guest atoms, pair table, k-space tables, the framework
+ * structure factor, the per-molecule structure factors sums[:, ij+1] and their total sums[:, 1] of the reference's
+ * IncrementalEwaldContext (src/ewald.jl:584-652).  One kernel launch evaluates, per placement,
+ *   framework_interactions    (montecarlo.jl:490-504)  sum_atoms interpolate_grid(vdw grid of the atom's kind) and
+ *                                                      sum_atoms charge * interpolate_grid(coulomb grid) (1e100 kept)
+ *   single_contribution_vdw   (energy.jl:407-427)      against every guest atom of the OTHER molecules
+ *   single_contribution_ewald (ewald.jl:704-738)       2 sum kf Re(conj(rest) S) + sum kf |S|^2,
+ *                                                      rest = framework + sums[:,1] - sums[:,ij+1]
+ * and ceg_mc_accept applies update_mc! / update_ewald_context! (montecarlo.jl:615-628, ewald.jl:757-773) on the
+ * device: no host-built structure factor is uploaded between moves.  Molecules are rigid, <= 16 atoms; insertion and
+ * deletion (GCMC swaps) go through ceg_mc_set_guests.
+ *
+ *  vdw_grids    [nkinds] interpolation handles by 0-based force-field index, NULL where the kind has no grid / a zero grid;
+ *               coulomb_grid NULL when the framework carries no charges.  The handles must outlive this object.
+ *  kind_charge  [nkinds] e;  mat, invmat: MC cell (= supercell), column-major;  rules / rule_offset / coulombic as ceg_pairs_create
+ *  kvec_ijk, kfactors, sf_re, sf_im, nk, ks, ewald_invmat as ceg_recip_create (nk = 0: no Ewald summation)
+ */
+typedef struct ceg_mc ceg_mc_t;
+
+CEG_API int ceg_mc_create(ceg_mc_t** handle, int32_t device, ceg_interp_t* const* vdw_grids, ceg_interp_t* coulomb_grid,
+                          const double* kind_charge, int32_t nkinds, const double mat[9], const double invmat[9],
+                          double cutoff2, const ceg_rule_t* rules, const int32_t* rule_offset, double coulombic,
+                          const int32_t* kvec_ijk, const double* kfactors, const double* sf_re, const double* sf_im,
+                          int64_t nk, const int32_t ks[3], const double ewald_invmat[9]);
+CEG_API int ceg_mc_destroy(ceg_mc_t* handle);
+/* the guests currently in the system, molecule j = atoms [mol_first[j], mol_first[j+1]) (mol_first[0] = 0):
+ * positions [3*natoms] A, kinds [natoms] 0-based ff index.  Computes every sums[:, ij+1] and sums[:, 1] on the device
+ * (compute_ewald(::IncrementalEwaldContext), ewald.jl:630-652).  Synchronous. */
+CEG_API int ceg_mc_set_guests(ceg_mc_t* handle, const double* positions, const int32_t* kinds,
+                              const int32_t* mol_first, int32_t nmol);
+/* trial [n][m][3] A placements of molecule `molecule` (m = its atom count); out [(n+1)][4] K:
+ * row 0 = movement_energy where the molecule is now, row 1+t = at trial t; columns framework vdw, framework direct,
+ * guest-guest, reciprocal.  Host memory; one launch + one stream synchronisation (small batches travel through pinned,
+ * device-mapped buffers). */
+CEG_API int ceg_mc_trial(ceg_mc_t* handle, int32_t molecule, const double* trial, int64_t n, double* out);
+/* the molecule now sits at positions [m][3]: update_mc! on the device.  Asynchronous; later calls on this handle are
+ * ordered behind it. */
+CEG_API int ceg_mc_accept(ceg_mc_t* handle, int32_t molecule, const double* positions);
+/* read back (any pointer may be NULL): positions [3*natoms], total guest structure factor sums[:, 1] as re / im [nk] */
+CEG_API int ceg_mc_get_state(ceg_mc_t* handle, double* positions, double* sf_total_re, double* sf_total_im);
+
 /* ---- blocking masks on the grid lattice ----------------------------- */
 /*
  * BlockFile(g::EnergyGrid), src/grids.jl:188-204: a lattice cell (i, j, k), i < dims[0] etc., whose

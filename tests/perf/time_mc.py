@@ -1,0 +1,76 @@
+"""BASELINE config 5 at the granularity the reference runs it: latency of ONE movement_energy evaluation on the
+device-resident Monte-Carlo state (ceg_mc_trial: before + after in one launch), and of batches of 16 and 1024 trial
+placements, with the device-side update (ceg_mc_accept) between moves; beside it the CPU oracle (C, one thread) doing the
+same three sums for one placement.  CHA + Na framework (1107 atoms, 0.15 A grids built by the HIP kernels), 64 CO2 guests."""
+import os, sys, time, tempfile
+here = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(here, '..', '..', 'crystalenergygrids.jl_amd'), os.path.join(here, '..', '..')]
+import numpy as np
+import ceg_hip as ceg
+from ceg_hip import montecarlo as M, workloads as W
+from ceg_hip.energy import DeviceMonteCarlo
+from oracle import oracle as O
+
+golden = os.path.join(here, '..', 'golden', 'raspa')
+tmp = tempfile.mkdtemp(prefix="ceg_mc_")
+os.makedirs(os.path.join(tmp, "raspa"))
+for sub in ("forcefield", "molecules", "structures"):
+    os.symlink(os.path.join(golden, sub), os.path.join(tmp, "raspa", sub))
+ceg.setdir_RASPA(os.path.join(tmp, "raspa"))
+FF = "BoulfelfelSholl2021"
+nguest = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+co2 = ceg.load_molecule_RASPA("CO2", "TraPPE", FF)
+base = np.asarray(co2.position, dtype=np.float64).reshape(-1, 3)
+fw = ceg.load_framework_RASPA("CHA_1.4_3b4eeb96_Na_11812", FF)
+rng = np.random.default_rng(0)
+centers = (W._random_atoms_min_sep(nguest, 1.0, 0.14, rng)) @ fw.mat.T        # fractional, >= ~4 A apart
+t0 = time.perf_counter()
+mc = M.setup_montecarlo("CHA_1.4_3b4eeb96_Na_11812", FF, [co2.with_positions(c + base) for c in centers])
+print(f"# setup_montecarlo (3 grids of {tuple(int(d) + 1 for d in mc.coulomb.csetup.dims)} points built on the GPU, written, parsed): {time.perf_counter() - t0:.1f} s")
+M.baseline_energy(mc) if nguest <= 16 else M.compute_ewald_mc(mc)
+dev = DeviceMonteCarlo(mc)
+mols = [(i, j) for i, kind in enumerate(mc.positions) for j in range(len(kind))]
+natoms = sum(len(ids) for *_x, ids, _p in mc.molecules())
+print(f"# {len(mols)} molecules, {natoms} guest atoms, {len(mc.ewald.kfactors)} k-vectors, MC cell = 1 x 1 x 1 CHA cell")
+
+def bench(nbatch, reps):
+    idx = mols[7 % len(mols)]
+    cur = mc.positions[idx[0]][idx[1]]
+    trial = cur[None] + rng.uniform(-0.5, 0.5, (nbatch, 1, 3))
+    dev.trial(idx, trial)
+    t = time.perf_counter()
+    for k in range(reps):
+        e = dev.trial(idx, trial)
+        if k % 2 == 0:
+            dev.accept(idx, trial[0])
+    dt = (time.perf_counter() - t) / reps
+    return dt, e
+
+for nbatch, reps in ((1, 2000), (16, 1000), (1024, 200), (65536, 10)):
+    dt, e = bench(nbatch, reps)
+    print(f"GPU  batch {nbatch:6d}: {dt * 1e6:9.1f} us per call (trial launch + every second call an accept) = {dt * 1e6 / nbatch:9.3f} us per trial placement")
+
+# CPU: the oracle's three sums for the same molecule, one thread, amortised over 2000 placements (no per-call overhead)
+idx = mols[7 % len(mols)]
+cur = mc.positions[idx[0]][idx[1]]
+n = 2000
+trial = cur[None] + rng.uniform(-0.5, 0.5, (n, 1, 3))
+ids = mc.ffidx[idx[0]]
+t = time.perf_counter()
+pair = O.single_contribution_vdw(mc, idx, trial, nthreads=1)
+t_pair = time.perf_counter() - t
+t = time.perf_counter()
+for a, ix in enumerate(ids):
+    O.interpolate_points(mc.grids[ix - 1], trial[:, a], nthreads=1)
+    O.interpolate_points(mc.coulomb, trial[:, a], nthreads=1)
+t_int = time.perf_counter() - t
+t = time.perf_counter()
+O.reciprocal_energies(mc.ewald, co2, trial, nthreads=1)
+t_rec = time.perf_counter() - t
+print(f"CPU oracle, 1 thread, per placement: pairs {t_pair / n * 1e6:.1f} us + interpolation {t_int / n * 1e6:.1f} us + reciprocal {t_rec / n * 1e6:.1f} us "
+      f"= {(t_pair + t_int + t_rec) / n * 1e6:.1f} us")
+t = time.perf_counter()
+for k in range(20):
+    M.movement_energy(mc, idx, trial[k])
+print(f"Python host mirror ceg_hip.montecarlo.movement_energy: {(time.perf_counter() - t) / 20 * 1e6:.0f} us per placement")
+dev.close()

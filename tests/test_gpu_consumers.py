@@ -3,6 +3,7 @@ thousands of guest atoms, 10^4+ trial placements, every code path of the pair ke
 loop, queue flushes, pair table in LDS and in global memory, ceg_math.h and libm-grade rule arithmetic).
 Oracle: oracle_single_contribution_vdw (energy.jl:397-427).  Run with `pytest -m gpu` on an MI355X."""
 import ctypes as C
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -148,3 +149,95 @@ def test_pairs_kernel_variants(hip_lib, oracle, nkinds, alpha, what):
     ref = oracle.single_contribution_vdw_raw(args[0], np.linalg.inv(mat), *args[1:])
     assert np.isfinite(ref).all()
     _assert_energies(got, ref, what)
+
+
+# ------------------------------------------------------------------ BASELINE config 5: device-resident MC state
+def _mc_setup(tmp_path):
+    """Na + 4 CO2 in CIT-7 (2x3x3 supercell, triclinic): grids at 0.15 A built by the HIP kernels via setup_montecarlo."""
+    import os
+    from pathlib import Path
+    from ceg_hip import montecarlo as M
+    golden = Path(__file__).parent / "golden" / "raspa"
+    raspa = tmp_path / "raspa"
+    raspa.mkdir()
+    for sub in ("forcefield", "molecules", "structures"):
+        os.symlink(golden / sub, raspa / sub)
+    ceg.setdir_RASPA(raspa)
+    ff = "BoulfelfelSholl2021"
+
+    def mol(name, positions):
+        return ceg.load_molecule_RASPA(name, "TraPPE", ff).with_positions(positions)
+    na = [[3.019388765467742, 0.8997706038543032, 26.11901621898599]]
+    co2 = np.array([[11.93940309885289, 8.48657378465003, 2.135736631609201], [11.10485516124311, 7.710040763525694, 1.991767166323031],
+                    [10.27030722363334, 6.933507742401357, 1.84779770103686]])
+    shifts = [[0, 0, 0], [-5.6, -0.4, 6.5], [3.0, 9.0, 11.0], [-8.0, 14.0, 4.0]]
+    return M, M.setup_montecarlo("CIT-7", ff, [mol("Na", na)] + [mol("CO2", co2 + np.array(s)) for s in shifts])
+
+
+def _rotation(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    a, b, c, d = q
+    return np.array([[a * a + b * b - c * c - d * d, 2 * (b * c - a * d), 2 * (b * d + a * c)],
+                     [2 * (b * c + a * d), a * a - b * b + c * c - d * d, 2 * (c * d - a * b)],
+                     [2 * (b * d - a * c), 2 * (c * d + a * b), a * a - b * b - c * c + d * d]])
+
+
+def test_mc_replay_1000_moves(hip_lib, tmp_path):
+    """BASELINE config 5 as the reference runs it (montecarlo.jl:563-628, simulation.jl:727-781): one trial per Markov step.
+    A fixed sequence of 1000 translation / rotation moves with an energy-independent acceptance pattern is replayed on
+    the device-resident state (ceg_mc_trial: ONE launch per step, ceg_mc_accept: update_mc! on the device, nothing uploaded
+    between moves) and on the host mirror ceg_hip.montecarlo; every movement_energy (before, after; four terms) must agree
+    to 1e-9, and so must the final positions and total structure factor."""
+    from ceg_hip.energy import DeviceMonteCarlo
+    try:
+        M, mc = _mc_setup(tmp_path)
+        M.baseline_energy(mc)                                   # host: per-molecule structure factors (mc.sums)
+        dev = DeviceMonteCarlo(mc)
+        mols = [(i, j) for i, kind in enumerate(mc.positions) for j in range(len(kind))]
+        rng = np.random.default_rng(2024)
+        worst = 0.0
+        naccept = 0
+        for step in range(1000):
+            idx = mols[int(rng.integers(len(mols)))]
+            cur = mc.positions[idx[0]][idx[1]]
+            if step % 7 == 3:                                   # a jump anywhere in (and beyond) the MC cell
+                new = cur + mc.mat @ rng.uniform(-1.5, 1.5, 3)
+            else:
+                new = cur + rng.uniform(-0.35, 0.35, 3)
+            if len(cur) > 1 and step % 2 == 0:                  # rigid rotation about the centre atom
+                c = new[len(cur) // 2]
+                new = c + (new - c) @ _rotation(rng).T
+            got = dev.trial(idx, new[None])
+            before, after = M.movement_energy(mc, idx), M.movement_energy(mc, idx, new)
+            for row, ref in ((got[0], before), (got[1], after)):
+                r = np.array([ref.framework_vdw, ref.framework_direct, ref.inter, ref.reciprocal])
+                ok = np.isfinite(r) & (np.abs(r) < 1e90)
+                assert np.array_equal(row[~ok] >= 1e90, r[~ok] >= 1e90) or not (~ok).any(), (step, row, r)
+                err = np.abs(row[ok] - r[ok]) / (1e-9 * np.abs(r[ok]) + 1e-7)
+                worst = max(worst, float(err.max()) if ok.any() else 0.0)
+                assert (err <= 1.0).all(), (step, idx, row, r)
+            if step % 3 != 0:                                   # energy-independent acceptance pattern
+                dev.accept(idx, new)
+                M.update_mc(mc, idx, new)
+                naccept += 1
+        assert naccept > 600
+        pos, sf = dev.state()
+        ref_pos = np.concatenate([p for _i, _j, _ids, p in mc.molecules()])
+        assert np.array_equal(pos, ref_pos)                     # positions are copied, not recomputed
+        scale = np.abs(mc.sums[:, 0]).max()
+        assert np.abs(sf - mc.sums[:, 0]).max() <= 1e-9 * scale
+        # the same through a batch: 64 placements of one CO2 in one launch == the step-by-step rows
+        idx = mols[2]
+        cur = mc.positions[idx[0]][idx[1]]
+        batch = cur[None] + rng.uniform(-1.0, 1.0, (64, 1, 3))
+        rows = dev.trial(idx, batch)
+        for t in (0, 17, 63):
+            ref = M.movement_energy(mc, idx, batch[t])
+            r = np.array([ref.framework_vdw, ref.framework_direct, ref.inter, ref.reciprocal])
+            ok = np.abs(r) < 1e90
+            assert np.all(np.abs(rows[1 + t][ok] - r[ok]) <= 1e-9 * np.abs(r[ok]) + 1e-7)
+        print(f"mc replay: 1000 moves, {naccept} accepted, worst error {worst:.2e} of the tolerance")
+        dev.close()
+    finally:
+        ceg.setdir_RASPA(Path(__file__).parent / "golden" / "raspa")
