@@ -311,6 +311,9 @@ int upload(T** dst, const T* src, size_t n)
 
 // Expand the atoms into every lattice image that can be within the cutoff of a grid point
 // (grid bounding box grown by the cutoff), bin them on a cartesian lattice and upload.
+#ifndef CEG_BIN_Z
+#define CEG_BIN_Z 1.5
+#endif
 int build_images(ceg_plan* p)
 {
     const Geom& g = p->g;
@@ -321,12 +324,15 @@ int build_images(ceg_plan* p)
         lo[a] = g.shift[a] - margin;
         hi[a] = g.shift[a] + g.size[a] + margin;
     }
-    // bins: ~4.5 A edge
-    const double target = 4.5;
+    // bins: ~4.5 A edge in x and y (a tile's neighbourhood is then <= 64 bin rows (bx, by): one row per lane); z is the
+    // contiguous direction of a row, where a finer bin only tightens the [bz0, bz1] range a row contributes
+    double target[3] = {4.5, 4.5, CEG_BIN_Z};
+    if (const char* e = std::getenv("CEG_HIP_BIN_XY")) target[0] = target[1] = std::max(0.5, atof(e));
+    if (const char* e = std::getenv("CEG_HIP_BIN_Z")) target[2] = std::max(0.25, atof(e));
     int nb[3];
     double bin[3];
     for (int a = 0; a < 3; ++a) {
-        nb[a] = std::max(1, (int)std::floor((hi[a] - lo[a]) / target));
+        nb[a] = std::max(1, (int)std::floor((hi[a] - lo[a]) / target[a]));
         bin[a] = (hi[a] - lo[a]) / nb[a];
     }
     struct Img { double x, y, z, q; int32_t kind; int32_t bin; int32_t atom; };
