@@ -106,6 +106,9 @@ PROTOTYPES = {
     "ceg_mc_trial": (C.c_int, [C.c_void_p, C.c_int32, c_double_p, C.c_int64, c_double_p]),
     "ceg_mc_accept": (C.c_int, [C.c_void_p, C.c_int32, c_double_p]),
     "ceg_mc_get_state": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
+    "ceg_mc_trial_insert": (C.c_int, [C.c_void_p, c_int32_p, C.c_int32, c_double_p, C.c_int64, c_double_p]),
+    "ceg_mc_insert": (C.c_int, [C.c_void_p, c_int32_p, C.c_int32, c_double_p, c_int32_p]),
+    "ceg_mc_remove": (C.c_int, [C.c_void_p, C.c_int32, c_int32_p]),
     "ceg_recip_energy_device": (C.c_int, [C.c_void_p, C.c_void_p, c_double_p, C.c_int32, C.c_int64, C.c_double, C.c_double,
                                           C.c_void_p, C.c_void_p]),
 }

@@ -280,9 +280,11 @@ class DeviceMonteCarlo:
         self.refresh()
 
     def refresh(self) -> None:
-        """Upload the guests of ``self.mc`` (initial state, or after an insertion / deletion on the host side)."""
+        """Upload the guests of ``self.mc`` (initial state, or to resynchronise with the host side)."""
         pos, kinds, first = [], [], [0]
+        self._slot = [[] for _ in self.mc.positions]          # [kind][index in kind] -> molecule index on the device
         for i, j, ids, p in self.mc.molecules():
+            self._slot[i].append(len(first) - 1)
             pos.append(np.asarray(p, dtype=np.float64).reshape(-1, 3))
             kinds += [k - 1 for k in ids]
             first.append(first[-1] + len(ids))
@@ -294,7 +296,7 @@ class DeviceMonteCarlo:
     def trial(self, idx, positions) -> np.ndarray:
         """-> float64[n + 1, 4]: row 0 movement_energy of molecule ``idx`` (0-based (kind, molecule)) where it is now, row 1 + t at
         ``positions[t]``; columns (framework vdw, framework direct, inter, reciprocal)."""
-        mol = self.mc.flat_index(*idx)
+        mol = self._slot[idx[0]][idx[1]]
         m = len(self.mc.ffidx[idx[0]])
         t = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, m, 3)
         out = np.empty((len(t) + 1, 4), dtype=np.float64)
@@ -304,7 +306,36 @@ class DeviceMonteCarlo:
     def accept(self, idx, positions) -> None:
         """update_mc!(mc, idx, positions) on the device (asynchronous).  The host-side ``mc`` is NOT touched."""
         p = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1)
-        _abi.check(self._lib, self._lib.ceg_mc_accept(self._h, self.mc.flat_index(*idx), _abi.dptr(p)))
+        _abi.check(self._lib, self._lib.ceg_mc_accept(self._h, self._slot[idx[0]][idx[1]], _abi.dptr(p)))
+
+    def trial_insert(self, i: int, positions) -> np.ndarray:
+        """movement_energy of a NEW molecule of kind ``i`` at each of ``positions[n, m, 3]`` -> float64[n, 4]."""
+        k = np.ascontiguousarray([ix - 1 for ix in self.mc.ffidx[i]], dtype=np.int32)
+        t = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, len(k), 3)
+        out = np.empty((len(t), 4), dtype=np.float64)
+        _abi.check(self._lib, self._lib.ceg_mc_trial_insert(self._h, _abi.i32ptr(k), len(k), _abi.dptr(t.reshape(-1)), len(t), _abi.dptr(out.reshape(-1))))
+        return out
+
+    def insert(self, i: int, positions) -> int:
+        """add_one_system! on the device: a molecule of kind ``i`` joins (index in its kind returned, = append)."""
+        k = np.ascontiguousarray([ix - 1 for ix in self.mc.ffidx[i]], dtype=np.int32)
+        p = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1)
+        mol = C.c_int32(-1)
+        _abi.check(self._lib, self._lib.ceg_mc_insert(self._h, _abi.i32ptr(k), len(k), _abi.dptr(p), C.byref(mol)))
+        self._slot[i].append(int(mol.value))
+        return len(self._slot[i]) - 1
+
+    def remove(self, idx) -> None:
+        """remove_one_system! on the device; the host-side indices behave like ``del positions[i][j]``."""
+        i, j = idx
+        d = self._slot[i].pop(j)
+        moved = C.c_int32(-1)
+        _abi.check(self._lib, self._lib.ceg_mc_remove(self._h, d, C.byref(moved)))
+        if moved.value != d:                         # the device moved its last molecule into the hole
+            for kind in self._slot:
+                for q, v in enumerate(kind):
+                    if v == moved.value:
+                        kind[q] = d
 
     def state(self):
         """(positions[natoms, 3], total guest structure factor complex[nk]) read back from the device."""
@@ -312,7 +343,17 @@ class DeviceMonteCarlo:
         nk = len(self.mc.ewald.kfactors) if self.mc.ewald.alpha != 0.0 else 0
         pos = np.empty((natoms, 3)); re = np.empty(max(nk, 1)); im = np.empty(max(nk, 1))
         _abi.check(self._lib, self._lib.ceg_mc_get_state(self._h, _abi.dptr(pos.reshape(-1)) if natoms else None, _abi.dptr(re), _abi.dptr(im)))
-        return pos, (re[:nk] + 1j * im[:nk])
+        # device molecule order -> the host's (kind, index) order
+        sizes = {}
+        for i, kind in enumerate(self._slot):
+            for d in kind:
+                sizes[d] = len(self.mc.ffidx[i])
+        start, o = {}, 0
+        for d in sorted(sizes):
+            start[d] = o
+            o += sizes[d]
+        host = [pos[start[d]:start[d] + sizes[d]] for kind in self._slot for d in kind]
+        return (np.concatenate(host) if host else pos), (re[:nk] + 1j * im[:nk])
 
     def close(self) -> None:
         if getattr(self, "_h", None):

@@ -287,6 +287,41 @@ def update_mc(mc: MonteCarloSetup, idx: Tuple[int, int], positions) -> None:
     mc.positions[i][j] = pos
 
 
+def insertion_energy(mc: MonteCarloSetup, i: int, positions) -> MCEnergyReport:
+    """movement_energy(mc, (i, length + 1), positions) (montecarlo.jl:563-579 with ``ij = -i``): a molecule of kind ``i`` that is
+    not in the system yet; no tail-correction change included."""
+    poss = np.asarray(positions, dtype=np.float64).reshape(-1, 3)
+    idx = (i, len(mc.positions[i]))
+    rec = single_contribution_ewald(mc, idx, poss, new=True)
+    fv, fd = framework_interactions(mc, mc.ffidx[i], poss)
+    return MCEnergyReport(fv, fd, single_contribution_vdw(mc, idx, poss), rec)
+
+
+def add_molecule(mc: MonteCarloSetup, i: int, positions) -> int:
+    """add_one_system! (montecarlo.jl:615-621, ewald.jl:775-792): append a molecule of kind ``i``; returns its index in the kind."""
+    pos = np.array(positions, dtype=np.float64).reshape(-1, 3)
+    j = len(mc.positions[i])
+    if mc.ewald.alpha != 0.0:
+        assert mc.sums is not None, "Please call baseline_energy(mc) first"
+        col = 1 + mc.flat_index(i, j)
+        new = _molecule_sf(mc, mc.ffidx[i], pos)
+        mc.sums = np.insert(mc.sums, col, new, axis=1)
+        mc.sums[:, 0] += new
+    mc.positions[i].append(pos)
+    return j
+
+
+def remove_molecule(mc: MonteCarloSetup, idx: Tuple[int, int]) -> None:
+    """remove_one_system! (ewald.jl:794-810): the molecule leaves; later molecules of its kind move down by one."""
+    i, j = idx
+    if mc.ewald.alpha != 0.0:
+        assert mc.sums is not None
+        col = 1 + mc.flat_index(i, j)
+        mc.sums[:, 0] -= mc.sums[:, col]
+        mc.sums = np.delete(mc.sums, col, axis=1)
+    del mc.positions[i][j]
+
+
 def setup_montecarlo(framework, pff, systems: Sequence[RASPASystem], *, blockfiles=None, gridstep: float = 0.15,
                      supercell=None, new: bool = False, cutoff: float = 12.0, ngpus: int = 1) -> MonteCarloSetup:
     """montecarlo.jl:266-323 + :70-216 for explicit rigid molecules (one entry of ``systems`` per

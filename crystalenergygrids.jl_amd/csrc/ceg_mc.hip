@@ -52,7 +52,7 @@ struct McView {
     double cutoff2, coulombic;
     int32_t nkinds, nrules, fast, table_in_lds;
     int32_t ks[3], nk;
-    int32_t natoms, nmol;
+    int32_t natoms, nmol;                      // natoms: high-water mark of the atom slots
     const McGrid* vdw;                         // [nkinds]
     McGrid coulomb;
     const double* kind_charge;                 // [nkinds]
@@ -63,9 +63,12 @@ struct McView {
     const double2* sf_fw;                      // [nk] StoreRigidChargeFramework
     double2* sf_tot;                           // [nk] sums[:, 1]
     double2* sf_mol;                           // [nmol][nk] sums[:, ij+1]
-    double4* atoms;                            // x, y, z, (molecule << 32 | kind)
-    const int32_t* mol_first;                  // [nmol + 1] atoms of molecule j: [mol_first[j], mol_first[j+1])
+    double4* atoms;                            // x, y, z, (molecule << 32 | kind); molecule < 0: free slot
+    int2* mol;                                 // [nmol] atoms of molecule j: slots [mol[j].x, mol[j].x + mol[j].y)
 };
+
+// a molecule that is not (yet) in the system: kinds of its atoms (single_contribution_ewald with ij < 0, ewald.jl:704-728)
+struct McMolecule { int32_t m; int32_t kinds[MC_MAX_ATOMS]; };
 
 struct McPositions { double xyz[MC_MAX_ATOMS * 3]; };
 
@@ -117,8 +120,10 @@ __device__ __forceinline__ double2 molecule_sf(const McView& v, const double2* t
     return make_double2(sr, si);
 }
 
-template <bool FAST>
-__global__ __launch_bounds__(MC_THREADS) void k_mc_trial(McView v, int32_t molecule, const double* __restrict__ trial, int64_t n,
+// INSERT: the molecule is described by `nm` and is not in the system -- no current-position row, nothing excluded from the
+// pair sum, rest = framework + sums[:, 1]
+template <bool FAST, bool INSERT>
+__global__ __launch_bounds__(MC_THREADS) void k_mc_trial(McView v, int32_t molecule, McMolecule nm, const double* __restrict__ trial, int64_t n,
                                                           double* __restrict__ out, int stride)
 {
     // dynamic LDS: [m][stride] double2 tables, then (table_in_lds) the pair table
@@ -128,8 +133,8 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_trial(McView v, int32_t molec
     __shared__ int32_t s_kind[MC_MAX_ATOMS];
     __shared__ double s_red[MC_THREADS / 64][5];
     const int tid = threadIdx.x;
-    const int64_t b = blockIdx.x;                        // 0: where the molecule is now; b >= 1: trial b - 1
-    const int first = v.mol_first[molecule], m = v.mol_first[molecule + 1] - first;
+    const int64_t b = INSERT ? (int64_t)blockIdx.x + 1 : (int64_t)blockIdx.x;     // 0: where the molecule is now; b >= 1: trial b - 1
+    const int first = INSERT ? 0 : v.mol[molecule].x, m = INSERT ? nm.m : v.mol[molecule].y;
     double2* tab = reinterpret_cast<double2*>(s_raw);
     const DevRule* rules = v.rules;
     const int32_t* offset = v.rule_offset;
@@ -151,7 +156,8 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_trial(McView v, int32_t molec
     }
     if (tid < m) {
         int kind, mol;
-        unpack(v.atoms[first + tid].w, kind, mol);
+        if (INSERT) kind = nm.kinds[tid];
+        else unpack(v.atoms[first + tid].w, kind, mol);
         s_kind[tid] = kind;
         s_q[tid] = v.kind_charge[kind];
     }
@@ -174,9 +180,9 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_trial(McView v, int32_t molec
     if (v.nk > 0) {
         if (b != 0) fill_tables(v, s_pos, m, tab, stride, tid, MC_THREADS);
         __syncthreads();
-        const double2* mine = v.sf_mol + (size_t)molecule * v.nk;
+        const double2* mine = v.sf_mol + (size_t)(INSERT ? 0 : molecule) * v.nk;
         for (int64_t q = tid; q < v.nk; q += MC_THREADS) {
-            const double2 old = mine[q];
+            const double2 old = INSERT ? make_double2(0.0, 0.0) : mine[q];
             const double2 S = (b == 0) ? old : molecule_sf(v, tab, stride, s_q, m, q);
             const double2 f = v.sf_fw[q], t = v.sf_tot[q];
             const double rr = f.x + (t.x - old.x), ri = f.y + (t.y - old.y);      // rest = framework + (sums[:,1] - sums[:,ij+1])
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_trial(McView v, int32_t molec
             const double4 A = v.atoms[l];
             int kind1, mol;
             unpack(A.w, kind1, mol);
-            if (mol == molecule) continue;                                  // :419
+            if (mol < 0 || (!INSERT && mol == molecule)) continue;          // :419 (and free slots)
             for (int a = 0; a < m; ++a) {
                 double r2;
                 {
@@ -237,10 +243,11 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_trial(McView v, int32_t molec
         double tot[5] = {0, 0, 0, 0, 0};
         for (int w = 0; w < MC_THREADS / 64; ++w)
             for (int c = 0; c < 5; ++c) tot[c] += s_red[w][c];
-        out[4 * b + 0] = tot[0];
-        out[4 * b + 1] = tot[1];
-        out[4 * b + 2] = tot[2];
-        out[4 * b + 3] = 2.0 * tot[3] + tot[4];
+        double* o = out + 4 * (size_t)blockIdx.x;
+        o[0] = tot[0];
+        o[1] = tot[1];
+        o[2] = tot[2];
+        o[3] = 2.0 * tot[3] + tot[4];
     }
 }
 
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_accept(McView v, int32_t mole
     __shared__ double s_pos[MC_MAX_ATOMS * 3];
     __shared__ double s_q[MC_MAX_ATOMS];
     const int tid = threadIdx.x;
-    const int first = v.mol_first[molecule], m = v.mol_first[molecule + 1] - first;
+    const int first = v.mol[molecule].x, m = v.mol[molecule].y;
     if (tid < 3 * m) s_pos[tid] = np.xyz[tid];
     if (tid < m) {
         double4 A = v.atoms[first + tid];
@@ -285,7 +292,7 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_sf_molecules(McView v, int st
     __shared__ double s_pos[MC_MAX_ATOMS * 3];
     __shared__ double s_q[MC_MAX_ATOMS];
     const int tid = threadIdx.x, molecule = blockIdx.x;
-    const int first = v.mol_first[molecule], m = v.mol_first[molecule + 1] - first;
+    const int first = v.mol[molecule].x, m = v.mol[molecule].y;
     if (tid < m) {
         const double4 A = v.atoms[first + tid];
         int kind, mol;
@@ -313,6 +320,72 @@ __global__ void k_mc_sf_total(McView v)
         si += s.y;
     }
     v.sf_tot[q] = make_double2(sr, si);
+}
+
+// add_one_system! (ewald.jl:775-792, montecarlo.jl:615-621): new molecule `molecule` (= old nmol) in atom slots [first, first + m)
+__global__ __launch_bounds__(MC_THREADS) void k_mc_insert(McView v, int32_t molecule, int32_t first, McMolecule nm, McPositions np, int stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    __shared__ double s_pos[MC_MAX_ATOMS * 3];
+    __shared__ double s_q[MC_MAX_ATOMS];
+    const int tid = threadIdx.x, m = nm.m;
+    if (tid < 3 * m) s_pos[tid] = np.xyz[tid];
+    if (tid < m) {
+        const long long bits = ((long long)molecule << 32) | (long long)(uint32_t)nm.kinds[tid];
+        v.atoms[first + tid] = make_double4(np.xyz[3 * tid], np.xyz[3 * tid + 1], np.xyz[3 * tid + 2], __longlong_as_double(bits));
+        s_q[tid] = v.kind_charge[nm.kinds[tid]];
+    }
+    if (tid == 0) v.mol[molecule] = make_int2(first, m);
+    __syncthreads();
+    if (v.nk == 0) return;
+    double2* tab = reinterpret_cast<double2*>(s_raw);
+    fill_tables(v, s_pos, m, tab, stride, tid, MC_THREADS);
+    __syncthreads();
+    double2* mine = v.sf_mol + (size_t)molecule * v.nk;
+    for (int64_t q = tid; q < v.nk; q += MC_THREADS) {
+        const double2 S = molecule_sf(v, tab, stride, s_q, m, q);
+        double2 t = v.sf_tot[q];
+        t.x += S.x;
+        t.y += S.y;
+        v.sf_tot[q] = t;
+        mine[q] = S;
+    }
+}
+
+// remove_one_system! (ewald.jl:794-810, :404-413): sums[:,1] -= sums[:,ij+1]; the LAST molecule takes index `molecule`
+// (its structure factor column and the molecule id of its atoms); the atom slots of the removed molecule become free
+__global__ __launch_bounds__(MC_THREADS) void k_mc_remove(McView v, int32_t molecule, int32_t last)
+{
+    const int tid = threadIdx.x;
+    const int2 gone = v.mol[molecule], moved = v.mol[last];
+    double2* mine = v.sf_mol + (size_t)molecule * v.nk;
+    const double2* lastsf = v.sf_mol + (size_t)last * v.nk;
+    for (int64_t q = tid; q < v.nk; q += MC_THREADS) {
+        const double2 old = mine[q];
+        double2 t = v.sf_tot[q];
+        t.x -= old.x;
+        t.y -= old.y;
+        v.sf_tot[q] = t;
+        if (last != molecule) mine[q] = lastsf[q];
+    }
+    if (tid < gone.y) {
+        double4 A = v.atoms[gone.x + tid];
+        int kind, mol;
+        unpack(A.w, kind, mol);
+        const long long bits = (long long)(0xffffffff00000000ull | (unsigned long long)(uint32_t)kind);      // molecule id -1: free slot
+        A.w = __longlong_as_double(bits);
+        v.atoms[gone.x + tid] = A;
+    }
+    if (last != molecule && tid >= 64 && tid < 64 + moved.y) {
+        double4 A = v.atoms[moved.x + tid - 64];
+        int kind, mol;
+        unpack(A.w, kind, mol);
+        const long long bits = ((long long)molecule << 32) | (long long)(uint32_t)kind;
+        A.w = __longlong_as_double(bits);
+        v.atoms[moved.x + tid - 64] = A;
+    }
+    __syncthreads();
+    if (tid == 0 && last != molecule) v.mol[molecule] = moved;
 }
 
 int merr(int code, const char* msg)
@@ -358,10 +431,11 @@ struct ceg_mc {
     double* d_kf = nullptr;
     double2 *d_fw = nullptr, *d_tot = nullptr, *d_mol = nullptr;
     double4* d_atoms = nullptr;
-    int32_t* d_first = nullptr;
+    int2* d_molidx = nullptr;
     int64_t atoms_cap = 0, mol_cap = 0;
-    std::vector<int32_t> h_first;
-    int stride = 0, max_m = 1;
+    std::vector<int2> h_mol;                     // host copy of (start, count) per molecule
+    std::vector<std::vector<int32_t>> free_runs; // free_runs[m]: starts of free runs of m atom slots
+    int stride = 0;
     // pinned, device-mapped staging for small batches; device scratch for large ones
     double *h_in = nullptr, *h_out = nullptr, *dm_in = nullptr, *dm_out = nullptr;
     double *d_in = nullptr, *d_out = nullptr;
@@ -459,7 +533,7 @@ extern "C" int ceg_mc_destroy(ceg_mc_t* h)
     if (guard.ok) {
         if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
         for (void* p : {(void*)h->d_vdw, (void*)h->d_charge, (void*)h->d_rules, (void*)h->d_offset, (void*)h->d_ijk, (void*)h->d_kf,
-                        (void*)h->d_fw, (void*)h->d_tot, (void*)h->d_mol, (void*)h->d_atoms, (void*)h->d_first, (void*)h->d_in, (void*)h->d_out})
+                        (void*)h->d_fw, (void*)h->d_tot, (void*)h->d_mol, (void*)h->d_atoms, (void*)h->d_molidx, (void*)h->d_in, (void*)h->d_out})
             if (p) (void)hipFree(p);
         if (h->h_in) (void)hipHostFree(h->h_in);
         if (h->h_out) (void)hipHostFree(h->h_out);
@@ -468,71 +542,56 @@ extern "C" int ceg_mc_destroy(ceg_mc_t* h)
     return CEG_OK;
 }
 
-extern "C" int ceg_mc_set_guests(ceg_mc_t* h, const double* positions, const int32_t* kinds, const int32_t* mol_first, int32_t nmol)
+namespace {
+
+// grow the device arrays (contents kept); the stream is idle when this returns
+int ensure_capacity(ceg_mc* h, int64_t natoms, int64_t nmol)
 {
-    if (!h || nmol < 0 || !mol_first || mol_first[0] != 0) return merr(CEG_ERR_INVALID, "bad argument");
-    for (int32_t j = 0; j < nmol; ++j) {
-        const int32_t m = mol_first[j + 1] - mol_first[j];
-        if (m < 1) return merr(CEG_ERR_INVALID, "empty molecule");
-        if (m > MC_MAX_ATOMS) return merr(CEG_ERR_UNSUPPORTED, "molecule has more atoms than the kernels hold in LDS (16)");
-    }
-    const int64_t natoms = mol_first[nmol];
-    if (natoms > 0 && (!positions || !kinds)) return merr(CEG_ERR_INVALID, "bad argument");
-    std::vector<double4> host((size_t)(natoms > 0 ? natoms : 1));
-    for (int32_t j = 0; j < nmol; ++j)
-        for (int32_t l = mol_first[j]; l < mol_first[j + 1]; ++l) {
-            if (kinds[l] < 0 || kinds[l] >= h->v.nkinds) return merr(CEG_ERR_INVALID, "atom kind outside the pair table");
-            const long long bits = ((long long)j << 32) | (long long)(uint32_t)kinds[l];
-            double w;
-            memcpy(&w, &bits, sizeof(w));
-            host[l] = make_double4(positions[3 * l], positions[3 * l + 1], positions[3 * l + 2], w);
-        }
-    Guard guard(h->device);
-    if (!guard.ok) return merr(CEG_ERR_HIP, "hipSetDevice failed");
+    if (natoms <= h->atoms_cap && nmol <= h->mol_cap) return CEG_OK;
     if (hipStreamSynchronize(h->stream) != hipSuccess) return merr(CEG_ERR_HIP, "stream synchronisation failed");
-    bool ok = true;
+    const size_t nk = (size_t)(h->v.nk > 0 ? h->v.nk : 1);
     if (natoms > h->atoms_cap) {
+        const int64_t cap = natoms + natoms / 2 + 64;
+        double4* p = nullptr;
+        if (hipMalloc((void**)&p, sizeof(double4) * (size_t)cap) != hipSuccess) return merr(CEG_ERR_HIP, "could not allocate the guest atoms");
+        if (h->d_atoms && h->v.natoms > 0 &&
+            hipMemcpy(p, h->d_atoms, sizeof(double4) * (size_t)h->v.natoms, hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipFree(p); return merr(CEG_ERR_HIP, "device copy failed"); }
         if (h->d_atoms) (void)hipFree(h->d_atoms);
-        h->d_atoms = nullptr;
-        h->atoms_cap = natoms + natoms / 2 + 64;
-        ok = hipMalloc((void**)&h->d_atoms, sizeof(double4) * (size_t)h->atoms_cap) == hipSuccess;
+        h->d_atoms = p;
+        h->atoms_cap = cap;
     }
-    if (ok && nmol > h->mol_cap) {
+    if (nmol > h->mol_cap) {
+        const int64_t cap = nmol + nmol / 2 + 16;
+        double2* pm = nullptr;
+        int2* pi = nullptr;
+        if (hipMalloc((void**)&pm, sizeof(double2) * (size_t)cap * nk) != hipSuccess || hipMalloc((void**)&pi, sizeof(int2) * (size_t)cap) != hipSuccess) {
+            if (pm) (void)hipFree(pm);
+            return merr(CEG_ERR_HIP, "could not allocate the per-molecule arrays");
+        }
+        bool ok = true;
+        if (h->d_mol && h->v.nmol > 0) ok = hipMemcpy(pm, h->d_mol, sizeof(double2) * (size_t)h->v.nmol * nk, hipMemcpyDeviceToDevice) == hipSuccess;
+        if (ok && h->d_molidx && h->v.nmol > 0) ok = hipMemcpy(pi, h->d_molidx, sizeof(int2) * (size_t)h->v.nmol, hipMemcpyDeviceToDevice) == hipSuccess;
+        if (!ok) { (void)hipFree(pm); (void)hipFree(pi); return merr(CEG_ERR_HIP, "device copy failed"); }
         if (h->d_mol) (void)hipFree(h->d_mol);
-        if (h->d_first) (void)hipFree(h->d_first);
-        h->d_mol = nullptr; h->d_first = nullptr;
-        h->mol_cap = nmol + nmol / 2 + 16;
-        ok = hipMalloc((void**)&h->d_mol, sizeof(double2) * (size_t)h->mol_cap * (size_t)(h->v.nk > 0 ? h->v.nk : 1)) == hipSuccess &&
-             hipMalloc((void**)&h->d_first, sizeof(int32_t) * (size_t)(h->mol_cap + 1)) == hipSuccess;
+        if (h->d_molidx) (void)hipFree(h->d_molidx);
+        h->d_mol = pm;
+        h->d_molidx = pi;
+        h->mol_cap = cap;
     }
-    if (!ok) { h->atoms_cap = 0; h->mol_cap = 0; return merr(CEG_ERR_HIP, "could not allocate the guest arrays"); }
-    if (natoms > 0) ok = hipMemcpy(h->d_atoms, host.data(), sizeof(double4) * (size_t)natoms, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && hipMemcpy(h->d_first, mol_first, sizeof(int32_t) * (size_t)(nmol + 1), hipMemcpyHostToDevice) == hipSuccess;
-    if (!ok) return merr(CEG_ERR_HIP, "could not upload the guest atoms");
-    h->h_first.assign(mol_first, mol_first + nmol + 1);
-    h->max_m = 1;
-    for (int32_t j = 0; j < nmol; ++j) h->max_m = std::max(h->max_m, mol_first[j + 1] - mol_first[j]);
-    if (sizeof(double2) * (size_t)h->max_m * (size_t)h->stride > 64 * 1024) return merr(CEG_ERR_UNSUPPORTED, "k-space tables of a molecule do not fit in LDS");
-    McView& v = h->v;
-    v.atoms = h->d_atoms; v.mol_first = h->d_first; v.sf_mol = h->d_mol; v.natoms = (int32_t)natoms; v.nmol = nmol;
-    if (v.nk > 0) {
-        if (nmol > 0)
-            hipLaunchKernelGGL(k_mc_sf_molecules, dim3((unsigned)nmol), dim3(MC_THREADS), sizeof(double2) * (size_t)h->max_m * (size_t)h->stride,
-                               h->stream, v, h->stride);
-        hipLaunchKernelGGL(k_mc_sf_total, dim3((unsigned)((v.nk + 255) / 256)), dim3(256), 0, h->stream, v);
-        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
-            return merr(CEG_ERR_HIP, "structure-factor kernels failed");
-    }
+    h->v.atoms = h->d_atoms; h->v.mol = h->d_molidx; h->v.sf_mol = h->d_mol;
     return CEG_OK;
 }
 
-extern "C" int ceg_mc_trial(ceg_mc_t* h, int32_t molecule, const double* trial, int64_t n, double* out)
+size_t tables_bytes(const ceg_mc* h, int m) { return sizeof(double2) * (size_t)m * (size_t)h->stride; }
+
+// launch the trial kernel for n placements (INSERT: of a molecule that is not in the system) and bring the rows back
+int run_trial(ceg_mc* h, bool insert, int32_t molecule, const McMolecule& nm, int m, const double* trial, int64_t n, double* out)
 {
-    if (!h || n < 0 || !out || (n > 0 && !trial)) return merr(CEG_ERR_INVALID, "bad argument");
-    if (molecule < 0 || molecule >= h->v.nmol) return merr(CEG_ERR_INVALID, "no such molecule");
-    const int m = h->h_first[molecule + 1] - h->h_first[molecule];
-    const size_t in_bytes = sizeof(double) * 3 * (size_t)m * (size_t)n, out_bytes = sizeof(double) * 4 * (size_t)(n + 1);
-    if (n + 1 > 0x7fffffffLL) return merr(CEG_ERR_INVALID, "too many placements");
+    const int64_t rows = insert ? n : n + 1;
+    if (rows <= 0) return CEG_OK;
+    if (rows > 0x7fffffffLL) return merr(CEG_ERR_INVALID, "too many placements");
+    if (tables_bytes(h, m) > 64 * 1024) return merr(CEG_ERR_UNSUPPORTED, "k-space tables of the molecule do not fit in LDS");
+    const size_t in_bytes = sizeof(double) * 3 * (size_t)m * (size_t)n, out_bytes = sizeof(double) * 4 * (size_t)rows;
     Guard guard(h->device);
     if (!guard.ok) return merr(CEG_ERR_HIP, "hipSetDevice failed");
     const bool mapped = in_bytes <= MC_MAPPED_BYTES && out_bytes <= MC_MAPPED_BYTES;
@@ -561,13 +620,13 @@ extern "C" int ceg_mc_trial(ceg_mc_t* h, int32_t molecule, const double* trial, 
     }
     McView v = h->v;
     size_t table_bytes = v.table_in_lds ? sizeof(DevRule) * (size_t)(v.nrules > 0 ? v.nrules : 1) + sizeof(int32_t) * ((size_t)v.nkinds * v.nkinds + 1) : 0;
-    if (sizeof(double2) * (size_t)m * (size_t)h->stride + table_bytes > 64 * 1024) { v.table_in_lds = 0; table_bytes = 0; }   // pair table from global memory then
-    const size_t lds = sizeof(double2) * (size_t)m * (size_t)h->stride + table_bytes;
-    const dim3 grid((unsigned)(n + 1)), block(MC_THREADS);
-    if (v.fast)
-        hipLaunchKernelGGL((k_mc_trial<true>), grid, block, lds, h->stream, v, molecule, d_in, n, d_out, h->stride);
-    else
-        hipLaunchKernelGGL((k_mc_trial<false>), grid, block, lds, h->stream, v, molecule, d_in, n, d_out, h->stride);
+    if (tables_bytes(h, m) + table_bytes > 64 * 1024) { v.table_in_lds = 0; table_bytes = 0; }   // pair table from global memory then
+    const size_t lds = tables_bytes(h, m) + table_bytes;
+    const dim3 grid((unsigned)rows), block(MC_THREADS);
+#define CEG_MC_LAUNCH(F, I) hipLaunchKernelGGL((k_mc_trial<F, I>), grid, block, lds, h->stream, v, molecule, nm, d_in, n, d_out, h->stride)
+    if (insert) { if (v.fast) CEG_MC_LAUNCH(true, true); else CEG_MC_LAUNCH(false, true); }
+    else { if (v.fast) CEG_MC_LAUNCH(true, false); else CEG_MC_LAUNCH(false, false); }
+#undef CEG_MC_LAUNCH
     if (hipGetLastError() != hipSuccess) return merr(CEG_ERR_HIP, "trial kernel launch failed");
     if (!mapped && hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return merr(CEG_ERR_HIP, "D2H failed");
     if (hipStreamSynchronize(h->stream) != hipSuccess) return merr(CEG_ERR_HIP, "trial kernel failed");
@@ -575,19 +634,143 @@ extern "C" int ceg_mc_trial(ceg_mc_t* h, int32_t molecule, const double* trial, 
     return CEG_OK;
 }
 
+int check_molecule(const ceg_mc* h, const int32_t* kinds, int32_t m, McMolecule* nm)
+{
+    if (!kinds || m < 1) return merr(CEG_ERR_INVALID, "bad argument");
+    if (m > MC_MAX_ATOMS) return merr(CEG_ERR_UNSUPPORTED, "molecule has more atoms than the kernels hold in LDS (16)");
+    nm->m = m;
+    for (int a = 0; a < m; ++a) {
+        if (kinds[a] < 0 || kinds[a] >= h->v.nkinds) return merr(CEG_ERR_INVALID, "atom kind outside the pair table");
+        nm->kinds[a] = kinds[a];
+    }
+    return CEG_OK;
+}
+
+}  // namespace
+
+extern "C" int ceg_mc_set_guests(ceg_mc_t* h, const double* positions, const int32_t* kinds, const int32_t* mol_first, int32_t nmol)
+{
+    if (!h || nmol < 0 || !mol_first || mol_first[0] != 0) return merr(CEG_ERR_INVALID, "bad argument");
+    int max_m = 1;
+    for (int32_t j = 0; j < nmol; ++j) {
+        const int32_t m = mol_first[j + 1] - mol_first[j];
+        if (m < 1) return merr(CEG_ERR_INVALID, "empty molecule");
+        if (m > MC_MAX_ATOMS) return merr(CEG_ERR_UNSUPPORTED, "molecule has more atoms than the kernels hold in LDS (16)");
+        max_m = std::max(max_m, m);
+    }
+    if (tables_bytes(h, max_m) > 64 * 1024) return merr(CEG_ERR_UNSUPPORTED, "k-space tables of a molecule do not fit in LDS");
+    const int64_t natoms = mol_first[nmol];
+    if (natoms > 0 && (!positions || !kinds)) return merr(CEG_ERR_INVALID, "bad argument");
+    std::vector<double4> host((size_t)(natoms > 0 ? natoms : 1));
+    std::vector<int2> idx((size_t)(nmol > 0 ? nmol : 1));
+    for (int32_t j = 0; j < nmol; ++j) {
+        idx[j] = make_int2(mol_first[j], mol_first[j + 1] - mol_first[j]);
+        for (int32_t l = mol_first[j]; l < mol_first[j + 1]; ++l) {
+            if (kinds[l] < 0 || kinds[l] >= h->v.nkinds) return merr(CEG_ERR_INVALID, "atom kind outside the pair table");
+            const long long bits = ((long long)j << 32) | (long long)(uint32_t)kinds[l];
+            double w;
+            memcpy(&w, &bits, sizeof(w));
+            host[l] = make_double4(positions[3 * l], positions[3 * l + 1], positions[3 * l + 2], w);
+        }
+    }
+    Guard guard(h->device);
+    if (!guard.ok) return merr(CEG_ERR_HIP, "hipSetDevice failed");
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return merr(CEG_ERR_HIP, "stream synchronisation failed");
+    h->v.natoms = 0; h->v.nmol = 0;                        // nothing worth copying when the arrays grow
+    if (int rc = ensure_capacity(h, std::max<int64_t>(natoms, 1), std::max<int64_t>(nmol, 1))) return rc;
+    bool ok = true;
+    if (natoms > 0) ok = hipMemcpy(h->d_atoms, host.data(), sizeof(double4) * (size_t)natoms, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && nmol > 0) ok = hipMemcpy(h->d_molidx, idx.data(), sizeof(int2) * (size_t)nmol, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) return merr(CEG_ERR_HIP, "could not upload the guest atoms");
+    h->h_mol.assign(idx.begin(), idx.begin() + nmol);
+    h->free_runs.assign(MC_MAX_ATOMS + 1, {});
+    McView& v = h->v;
+    v.natoms = (int32_t)natoms; v.nmol = nmol;
+    if (v.nk > 0) {
+        if (nmol > 0)
+            hipLaunchKernelGGL(k_mc_sf_molecules, dim3((unsigned)nmol), dim3(MC_THREADS), tables_bytes(h, max_m), h->stream, v, h->stride);
+        hipLaunchKernelGGL(k_mc_sf_total, dim3((unsigned)((v.nk + 255) / 256)), dim3(256), 0, h->stream, v);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
+            return merr(CEG_ERR_HIP, "structure-factor kernels failed");
+    }
+    return CEG_OK;
+}
+
+extern "C" int ceg_mc_trial(ceg_mc_t* h, int32_t molecule, const double* trial, int64_t n, double* out)
+{
+    if (!h || n < 0 || !out || (n > 0 && !trial)) return merr(CEG_ERR_INVALID, "bad argument");
+    if (molecule < 0 || molecule >= h->v.nmol) return merr(CEG_ERR_INVALID, "no such molecule");
+    return run_trial(h, false, molecule, McMolecule{}, h->h_mol[molecule].y, trial, n, out);
+}
+
+extern "C" int ceg_mc_trial_insert(ceg_mc_t* h, const int32_t* kinds, int32_t m, const double* trial, int64_t n, double* out)
+{
+    if (!h || n < 0 || (n > 0 && (!trial || !out))) return merr(CEG_ERR_INVALID, "bad argument");
+    McMolecule nm{};
+    if (int rc = check_molecule(h, kinds, m, &nm)) return rc;
+    return run_trial(h, true, -1, nm, m, trial, n, out);
+}
+
 extern "C" int ceg_mc_accept(ceg_mc_t* h, int32_t molecule, const double* positions)
 {
     if (!h || !positions) return merr(CEG_ERR_INVALID, "bad argument");
     if (molecule < 0 || molecule >= h->v.nmol) return merr(CEG_ERR_INVALID, "no such molecule");
-    const int m = h->h_first[molecule + 1] - h->h_first[molecule];
+    const int m = h->h_mol[molecule].y;
     McPositions np{};
     for (int t = 0; t < 3 * m; ++t) np.xyz[t] = positions[t];
     Guard guard(h->device);
     if (!guard.ok) return merr(CEG_ERR_HIP, "hipSetDevice failed");
-    hipLaunchKernelGGL(k_mc_accept, dim3(1), dim3(MC_THREADS), sizeof(double2) * (size_t)m * (size_t)h->stride, h->stream, h->v, molecule, np,
-                       h->stride);
+    hipLaunchKernelGGL(k_mc_accept, dim3(1), dim3(MC_THREADS), tables_bytes(h, m), h->stream, h->v, molecule, np, h->stride);
     if (hipGetLastError() != hipSuccess) return merr(CEG_ERR_HIP, "accept kernel launch failed");
-    return CEG_OK;                      // asynchronous: the next ceg_mc_trial on this handle is ordered behind it
+    return CEG_OK;                      // asynchronous: the next call on this handle is ordered behind it
+}
+
+extern "C" int ceg_mc_insert(ceg_mc_t* h, const int32_t* kinds, int32_t m, const double* positions, int32_t* molecule_out)
+{
+    if (!h || !positions) return merr(CEG_ERR_INVALID, "bad argument");
+    McMolecule nm{};
+    if (int rc = check_molecule(h, kinds, m, &nm)) return rc;
+    if (tables_bytes(h, m) > 64 * 1024) return merr(CEG_ERR_UNSUPPORTED, "k-space tables of the molecule do not fit in LDS");
+    Guard guard(h->device);
+    if (!guard.ok) return merr(CEG_ERR_HIP, "hipSetDevice failed");
+    if (h->free_runs.empty()) h->free_runs.assign(MC_MAX_ATOMS + 1, {});
+    int32_t first;
+    if (!h->free_runs[m].empty()) {            // reuse the slots of a removed molecule of the same size
+        first = h->free_runs[m].back();
+        h->free_runs[m].pop_back();
+        if (int rc = ensure_capacity(h, h->v.natoms, (int64_t)h->v.nmol + 1)) return rc;
+    } else {
+        first = h->v.natoms;
+        if (int rc = ensure_capacity(h, (int64_t)h->v.natoms + m, (int64_t)h->v.nmol + 1)) return rc;
+        h->v.natoms += m;
+    }
+    const int32_t molecule = h->v.nmol;
+    McPositions np{};
+    for (int t = 0; t < 3 * m; ++t) np.xyz[t] = positions[t];
+    h->v.nmol += 1;
+    h->h_mol.push_back(make_int2(first, m));
+    hipLaunchKernelGGL(k_mc_insert, dim3(1), dim3(MC_THREADS), tables_bytes(h, m), h->stream, h->v, molecule, first, nm, np, h->stride);
+    if (hipGetLastError() != hipSuccess) return merr(CEG_ERR_HIP, "insert kernel launch failed");
+    if (molecule_out) *molecule_out = molecule;
+    return CEG_OK;
+}
+
+extern "C" int ceg_mc_remove(ceg_mc_t* h, int32_t molecule, int32_t* moved_out)
+{
+    if (!h) return merr(CEG_ERR_INVALID, "bad argument");
+    if (molecule < 0 || molecule >= h->v.nmol) return merr(CEG_ERR_INVALID, "no such molecule");
+    Guard guard(h->device);
+    if (!guard.ok) return merr(CEG_ERR_HIP, "hipSetDevice failed");
+    const int32_t last = h->v.nmol - 1;
+    hipLaunchKernelGGL(k_mc_remove, dim3(1), dim3(MC_THREADS), 0, h->stream, h->v, molecule, last);
+    if (hipGetLastError() != hipSuccess) return merr(CEG_ERR_HIP, "remove kernel launch failed");
+    if (h->free_runs.empty()) h->free_runs.assign(MC_MAX_ATOMS + 1, {});
+    h->free_runs[h->h_mol[molecule].y].push_back(h->h_mol[molecule].x);
+    if (last != molecule) h->h_mol[molecule] = h->h_mol[last];
+    h->h_mol.pop_back();
+    h->v.nmol = last;
+    if (moved_out) *moved_out = last;     // like remove_one_system! (ewald.jl:404-413): the molecule that was `last` is now `molecule`
+    return CEG_OK;
 }
 
 extern "C" int ceg_mc_get_state(ceg_mc_t* h, double* positions, double* sf_total_re, double* sf_total_im)
@@ -596,10 +779,14 @@ extern "C" int ceg_mc_get_state(ceg_mc_t* h, double* positions, double* sf_total
     Guard guard(h->device);
     if (!guard.ok) return merr(CEG_ERR_HIP, "hipSetDevice failed");
     if (hipStreamSynchronize(h->stream) != hipSuccess) return merr(CEG_ERR_HIP, "stream synchronisation failed");
-    if (positions && h->v.natoms > 0) {
+    if (positions && h->v.natoms > 0) {          // molecule order: atoms of molecule 0, then 1, ...
         std::vector<double4> host((size_t)h->v.natoms);
         if (hipMemcpy(host.data(), h->d_atoms, sizeof(double4) * host.size(), hipMemcpyDeviceToHost) != hipSuccess) return merr(CEG_ERR_HIP, "D2H failed");
-        for (size_t l = 0; l < host.size(); ++l) { positions[3 * l] = host[l].x; positions[3 * l + 1] = host[l].y; positions[3 * l + 2] = host[l].z; }
+        size_t o = 0;
+        for (const int2& mj : h->h_mol)
+            for (int a = 0; a < mj.y; ++a, ++o) {
+                positions[3 * o] = host[mj.x + a].x; positions[3 * o + 1] = host[mj.x + a].y; positions[3 * o + 2] = host[mj.x + a].z;
+            }
     }
     if ((sf_total_re || sf_total_im) && h->v.nk > 0) {
         std::vector<double2> t((size_t)h->v.nk);

@@ -343,8 +343,7 @@ CEG_API int ceg_pairs_energy_device(ceg_pairs_t* handle, const double* d_trial, 
  *   single_contribution_ewald (ewald.jl:704-738)       2 sum kf Re(conj(rest) S) + sum kf |S|^2,
  *                                                      rest = framework + sums[:,1] - sums[:,ij+1]
  * and ceg_mc_accept applies update_mc! / update_ewald_context! (montecarlo.jl:615-628, ewald.jl:757-773) on the
- * device: no host-built structure factor is uploaded between moves.  Molecules are rigid, <= 16 atoms; insertion and
- * deletion (GCMC swaps) go through ceg_mc_set_guests.
+ * device: no host-built structure factor is uploaded between moves.  Molecules are rigid, <= 16 atoms.
  *
  *  vdw_grids    [nkinds] interpolation handles by 0-based force-field index, NULL where the kind has no grid / a zero grid;
  *               coulomb_grid NULL when the framework carries no charges.  The handles must outlive this object.
@@ -372,7 +371,17 @@ CEG_API int ceg_mc_trial(ceg_mc_t* handle, int32_t molecule, const double* trial
 /* the molecule now sits at positions [m][3]: update_mc! on the device.  Asynchronous; later calls on this handle are
  * ordered behind it. */
 CEG_API int ceg_mc_accept(ceg_mc_t* handle, int32_t molecule, const double* positions);
-/* read back (any pointer may be NULL): positions [3*natoms], total guest structure factor sums[:, 1] as re / im [nk] */
+/* GCMC swaps (gcmc.jl / mcmoves.jl evaluate them with the same movement_energy):
+ * trial_insert: movement_energy of a molecule that is NOT in the system (kinds [m] 0-based ff indices) at each of n trial
+ *   placements trial [n][m][3]: nothing excluded from the pair sum, rest = framework + sums[:, 1]
+ *   (single_contribution_ewald with ij < 0, ewald.jl:704-728); out [n][4], no current-position row.  Synchronous.
+ * insert: add_one_system! (ewald.jl:775-792): the molecule becomes index nmol (returned in *molecule_out); asynchronous.
+ * remove: remove_one_system! (ewald.jl:794-810, :404-413): sums[:, 1] -= sums[:, ij+1]; the LAST molecule takes index
+ *   `molecule` (*moved_out = its old index, = `molecule` when it was the last one); asynchronous. */
+CEG_API int ceg_mc_trial_insert(ceg_mc_t* handle, const int32_t* kinds, int32_t m, const double* trial, int64_t n, double* out);
+CEG_API int ceg_mc_insert(ceg_mc_t* handle, const int32_t* kinds, int32_t m, const double* positions, int32_t* molecule_out);
+CEG_API int ceg_mc_remove(ceg_mc_t* handle, int32_t molecule, int32_t* moved_out);
+/* read back (any pointer may be NULL): positions [3*natoms] in molecule order, total guest structure factor sums[:, 1] as re / im [nk] */
 CEG_API int ceg_mc_get_state(ceg_mc_t* handle, double* positions, double* sf_total_re, double* sf_total_im);
 
 /* ---- blocking masks on the grid lattice ----------------------------- */

@@ -241,3 +241,64 @@ def test_mc_replay_1000_moves(hip_lib, tmp_path):
         dev.close()
     finally:
         ceg.setdir_RASPA(Path(__file__).parent / "golden" / "raspa")
+
+
+def test_mc_insertions_and_removals(hip_lib, tmp_path):
+    """GCMC swaps on the device-resident state (ceg_mc_trial_insert / ceg_mc_insert / ceg_mc_remove = movement_energy with
+    ij < 0, add_one_system!, remove_one_system!; ewald.jl:704-728,775-810) interleaved with displacements, against the host
+    mirror: insertion energies, the energies of every later move (they see the inserted / miss the removed molecules in the
+    pair sum and in the total structure factor), final positions and structure factor."""
+    from ceg_hip.energy import DeviceMonteCarlo
+    try:
+        M, mc = _mc_setup(tmp_path)
+        M.baseline_energy(mc)
+        dev = DeviceMonteCarlo(mc)
+        rng = np.random.default_rng(77)
+        base = mc.positions[1][0] - mc.positions[1][0][1]              # CO2 geometry about its carbon
+        na = np.zeros((1, 3))
+
+        def check(row, ref, what):
+            r = np.array([ref.framework_vdw, ref.framework_direct, ref.inter, ref.reciprocal])
+            ok = np.abs(r) < 1e90
+            assert np.all(np.abs(row[ok] - r[ok]) <= 1e-9 * np.abs(r[ok]) + 1e-7), (what, row, r)
+
+        nins = nrem = 0
+        for step in range(240):
+            kind = int(rng.integers(2))
+            op = step % 4
+            if op == 0:                                              # insertion trial batch + insertion of one of them
+                shape = (na if kind == 0 else base @ _rotation(rng).T)
+                trials = (mc.mat @ rng.uniform(0, 1, (5, 3)).T).T[:, None, :] + shape[None]
+                rows = dev.trial_insert(kind, trials)
+                for t in (0, 4):
+                    check(rows[t], M.insertion_energy(mc, kind, trials[t]), ("insert", step, t))
+                dev.insert(kind, trials[2])
+                M.add_molecule(mc, kind, trials[2])
+                nins += 1
+            elif op == 2 and len(mc.positions[kind]) > 1:            # deletion: energy of the molecule where it is, then remove
+                j = int(rng.integers(len(mc.positions[kind])))
+                row = dev.trial((kind, j), np.empty((0, len(mc.ffidx[kind]), 3)))[0]
+                check(row, M.movement_energy(mc, (kind, j)), ("delete", step))
+                dev.remove((kind, j))
+                M.remove_molecule(mc, (kind, j))
+                nrem += 1
+            else:                                                    # displacement
+                if not mc.positions[kind]:
+                    continue
+                j = int(rng.integers(len(mc.positions[kind])))
+                cur = mc.positions[kind][j]
+                new = cur + rng.uniform(-0.4, 0.4, 3)
+                got = dev.trial((kind, j), new[None])
+                check(got[0], M.movement_energy(mc, (kind, j)), ("before", step))
+                check(got[1], M.movement_energy(mc, (kind, j), new), ("after", step))
+                if step % 3:
+                    dev.accept((kind, j), new)
+                    M.update_mc(mc, (kind, j), new)
+        assert nins == 60 and nrem > 30
+        pos, sf = dev.state()
+        ref_pos = np.concatenate([p for _i, _j, _ids, p in mc.molecules()])
+        assert np.array_equal(pos, ref_pos)
+        assert np.abs(sf - mc.sums[:, 0]).max() <= 1e-9 * np.abs(mc.sums[:, 0]).max()
+        dev.close()
+    finally:
+        ceg.setdir_RASPA(Path(__file__).parent / "golden" / "raspa")
