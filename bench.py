@@ -105,7 +105,7 @@ def cpu_baseline(w, mode: str, rows: int):
         pT, tT = run(threads, mid, mid + 1)
         eff = (pT * w.natoms * ngrids / tT) / (threads * single)
     if rows < 0:
-        rows = int(max(1, min(ny, round(12.0 / max(tT, 1e-9)))))
+        rows = int(max(1, min(ny, round(float(os.environ.get("CEG_BENCH_CPU_SECONDS", "12")) / max(tT, 1e-9)))))
     j0 = max(0, mid - rows // 2)
     j1 = min(ny, j0 + rows)
     pts, t = run(threads, j0, j1)

@@ -239,6 +239,93 @@ function pairs_energy(h::Ptr{Cvoid}, placements, idx2::Vector{Int}, exclude_mole
     out
 end
 
+# ------------------------------------------------------------------ Monte-Carlo inner loop (BASELINE config 5)
+# Device-resident twin of the energy state of a MonteCarloSetup: movement_energy (src/montecarlo.jl:563-579) in one launch,
+# update_mc! (src/montecarlo.jl:615-628) on the device.  The driver (src/simulation.jl:727-781) keeps proposing and accepting.
+
+"`ceg_mc_create` + `ceg_mc_set_guests` from a `MonteCarloSetup` after `baseline_energy(mc)`; `vdw`/`coulomb` from `interp_handle`"
+function mc_handle(mc::CEG.MonteCarloSetup, vdw::Vector{Ptr{Cvoid}}, coulomb::Ptr{Cvoid}; device=0)
+    step = mc.step; ff = step.ff
+    nkinds = size(ff.interactions, 1)
+    charge = Float64[k <= length(step.charges) ? NoUnits(step.charges[k]/u"e_au") : 0.0 for k in 1:nkinds]
+    charge[isnan.(charge)] .= 0.0
+    flat = CegRule[]; offsets = Int32[0]
+    for a in 1:nkinds, b in 1:nkinds
+        for r in _rules(ff.interactions[a, b])
+            p = r.params
+            push!(flat, CegRule(Int32(Int(r.kind)), 0, get(p, 1, 0.0), get(p, 2, 0.0), get(p, 3, 0.0), r.shift))
+        end
+        push!(offsets, Int32(length(flat)))
+    end
+    mat = Vector{Float64}(vec(NoUnits.(step.mat ./ u"Å"))); invmat = Vector{Float64}(vec(inv(NoUnits.(step.mat ./ u"Å"))))
+    ef = mc.ewald.ctx.eframework
+    ijk = Int32[]
+    for (jy, jz, jxrange, _) in ef.kspace.kindices, jx in jxrange
+        push!(ijk, jx, jy, jz)
+    end
+    sf = ef.StoreRigidChargeFramework
+    re, im_ = Vector{Float64}(real.(sf)), Vector{Float64}(imag.(sf))
+    ks = Int32[ef.kspace.ks...]; einv = Vector{Float64}(vec(NoUnits.(ef.invmat .* u"Å")))
+    cutoff2 = NoUnits(ff.cutoff^2/u"Å^2")
+    coulombic = ustrip(u"K*Å/e_au^2", COULOMBIC_CONVERSION_FACTOR)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve vdw charge mat invmat flat offsets ijk re im_ ks einv _check(ccall((:ceg_mc_create, LIB[]), Cint,
+        (Ref{Ptr{Cvoid}}, Int32, Ptr{Ptr{Cvoid}}, Ptr{Cvoid}, Ptr{Float64}, Int32, Ptr{Float64}, Ptr{Float64}, Float64,
+         Ptr{CegRule}, Ptr{Int32}, Float64, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Int32}, Ptr{Float64}),
+        h, device, vdw, coulomb, charge, nkinds, mat, invmat, cutoff2, flat, offsets, coulombic,
+        ijk, ef.kfactors, re, im_, length(ef.kfactors), ks, einv))
+    # guests in the order of the Ewald indices ij (mc.revflatidx)
+    pos = Float64[]; kinds = Int32[]; first = Int32[0]
+    for (i, j) in mc.revflatidx
+        for (k, l) in enumerate(step.posidx[i][j])
+            append!(pos, NoUnits.(step.positions[l] ./ u"Å")); push!(kinds, Int32(step.ffidx[i][k] - 1))
+        end
+        push!(first, Int32(length(kinds)))
+    end
+    GC.@preserve pos kinds first _check(ccall((:ceg_mc_set_guests, LIB[]), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}, Int32), h[], pos, kinds, first, length(first)-1))
+    h[]
+end
+
+"movement_energy of species `ij` (Ewald index, 1-based) where it is (column 1) and at `newpos` (column 2); rows: framework vdw, framework direct, inter, reciprocal (K)"
+function mc_trial(h::Ptr{Cvoid}, ij::Int, newpos)
+    pts = _pts(newpos); out = Matrix{Float64}(undef, 4, 2)
+    GC.@preserve pts out _check(ccall((:ceg_mc_trial, LIB[]), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Int64, Ptr{Float64}),
+                                      h, ij - 1, pts, 1, out))
+    out
+end
+
+"update_mc!(mc, idx, newpos) for a displacement, on the device (asynchronous)"
+function mc_accept(h::Ptr{Cvoid}, ij::Int, newpos)
+    pts = _pts(newpos)
+    GC.@preserve pts _check(ccall((:ceg_mc_accept, LIB[]), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), h, ij - 1, pts))
+    nothing
+end
+
+"movement_energy of a NEW species with ff indices `idx` at `newpos` (ij < 0 in src/ewald.jl:704-728) -> 4 energies"
+function mc_trial_insert(h::Ptr{Cvoid}, idx::Vector{Int}, newpos)
+    pts = _pts(newpos); kinds = Int32.(idx .- 1); out = Vector{Float64}(undef, 4)
+    GC.@preserve pts kinds out _check(ccall((:ceg_mc_trial_insert, LIB[]), Cint,
+        (Ptr{Cvoid}, Ptr{Int32}, Int32, Ptr{Float64}, Int64, Ptr{Float64}), h, kinds, length(kinds), pts, 1, out))
+    out
+end
+
+"add_one_system! on the device; returns the new Ewald index ij (1-based)"
+function mc_insert(h::Ptr{Cvoid}, idx::Vector{Int}, newpos)
+    pts = _pts(newpos); kinds = Int32.(idx .- 1); ij = Ref{Int32}(-1)
+    GC.@preserve pts kinds _check(ccall((:ceg_mc_insert, LIB[]), Cint,
+        (Ptr{Cvoid}, Ptr{Int32}, Int32, Ptr{Float64}, Ref{Int32}), h, kinds, length(kinds), pts, ij))
+    Int(ij[]) + 1
+end
+
+"remove_one_system! on the device; returns oldij like src/ewald.jl:404-413 (the species that now answers to `ij`)"
+function mc_remove(h::Ptr{Cvoid}, ij::Int)
+    moved = Ref{Int32}(-1)
+    _check(ccall((:ceg_mc_remove, LIB[]), Cint, (Ptr{Cvoid}, Int32, Ref{Int32}), h, ij - 1, moved))
+    Int(moved[]) + 1
+end
+
+
 # ------------------------------------------------------------------ blocking masks (SURVEY 8f row f4)
 _to_bitarray(mask::Vector{UInt8}, a, b, c) = BitArray(permutedims(reshape(mask, c, b, a), (3, 2, 1)) .!= 0)
 

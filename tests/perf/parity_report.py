@@ -21,8 +21,15 @@ def report(name, got, ref):
     ulp = ulp_distance(got[fin], ref[fin])
     med = np.median(np.abs(ref[fin])) if fin.any() else 0.0
     rel = np.abs(got[fin].astype(np.float64) - ref[fin]) / np.maximum(np.abs(ref[fin].astype(np.float64)), 1e-9 * med)
+    where = ""
+    if rel.size and rel.max() > 2e-7:          # beyond one Float32 ULP: show how small the value is against its channel
+        q = int(np.argmax(rel))
+        ch = int(np.unravel_index(np.flatnonzero(fin)[q], got.shape)[1])          # arrays are [plane, channel, y, z]
+        col = ref[:, ch]
+        cmed = np.median(np.abs(col[np.isfinite(col)]))
+        where = f"  (worst at |value| = {abs(float(ref[fin][q])) / cmed:.1e} x the median of channel {ch}: a sum that cancels)"
     print(f"{name:78s} values {got.size:10d}  identical {same.sum() / got.size * 100:9.5f} %  differing {int((~same).sum()):6d}  "
-          f"max ulp {int(ulp.max()) if ulp.size else 0:3d}  max rel {rel.max() if rel.size else 0:.2e}  non-finite {int((~fin).sum())}", flush=True)
+          f"max ulp {int(ulp.max()) if ulp.size else 0:3d}  max rel {rel.max() if rel.size else 0:.2e}  non-finite {int((~fin).sum())}{where}", flush=True)
 
 def planes(w, n):
     nx = w.cset.npoints[0]

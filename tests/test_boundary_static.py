@@ -78,6 +78,7 @@ _JULIA_CLASS = {
     "Float64": "f64", "Int64": "i64", "Int32": "i32", "Cint": "i32", "Cstring": "char*",
     "Ptr{Float64}": "f64*", "Ptr{Int64}": "i64*", "Ptr{Int32}": "i32*", "Ptr{Cfloat}": "f32*",
     "Ptr{CegRule}": "rule*", "Ptr{Cvoid}": "void*", "Ref{Ptr{Cvoid}}": "handle**", "Ptr{UInt8}": "void*",
+    "Ptr{Ptr{Cvoid}}": "handle**", "Ref{Int32}": "i32*",
 }
 
 
@@ -117,7 +118,7 @@ def julia_ccalls():
 def test_julia_ccalls_match_the_header():
     hp = header_prototypes()
     calls = julia_ccalls()
-    assert len(calls) >= 11
+    assert len(calls) >= 18
     for name, ret, types, args in calls:
         assert name in hp, f"CEGHip.jl calls {name}, which include/ceg_hip.h does not declare"
         hret, hparams = hp[name]
@@ -128,7 +129,8 @@ def test_julia_ccalls_match_the_header():
             assert t in _JULIA_CLASS, (name, pos, t)
             assert _compatible(h, _JULIA_CLASS[t]), f"{name} argument {pos}: Julia {t} vs C {h}"
     # the two methods the shim overrides and the streamed variant all reach their entry point
-    assert {"ceg_grid_vdw", "ceg_grid_coulomb", "ceg_grid_vdw_file", "ceg_last_error"} <= {c[0] for c in calls}
+    assert {"ceg_grid_vdw", "ceg_grid_coulomb", "ceg_grid_vdw_file", "ceg_last_error", "ceg_mc_create", "ceg_mc_set_guests", "ceg_mc_trial",
+            "ceg_mc_accept", "ceg_mc_trial_insert", "ceg_mc_insert", "ceg_mc_remove"} <= {c[0] for c in calls}
 
 
 def test_julia_shim_does_not_strip_units_off_unitless_constants():

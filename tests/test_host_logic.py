@@ -332,3 +332,21 @@ def test_scripts_compile_and_pair_work_count():
     assert pw["buckingham_per_point"] == 0.0
     pn = W.count_pair_work(W.roofline_workload("Na", 255), planes=3, stride=16)
     assert pn["lj_per_point"] == 0.0 and abs(pn["buckingham_per_point"] - pw["lj_per_point"]) < 1e-9
+
+
+def test_bench_cpu_baseline_leg(monkeypatch):
+    """bench.py's cpu_baseline (the oracle timed on a bounded sample; runs on the GPU box at N = 1 only) on a small workload:
+    automatic row count, real thread count, preallocated output, the per-thread rates it reports."""
+    import importlib.util
+    root = Path(__file__).resolve().parent.parent
+    spec = importlib.util.spec_from_file_location("bench_module", root / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setenv("CEG_BENCH_CPU_SECONDS", "0.5")
+    w = W.fixture_workload("CIT-7", "Ar", 0.0, dims=(23, 23, 23))
+    for mode in ("fused", "vdw"):
+        cb = bench.cpu_baseline(w, mode, -1)
+        assert cb["kind"] == "port" and cb["unit"] == "grid-points/s" and cb["value"] > 0
+        assert 1 <= cb["cores"] <= 1024 and 0.05 < cb["parallel_efficiency"] < 1.5
+        assert cb["pair_checks_per_s_per_thread"] == pytest.approx(cb["pair_checks_per_s"] / cb["cores"])
+        assert "preallocated" in cb["sample"]
