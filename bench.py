@@ -92,10 +92,10 @@ def cpu_baseline(w, mode: str, rows: int):
         t = time.perf_counter() - t
         return planes * (j1 - j0) * nz, t
 
+    threads = int(os.environ.get("CEG_BENCH_THREADS", "0")) or O.usable_cpus()
     run(1, mid, mid + 1)                                         # page in the library and the touched rows
     p1, t1 = run(1, mid, mid + 1)
     single = p1 * w.natoms * ngrids / t1                         # pair checks/s of one thread alone
-    threads = int(os.environ.get("CEG_BENCH_THREADS", "0")) or O.usable_cpus()
     pT, tT = run(threads, mid, mid + 1)
     eff = (pT * w.natoms * ngrids / tT) / (threads * single)
     if eff < 0.5 and threads > 16 and "CEG_BENCH_THREADS" not in os.environ:

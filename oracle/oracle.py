@@ -338,4 +338,4 @@ def usable_cpus() -> int:
             pass
     if quota is not None:
         n = min(n, max(1, math.floor(quota + 1e-9)))
-    return max(1, min(n, max_threads()))
+    return max(1, min(n, os.cpu_count() or n))       # (not omp_get_max_threads(): a previous call with nthreads = 1 lowers it)
