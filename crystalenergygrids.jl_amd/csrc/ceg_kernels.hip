@@ -19,11 +19,17 @@
 //    been expanded on the host into explicit lattice images binned on a cartesian
 //    lattice; the wave gathers the images whose bin rows intersect the tile's cutoff
 //    neighbourhood, prunes them against the tile box, compacts the survivors into LDS
-//    and every lane then loops over the same (broadcast) candidate.  For each
+//    grouped by class (VdW-active / Coulomb only / near a cell-wrap boundary) and every lane
+//    then loops over the same (broadcast) candidate, one branch-free loop per class.  For each
 //    (point, image) pair inside the cutoff the reference's *selection rule* (is this
 //    image the one periodic_distance2! would return?) is evaluated exactly, including
 //    the `ortho` shortcut and the stale-vector fall-through of src/utils.jl:234-245.
-//    O(N_grid * n_cut).
+//    O(N_grid * n_cut).  Radial arithmetic of the hot loops: 1/r^2 by v_rcp_f64 + one Newton
+//    step; real-space Ewald factors from r^2-indexed polynomial tables + the B_n recurrence
+//    (EWK = 2: no sqrt / exp / erfc); Lennard-Jones in closed form; a single Buckingham class
+//    from an r^2-indexed table of A exp(-B r) (VDWK = 3); everything the tables do not cover
+//    (r < 2 A, threshold bands, wrap-boundary images) is redone with the reference's literal
+//    arithmetic after the loops (slow_pairs).
 //
 // No MFMA: this is a pairwise FP64 reduction, bound by the FP64 vector ALU.
 #include <type_traits>

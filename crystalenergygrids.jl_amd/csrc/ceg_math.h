@@ -1,10 +1,11 @@
-// ceg_math.h -- FP64 building blocks of the hot loop, written for the CDNA4 vector ALU:
+// ceg_math.h -- FP64 building blocks of the hot loops, written for the CDNA4 vector ALU:
 // no IEEE division / sqrt / libm calls (each costs 10-40 VALU instructions), only
-// v_rsq_f64 / v_rcp_f64 seeds refined by FMA Newton steps, a range-reduced exp and a
-// polynomial for erfcx.  Every function is accurate to a few 1e-16 relative on its stated
-// domain (tests/test_gpu_parity.py::test_radial_functions_accuracy), far inside the 1e-6
-// parity tolerance, so the result differs from the reference's Base.exp /
-// SpecialFunctions.erfc by rounding only.
+// v_rsq_f64 / v_rcp_f64 seeds (4.6e-8 / 5.2e-8 relative, scripts/probes/seed_accuracy.hip) refined by ONE
+// Newton / coupled Goldschmidt step (2e-15 / 4e-15), a range-reduced table exp and an erfcx table for the
+// variants that still evaluate exp / erfc in the loop (EWK = 1, per-candidate Buckingham classes), and the
+// scalar-operand FMA forms the compiler does not emit by itself.  The r^2-indexed tables of EWK = 2 / VDWK = 3
+// are described in ceg_internal.h (layout) and ceg_api.hip (host-side fit).  Accuracy of every path against the
+// oracle's libm: tests/test_gpu_parity.py::test_fast_math_accuracy_single_pair.
 #pragma once
 
 #include <hip/hip_runtime.h>

@@ -35,7 +35,11 @@ while done < n_cfg:
     pos = random_atoms(mat, n, rng, min_sep=float(rng.uniform(0.9, 2.0)))
     generic = rng.random() < 0.2
     hs = float(rng.choice([1.5, 1.5, 2.6]))
-    pv, pc = synthetic_probes(mat, pos, rng.integers(1, 5, n), rng.uniform(-1.5, 1.5, n), cutoff=cutoff, generic=generic, hs_radius=hs)
+    # kind palettes: everything mixed (per-candidate LJ / Buckingham classes), LJ kinds only, Buckingham + none only (the single
+    # tabulated Buckingham class of the culled kernel)
+    palette = [np.array([1, 2, 3, 4]), np.array([1, 3, 4]), np.array([2, 3])][int(rng.integers(0, 3))]
+    stats["palette%d" % len(palette)] = stats.get("palette%d" % len(palette), 0) + 1
+    pv, pc = synthetic_probes(mat, pos, palette[rng.integers(0, len(palette), n)], rng.uniform(-1.5, 1.5, n), cutoff=cutoff, generic=generic, hs_radius=hs)
     ortho, safemin2 = pv.periodic_setup()
     stats["ortho" if ortho else ("stale" if safemin2 < cutoff ** 2 else "plain")] += 1
     stats["generic"] += int(generic)

@@ -284,3 +284,40 @@ def test_gpu_montecarlo_energies(hip_lib, oracle, tmp_path):
         assert vals[0] == pytest.approx(-248306.13377495, rel=1e-7) and vals[1] == pytest.approx(-248306.13817777, rel=1e-7)
     finally:
         ceg.setdir_RASPA(golden)
+
+
+def test_incremental_ewald_sums_of_the_mirror(monkeypatch):
+    """update_mc / add_molecule / remove_molecule of the host mirror (update_ewald_context!, add_one_system!, remove_one_system!:
+    ewald.jl:757-810) keep `sums` equal to what compute_ewald(::IncrementalEwaldContext) (ewald.jl:630-652) rebuilds from scratch,
+    and single_contribution_ewald differences equal the change of the full reciprocal energy (the relation runtests.jl:234,261 rely on)."""
+    monkeypatch.setattr(M, "retrieve_or_create_grid", lambda *a, **k: G.EnergyGrid.trivial(True))
+    mc = _trio(M)
+    M.compute_ewald_mc(mc)
+    rng = np.random.default_rng(5)
+    for step in range(40):
+        kind = int(rng.integers(2))
+        if step % 5 == 0:
+            shape = mc.positions[kind][0] - mc.positions[kind][0][0] if mc.positions[kind] else np.zeros((len(mc.ffidx[kind]), 3))
+            M.add_molecule(mc, kind, rng.uniform(0, 25, 3) + shape)
+        elif step % 5 == 3 and len(mc.positions[kind]) > 1:
+            M.remove_molecule(mc, (kind, int(rng.integers(len(mc.positions[kind])))))
+        elif mc.positions[kind]:
+            j = int(rng.integers(len(mc.positions[kind])))
+            new = mc.positions[kind][j] + rng.uniform(-1, 1, 3)
+            e0 = M.compute_ewald_mc(_copy_mc(mc))
+            d = M.single_contribution_ewald(mc, (kind, j), new) - M.single_contribution_ewald(mc, (kind, j))
+            M.update_mc(mc, (kind, j), new)
+            e1 = M.compute_ewald_mc(_copy_mc(mc))
+            assert e1 - e0 == pytest.approx(d, rel=1e-9, abs=1e-7)
+        ref = _copy_mc(mc)
+        M.compute_ewald_mc(ref)
+        assert ref.sums.shape == mc.sums.shape
+        np.testing.assert_allclose(mc.sums, ref.sums, rtol=0, atol=1e-10 * max(1.0, np.abs(ref.sums).max()))
+
+
+def _copy_mc(mc):
+    import copy
+    c = copy.copy(mc)
+    c.positions = [[p.copy() for p in kind] for kind in mc.positions]
+    c.sums = None
+    return c
