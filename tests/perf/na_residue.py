@@ -3,13 +3,13 @@ every term of the energy separately, the interpolated grid terms beside the exac
 position, and the sensitivity of the total to each ingredient.  CPU only (oracle + host mirror)."""
 import json, math, os, sys
 here = os.path.dirname(os.path.abspath(__file__))
-sys.path[:0] = [os.path.join(here, '..', 'crystalenergygrids.jl_amd'), os.path.join(here, '..'), os.path.join(here, '..', 'tests')]
+sys.path[:0] = [os.path.join(here, '..', '..', 'crystalenergygrids.jl_amd'), os.path.join(here, '..', '..'), os.path.join(here, '..')]
 import numpy as np
 import ceg_hip as ceg
 from ceg_hip import grids as G
 from ceg_hip.probes import ProbeSystem
 from oracle import oracle as O
-ceg.setdir_RASPA(os.path.join(here, '..', 'tests', 'golden', 'raspa'))
+ceg.setdir_RASPA(os.path.join(here, '..', 'golden', 'raspa'))
 FF = "BoulfelfelSholl2021"
 ff = ceg.parse_forcefield_RASPA(FF)
 
@@ -98,3 +98,15 @@ if __name__ == "__main__":
     vm, dm, rm, vxm, dxm, _ = report("Na/CHA energy_grid minimum (29,60,60) (runtests.jl:49)", "CHA_1.4_3b4eeb96", pmin, -1927894.4364761321)
     print(f"   total {vm + dm + rm:.6f}   literal -1927894.436476   residue {vm + dm + rm + 1927894.4364761321:+.4f} K;  with exact framework terms "
           f"{vxm + dxm + rm + 1927894.4364761321:+.4f} K")
+    # --- Ewald convergence of the restatement: exact direct sum + reciprocal sum for precision 1e-6 ... 1e-12
+    from ceg_hip.utils import find_supercell
+    fwc = ceg.load_framework_RASPA("CIT-7", FF)
+    pcc = ProbeSystem.build(fwc, ff)
+    nac = ceg.load_molecule_RASPA("Na", "TraPPE", FF, fwc)
+    for name, p, lit, other in (("baseSolo", solo, -21375.116833457894, v + tail), ("baseSoloNext", nxt, -21795.8765195143, v2 + tail)):
+        print(f"\\n== {name}: Coulomb part implied by the literal (literal - VdW - tail) = {lit - other:.5f}")
+        for prec in (1e-6, 1e-8, 1e-10, 1e-12):
+            ewp = ceg.initialize_ewald(fwc, tuple(find_supercell(fwc.mat, 12.0)), prec)
+            dd = nac.atomic_charge[0] * exact(pcc, np.asarray(p, dtype=np.float64), ewp.alpha)
+            rr = ceg.compute_ewald(ewp, ((nac.with_positions([p]),),))
+            print(f"   precision {prec:g}: alpha {ewp.alpha:.5f}, {len(ewp.kfactors):6d} k-vectors: direct (exact) {dd:14.5f} + reciprocal {rr:14.5f} = {dd + rr:14.5f}")
