@@ -104,7 +104,7 @@ if __name__ == "__main__":
     pcc = ProbeSystem.build(fwc, ff)
     nac = ceg.load_molecule_RASPA("Na", "TraPPE", FF, fwc)
     for name, p, lit, other in (("baseSolo", solo, -21375.116833457894, v + tail), ("baseSoloNext", nxt, -21795.8765195143, v2 + tail)):
-        print(f"\\n== {name}: Coulomb part implied by the literal (literal - VdW - tail) = {lit - other:.5f}")
+        print(f"\n== {name}: Coulomb part implied by the literal (literal - VdW - tail) = {lit - other:.5f}")
         for prec in (1e-6, 1e-8, 1e-10, 1e-12):
             ewp = ceg.initialize_ewald(fwc, tuple(find_supercell(fwc.mat, 12.0)), prec)
             dd = nac.atomic_charge[0] * exact(pcc, np.asarray(p, dtype=np.float64), ewp.alpha)

@@ -82,6 +82,15 @@ def test_consumer_entry_points_reject_bad_arguments_and_have_no_cpu_path():
     assert lib.ceg_pairs_create(C.byref(h), 0, _abi.dptr(mat), _abi.dptr(inv), 144.0, rules.ctypes.data, _abi.i32ptr(off), 2,
                                 1.0) == -4
     assert b"Undefined" in lib.ceg_last_error()
+    # Monte-Carlo state: undefined interaction in the pair table, k-space tables announced but missing, calls on a NULL handle
+    charge2 = np.zeros(2)
+    assert lib.ceg_mc_create(C.byref(h), 0, None, None, _abi.dptr(charge2), 2, _abi.dptr(mat), _abi.dptr(inv), 144.0, rules.ctypes.data,
+                             _abi.i32ptr(off), 1.0, None, None, None, None, 0, None, None) == -4
+    assert lib.ceg_mc_create(C.byref(h), 0, None, None, _abi.dptr(charge2), 2, _abi.dptr(mat), _abi.dptr(inv), 144.0, rules.ctypes.data,
+                             _abi.i32ptr(off), 1.0, None, None, None, None, 5, None, None) == -1
+    assert lib.ceg_mc_trial(None, 0, None, 0, None) == -1 and lib.ceg_mc_accept(None, 0, None) == -1
+    assert lib.ceg_mc_insert(None, None, 0, None, None) == -1 and lib.ceg_mc_remove(None, 0, None) == -1
+    assert lib.ceg_mc_destroy(None) == 0
     # blocking masks: null pointers / empty dims
     dims = np.array([3, 3, 3], dtype=np.int32)
     assert lib.ceg_block_from_grid(0, None, 0, _abi.i32ptr(dims), 5e6, None) == -1
@@ -97,6 +106,11 @@ def test_consumer_entry_points_reject_bad_arguments_and_have_no_cpu_path():
     value = np.zeros((4, 4, 4), dtype=np.float32)
     out = np.zeros((4, 4, 4), dtype=np.uint8)
     assert lib.ceg_block_from_grid(0, value.ctypes.data, 0, _abi.i32ptr(dims), 5e6, out.ctypes.data) == -2
+    # device-resident Monte-Carlo state: no device, no state (and never a CPU evaluation)
+    charge = np.zeros(2)
+    assert lib.ceg_mc_create(C.byref(h), 0, None, None, _abi.dptr(charge), 2, _abi.dptr(mat), _abi.dptr(inv), 144.0, rules.ctypes.data,
+                             _abi.i32ptr(off), 1.0, None, None, None, None, 0, None, None) == -2
+    assert b"no HIP device" in lib.ceg_last_error() and not h.value
 
 
 # ------------------------------------------------------------------ geometry
