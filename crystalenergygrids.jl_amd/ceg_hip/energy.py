@@ -337,6 +337,29 @@ class DeviceMonteCarlo:
                     if v == moved.value:
                         kind[q] = d
 
+    def baseline_energy(self):
+        """baseline_energy (montecarlo.jl:530-542) from the device-resident state: framework and guest-guest terms from row 0 of one
+        trial launch per molecule (every pair is seen from both sides, hence the 1/2), the reciprocal term from the total guest
+        structure factor kept on the device and the two EwaldContext constants (ewald.jl:497-544)."""
+        from . import montecarlo as M
+        from .ewald import ewald_context_constants
+        mc = self.mc
+        fv = fd = inter = 0.0
+        for i, kind in enumerate(self._slot):
+            m = len(mc.ffidx[i])
+            for j in range(len(kind)):
+                row = self.trial((i, j), np.empty((0, m, 3)))[0]
+                fv += row[0]; fd += row[1]; inter += row[2]
+        reciprocal = 0.0
+        ef = mc.ewald
+        if ef.alpha != 0.0:
+            _pos, a = self.state()
+            enc, static = ewald_context_constants(ef, [k for k in M._ewald_systems(mc) if k])
+            f = ef.StoreRigidChargeFramework
+            reciprocal = (2 * (float((ef.kfactors * (f.real * a.real + f.imag * a.imag)).sum()) + enc)
+                          + float((ef.kfactors * (a.real ** 2 + a.imag ** 2)).sum()) + static)
+        return M.BaselineEnergyReport(fv, fd, 0.5 * inter, reciprocal, mc.tailcorrection)
+
     def state(self):
         """(positions[natoms, 3], total guest structure factor complex[nk]) read back from the device."""
         natoms = sum(len(ids) for _i, _j, ids, _p in self.mc.molecules())

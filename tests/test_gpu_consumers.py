@@ -237,6 +237,10 @@ def test_mc_replay_1000_moves(hip_lib, tmp_path):
             r = np.array([ref.framework_vdw, ref.framework_direct, ref.inter, ref.reciprocal])
             ok = np.abs(r) < 1e90
             assert np.all(np.abs(rows[1 + t][ok] - r[ok]) <= 1e-9 * np.abs(r[ok]) + 1e-7)
+        # baseline_energy of the final configuration from the device state == the host mirror's
+        b_dev, b_host = dev.baseline_energy(), M.baseline_energy(mc)
+        for name in ("framework_vdw", "framework_direct", "inter", "reciprocal"):
+            assert getattr(b_dev, name) == pytest.approx(getattr(b_host, name), rel=1e-9, abs=1e-6), name
         print(f"mc replay: 1000 moves, {naccept} accepted, worst error {worst:.2e} of the tolerance")
         dev.close()
     finally:
