@@ -722,6 +722,18 @@ extern "C" int ceg_plan_create(ceg_plan_t** plan, int32_t device,
         hc.rt = RuleTable{p->d_rules, p->d_offset, p->nkinds};
         hc.alpha2 = alpha * alpha;
         hc.r_exact2 = p->r_exact2;
+        {   // |f_k(centre - image)| <= |row_k(invmat)| (reach of a kept image from the tile centre) for every image a 4x4x4 tile can
+            // keep; if that plus the fractional half-extent of the tile stays below 1/2 on all three axes the kernel skips the test
+            const double hx = 1.5 * delta[0], hy = 1.5 * delta[1], hz = 1.5 * delta[2];
+            const double reach = std::sqrt(cutoff2 * (1.0 + 1e-9) + 1e-9) + std::sqrt(hx * hx + hy * hy + hz * hz);
+            bool all = true;
+            for (int k = 0; k < 3; ++k) {
+                const double rown = std::sqrt(invmat[k] * invmat[k] + invmat[k + 3] * invmat[k + 3] + invmat[k + 6] * invmat[k + 6]);
+                const double ek = std::fabs(invmat[k]) * hx + std::fabs(invmat[k + 3]) * hy + std::fabs(invmat[k + 6]) * hz + 1e-9;
+                if (!(rown * reach + ek < 0.5 - 1e-6)) all = false;
+            }
+            hc.all_simple = all ? 1 : 0;
+        }
         if (p->h_fast.empty()) p->h_fast.assign(1, FastVdw{});
         rc = upload(&p->d_fast, p->h_fast.data(), p->h_fast.size());
         hc.fastvdw = p->d_fast;

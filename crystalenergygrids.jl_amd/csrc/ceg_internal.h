@@ -121,6 +121,8 @@ struct PlanConst {
     const double* bk2_tab;
     int32_t bk2_ni, bk2_base;
     double bk_B, bk_C, bk_shift;
+    int32_t all_simple;        // grid mode: every image a tile can keep is provably the fractionally wrapped one (no per-candidate test)
+    int32_t _pad2;
 };
 
 // shared between the host table builder and the kernels

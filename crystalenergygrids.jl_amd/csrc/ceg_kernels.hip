@@ -625,6 +625,7 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
     int ew2_stride = CEG_EW2_STRIDE * 8;              // kept in a VGPR: v_mad_u32_u24 reads one scalar operand (ew2_off)
     asm volatile("" : "+v"(ew2_stride));
     const double two_alpha2 = pc->two_alpha2;
+    const bool all_simple = __builtin_amdgcn_readfirstlane(pc->all_simple) != 0;
     const int bk2_off = BK2 ? __builtin_amdgcn_readfirstlane(-pc->bk2_base * (CEG_BK2_STRIDE * 8)) : 0;
     int bk2_stride = CEG_BK2_STRIDE * 8;
     asm volatile("" : "+v"(bk2_stride));
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
                     }
                 }
                 if (MODE == MODE_VDW) keep = keep && hasvdw;   // kinds without a rule contribute exact zeros
-                bool simple = g.diag != 0;
+                bool simple = g.diag != 0 || (!POINTS && all_simple);
                 if (!simple && keep) {
                     const double* I = g.invmat;
                     const double ux = cx - P.x, uy = cy - P.y, uz = cz - P.z;

@@ -5,6 +5,14 @@ from pathlib import Path
 
 import pytest
 
+# torch ships its own HIP runtime: when it is first imported AFTER libceg_hip.so (linked against /opt/rocm) has initialised
+# the device in the same process, its lazy CUDA initialisation reports "No HIP GPUs are available" (observed when
+# tests/test_gpu_parity.py runs on its own).  Importing it up front keeps the suite independent of the collection order.
+try:
+    import torch  # noqa: F401
+except ImportError:           # the CPU-only parts of the suite do not need it
+    pass
+
 ROOT = Path(__file__).resolve().parent.parent
 for p in (str(ROOT / "crystalenergygrids.jl_amd"), str(ROOT)):
     if p not in sys.path:
