@@ -377,7 +377,14 @@ int build_images(ceg_plan* p)
                     Img im;
                     im.x = P[0]; im.y = P[1]; im.z = P[2];
                     im.q = p->has_charge ? p->h_charge[a] : 0.0;
-                    im.kind = p->has_rules ? p->h_kind[a] : -1;
+                    // kind (low 24 bits) + bit 25: the kind has at least one VdW rule (= META_HASVDW of the kernel), so that the
+                    // staging loop does not have to look the rule offsets up per image
+                    im.kind = -1;
+                    if (p->has_rules) {
+                        const int32_t k = p->h_kind[a];
+                        const bool hasvdw = k >= 0 && k + 1 < (int32_t)p->h_offset.size() && p->h_offset[k + 1] > p->h_offset[k];
+                        im.kind = k < 0 ? -1 : (k | (hasvdw ? (1 << 25) : 0));
+                    }
                     im.bin = (b[0] * nb[1] + b[1]) * nb[2] + b[2];
                     im.atom = (int32_t)a;
                     imgs.push_back(im);

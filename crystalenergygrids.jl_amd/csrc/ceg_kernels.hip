@@ -681,7 +681,8 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
                 const int img = s_rowstart[lo] + (t - s_rowprefix[lo]);
                 P = ib.xyzq[img];
                 aidx = ib.atom[img];
-                const int kd = ib.kind ? ib.kind[img] : -1;
+                const int kw = ib.kind ? ib.kind[img] : -1;            // kind | META_HASVDW (set on the host), or -1
+                const int kd = kw < 0 ? -1 : (kw & META_KINDMASK);
                 const double qx = fmax(0.0, fabs(cx - P.x) - hx);
                 const double qy = fmax(0.0, fabs(cy - P.y) - hy);
                 const double qz = fmax(0.0, fabs(cz - P.z) - hz);
@@ -689,8 +690,7 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
                 bool hasvdw = false;
                 int vclass = 0;
                 if (MODE != MODE_COULOMB && kd >= 0) {
-                    const int rb = rt.offset[kd];
-                    hasvdw = rt.offset[kd + 1] > rb;
+                    hasvdw = (kw & META_HASVDW) != 0;
                     if (FASTVDW && VDWK != 3 && hasvdw && keep) {
                         const FastVdw F = pc->fastvdw[kd];          // class + parameters of this kind
                         LJ = make_double4(F.p0, F.p1, F.p2, F.shift);
