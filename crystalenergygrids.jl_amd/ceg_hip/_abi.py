@@ -98,6 +98,7 @@ PROTOTYPES = {
     "ceg_pairs_set_atoms": (C.c_int, [C.c_void_p, c_double_p, c_int32_p, c_int32_p, C.c_int64]),
     "ceg_pairs_energy": (C.c_int, [C.c_void_p, c_double_p, c_int32_p, C.c_int32, C.c_int64, C.c_int32, c_double_p]),
     "ceg_pairs_energy_device": (C.c_int, [C.c_void_p, C.c_void_p, c_int32_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "ceg_pairs_neighbour_cells": (C.c_int, [C.c_void_p, c_int32_p]),
     "ceg_mc_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p), C.c_void_p, c_double_p, C.c_int32, c_double_p,
                                 c_double_p, C.c_double, C.c_void_p, c_int32_p, C.c_double, c_int32_p, c_double_p, c_double_p, c_double_p,
                                 C.c_int64, c_int32_p, c_double_p]),
@@ -106,6 +107,7 @@ PROTOTYPES = {
     "ceg_mc_trial": (C.c_int, [C.c_void_p, C.c_int32, c_double_p, C.c_int64, c_double_p]),
     "ceg_mc_accept": (C.c_int, [C.c_void_p, C.c_int32, c_double_p]),
     "ceg_mc_get_state": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
+    "ceg_mc_neighbour_cells": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p]),
     "ceg_mc_trial_insert": (C.c_int, [C.c_void_p, c_int32_p, C.c_int32, c_double_p, C.c_int64, c_double_p]),
     "ceg_mc_insert": (C.c_int, [C.c_void_p, c_int32_p, C.c_int32, c_double_p, c_int32_p]),
     "ceg_mc_remove": (C.c_int, [C.c_void_p, C.c_int32, c_int32_p]),

@@ -279,6 +279,16 @@ class DeviceMonteCarlo:
         self._h = h
         self.refresh()
 
+    def neighbour_cells(self):
+        """-> (bins per axis, capacity per cell) of the guest neighbour cells, or None when the guest-guest sum runs the exhaustive
+        loop (MC cells of a few cutoffs, i.e. every fixture of the reference; energy.jl:340-349 is the reference's own switch)."""
+        nb = np.zeros(3, dtype=np.int32)
+        cap = C.c_int32(0)
+        rc = self._lib.ceg_mc_neighbour_cells(self._h, _abi.i32ptr(nb), C.byref(cap))
+        if rc < 0:
+            _abi.check(self._lib, rc)
+        return (tuple(int(x) for x in nb), int(cap.value)) if rc == 1 else None
+
     def refresh(self) -> None:
         """Upload the guests of ``self.mc`` (initial state, or to resynchronise with the host side)."""
         pos, kinds, first = [], [], [0]

@@ -4,7 +4,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdint>
+#include <cstdlib>
 
 #include "../../include/ceg_hip.h"
 #include "ceg_internal.h"
@@ -182,6 +185,73 @@ __device__ __forceinline__ double rule_energy_fast(const DevRule& R, double r2, 
     return v - R.shift;
 }
 
+
+// ---- neighbour cells of the guest atoms (what the reference gets from CellListMap above 1200 atom x threads,
+// src/energy.jl:340-349,398-404): bins of the FRACTIONAL coordinates of the MC cell.  unsafe_periodic_distance2!
+// (src/utils.jl:294-302) measures the one image whose fractional difference lies in [-1/2, 1/2), and |f_i| <= cutoff / width_i
+// for a pair inside the cutoff (width_i = perpendicular width = 1 / |row i of invmat|): the partners of an atom at fractional
+// coordinate f sit in the bins of [f - hfrac, f + hfrac] mod 1 whatever the cell shape.  The kernels run every atom of those
+// bins through the same exact distance test as the exhaustive loop, so the sums are the same sets of pairs.
+struct CellBins {
+    int32_t on;
+    int32_t nb[3];
+    double hfrac[3];          // cutoff / width_i
+};
+
+// Cells pay when the bins a molecule can reach (cutoff sphere + its own extent + a bin either side) hold well under half the MC cell: never for the
+// reference's fixtures (24-36 A wide, cutoff 12 A), by a factor 2-6 for the north-star framework (57 x 57 x 85 A).
+// CEG_HIP_MC_CELLS=1 / 0 forces them on / off, CEG_HIP_MC_BIN sets the bin width (A, default 4).
+inline CellBins choose_cell_bins(const double invmat[9], double cutoff)
+{
+    CellBins cb{};
+    double bin = 4.0;
+    if (const char* e = getenv("CEG_HIP_MC_BIN")) { const double b = atof(e); if (b >= 0.5 && b <= 100.0) bin = b; }
+    double covered = 1.0;
+    int64_t ncells = 1;
+    for (int i = 0; i < 3; ++i) {
+        const double norm = std::sqrt(invmat[i] * invmat[i] + invmat[3 + i] * invmat[3 + i] + invmat[6 + i] * invmat[6 + i]);
+        const double width = 1.0 / norm;
+        cb.hfrac[i] = cutoff * norm;
+        cb.nb[i] = std::max(1, std::min(1024, (int)std::floor(width / bin)));
+        ncells *= cb.nb[i];
+        covered *= std::min(1.0, (2.0 * cutoff + 2.0 * bin + 3.0) / width);
+    }
+    cb.on = covered < 0.5 ? 1 : 0;
+    if (const char* e = getenv("CEG_HIP_MC_CELLS")) cb.on = atoi(e) != 0 ? 1 : 0;
+    if (ncells > (1 << 22)) cb.on = 0;
+    return cb;
+}
+
+inline int cell_of_position(const CellBins& cb, const double invmat[9], const double* p)
+{
+    int b[3];
+    for (int i = 0; i < 3; ++i) {
+        double f = invmat[i] * p[0] + invmat[3 + i] * p[1] + invmat[6 + i] * p[2];
+        f -= std::floor(f);
+        const int q = (int)(f * cb.nb[i]);
+        b[i] = q < 0 ? 0 : (q >= cb.nb[i] ? cb.nb[i] - 1 : q);
+    }
+    return (b[0] * cb.nb[1] + b[1]) * cb.nb[2] + b[2];
+}
+
+// bins along fractional axis `axis` that the cutoff spheres of the m atoms at pos[3m] can reach: `n` bins starting at `first`
+// (periodic, first in [0, nb), n <= nb so that no bin comes twice); 1e-6 of slack covers the rounding of the bin assignment
+__device__ __forceinline__ void cell_range(const double* I, const double* pos, int m, int axis, int nb, double hfrac, int& first, int& n)
+{
+    double lo = 1e300, hi = -1e300;
+    for (int a = 0; a < m; ++a) {
+        const double f = I[axis] * pos[3 * a] + I[3 + axis] * pos[3 * a + 1] + I[6 + axis] * pos[3 * a + 2];
+        lo = fmin(lo, f);
+        hi = fmax(hi, f);
+    }
+    const double slack = hfrac + 1e-6;
+    const long long blo = (long long)floor((lo - slack) * nb), bhi = (long long)floor((hi + slack) * nb);
+    const long long span = bhi - blo + 1;
+    long long f0 = blo % nb;
+    if (f0 < 0) f0 += nb;
+    first = (int)f0;
+    n = (int)(span < nb ? span : nb);
+}
 
 }  // namespace ceg_consumers
 

@@ -19,7 +19,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "../../include/ceg_hip.h"
@@ -65,7 +68,28 @@ struct McView {
     double2* sf_mol;                           // [nmol][nk] sums[:, ij+1]
     double4* atoms;                            // x, y, z, (molecule << 32 | kind); molecule < 0: free slot
     int2* mol;                                 // [nmol] atoms of molecule j: slots [mol[j].x, mol[j].x + mol[j].y)
+    // neighbour cells of the guest atoms (what the reference gets from CellListMap, src/energy.jl:341-349,399-404):
+    // fractional bins of the MC cell, fixed capacity, each holding COPIES of its atoms' records
+    int32_t use_cells, cell_cap;
+    int32_t nb[3];
+    double hfrac[3];                           // cutoff / perpendicular width: fractional half-extent of the cutoff sphere
+    double4* cells;                            // [nb0*nb1*nb2][cell_cap]
+    int32_t* cell_count;                       // [nb0*nb1*nb2]
 };
+
+// what an update does to the cells, worked out on the host mirror of the cell lists: cells[dst[i]] = atoms[src[i]] once the
+// atom records are current, then cell_count[cell[i]] = count[i]
+constexpr int MC_MAX_CELL_OPS = 2 * 16;
+struct McCellOps {
+    int32_t nops, ncnt;
+    int32_t dst[MC_MAX_CELL_OPS], src[MC_MAX_CELL_OPS], cell[MC_MAX_CELL_OPS], count[MC_MAX_CELL_OPS];
+};
+
+__device__ __forceinline__ void apply_cell_ops(const McView& v, const McCellOps& ops, int tid)
+{
+    if (tid < ops.nops) v.cells[ops.dst[tid]] = v.atoms[ops.src[tid]];
+    if (tid < ops.ncnt) v.cell_count[ops.cell[tid]] = ops.count[tid];
+}
 
 // a molecule that is not (yet) in the system: kinds of its atoms (single_contribution_ewald with ij < 0, ewald.jl:704-728)
 struct McMolecule { int32_t m; int32_t kinds[MC_MAX_ATOMS]; };
@@ -132,6 +156,7 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_trial(McView v, int32_t molec
     __shared__ double s_q[MC_MAX_ATOMS];
     __shared__ int32_t s_kind[MC_MAX_ATOMS];
     __shared__ double s_red[MC_THREADS / 64][5];
+    __shared__ int s_bin0[3], s_nbin[3], s_wtot[MC_THREADS / 64], s_first[MC_THREADS], s_cell[MC_THREADS];
     const int tid = threadIdx.x;
     const int64_t b = INSERT ? (int64_t)blockIdx.x + 1 : (int64_t)blockIdx.x;     // 0: where the molecule is now; b >= 1: trial b - 1
     const int first = INSERT ? 0 : v.mol[molecule].x, m = INSERT ? nm.m : v.mol[molecule].y;
@@ -196,11 +221,10 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_trial(McView v, int32_t molec
     {
         const double* M = v.mat;
         const double* I = v.invmat;
-        for (int l = tid; l < v.natoms; l += MC_THREADS) {
-            const double4 A = v.atoms[l];
+        auto pairs_with = [&](const double4 A) __attribute__((always_inline)) {
             int kind1, mol;
             unpack(A.w, kind1, mol);
-            if (mol < 0 || (!INSERT && mol == molecule)) continue;          // :419 (and free slots)
+            if (mol < 0 || (!INSERT && mol == molecule)) return;            // :419 (and free slots)
             for (int a = 0; a < m; ++a) {
                 double r2;
                 {
@@ -227,6 +251,54 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_trial(McView v, int32_t molec
                     for (int q = offset[t]; q < offset[t + 1]; ++q) inter += rule_energy(rules[q], r2, v.coulombic);
                 }
             }
+        };
+        if (!v.use_cells) {
+            for (int l = tid; l < v.natoms; l += MC_THREADS) pairs_with(v.atoms[l]);
+        } else {
+            // only the cells the cutoff spheres of the molecule's atoms can reach (ceg_consumers.h)
+            if (tid < 3) ceg_consumers::cell_range(I, s_pos, m, tid, v.nb[tid], v.hfrac[tid], s_bin0[tid], s_nbin[tid]);
+            __syncthreads();
+            const int n0 = s_nbin[0], n1 = s_nbin[1], n2 = s_nbin[2];
+            const int ncell = n0 * n1 * n2;
+            const int wave = tid >> 6, lane = tid & 63;
+            for (int base = 0; base < ncell; base += MC_THREADS) {
+                const int e = base + tid;
+                int cnt = 0, cell = 0;
+                if (e < ncell) {
+                    const int j2 = e % n2, j1 = (e / n2) % n1, j0 = e / (n2 * n1);
+                    int c0 = s_bin0[0] + j0, c1 = s_bin0[1] + j1, c2 = s_bin0[2] + j2;
+                    if (c0 >= v.nb[0]) c0 -= v.nb[0];
+                    if (c1 >= v.nb[1]) c1 -= v.nb[1];
+                    if (c2 >= v.nb[2]) c2 -= v.nb[2];
+                    cell = (c0 * v.nb[1] + c1) * v.nb[2] + c2;
+                    cnt = v.cell_count[cell];
+                }
+                int incl = cnt;                                            // inclusive scan over the workgroup
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int up = __shfl_up(incl, o);
+                    if (lane >= o) incl += up;
+                }
+                if (lane == 63) s_wtot[wave] = incl;
+                __syncthreads();
+                int before = 0, total = 0;
+#pragma unroll
+                for (int w = 0; w < MC_THREADS / 64; ++w) {
+                    if (w < wave) before += s_wtot[w];
+                    total += s_wtot[w];
+                }
+                s_first[tid] = before + incl - cnt;
+                s_cell[tid] = cell;
+                __syncthreads();
+                for (int l = tid; l < total; l += MC_THREADS) {
+                    int j = 0;                                             // last cell whose first entry is <= l
+#pragma unroll
+                    for (int step = MC_THREADS / 2; step > 0; step >>= 1)
+                        if (s_first[j + step] <= l) j += step;
+                    pairs_with(v.cells[(size_t)s_cell[j] * v.cell_cap + (l - s_first[j])]);
+                }
+                __syncthreads();
+            }
         }
     }
     // ---- block reduction
@@ -252,7 +324,7 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_trial(McView v, int32_t molec
 }
 
 // update_mc! for a displacement (montecarlo.jl:615-628): positions; sums[:,1] += new - sums[:,ij+1]; sums[:,ij+1] = new
-__global__ __launch_bounds__(MC_THREADS) void k_mc_accept(McView v, int32_t molecule, McPositions np, int stride)
+__global__ __launch_bounds__(MC_THREADS) void k_mc_accept(McView v, int32_t molecule, McPositions np, McCellOps ops, int stride)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     __shared__ double s_pos[MC_MAX_ATOMS * 3];
@@ -269,6 +341,7 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_accept(McView v, int32_t mole
         v.atoms[first + tid] = A;
     }
     __syncthreads();
+    if (v.use_cells) apply_cell_ops(v, ops, tid);
     if (v.nk == 0) return;
     double2* tab = reinterpret_cast<double2*>(s_raw);
     fill_tables(v, s_pos, m, tab, stride, tid, MC_THREADS);
@@ -323,7 +396,7 @@ __global__ void k_mc_sf_total(McView v)
 }
 
 // add_one_system! (ewald.jl:775-792, montecarlo.jl:615-621): new molecule `molecule` (= old nmol) in atom slots [first, first + m)
-__global__ __launch_bounds__(MC_THREADS) void k_mc_insert(McView v, int32_t molecule, int32_t first, McMolecule nm, McPositions np, int stride)
+__global__ __launch_bounds__(MC_THREADS) void k_mc_insert(McView v, int32_t molecule, int32_t first, McMolecule nm, McPositions np, McCellOps ops, int stride)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     __shared__ double s_pos[MC_MAX_ATOMS * 3];
@@ -337,6 +410,7 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_insert(McView v, int32_t mole
     }
     if (tid == 0) v.mol[molecule] = make_int2(first, m);
     __syncthreads();
+    if (v.use_cells) apply_cell_ops(v, ops, tid);
     if (v.nk == 0) return;
     double2* tab = reinterpret_cast<double2*>(s_raw);
     fill_tables(v, s_pos, m, tab, stride, tid, MC_THREADS);
@@ -354,7 +428,7 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_insert(McView v, int32_t mole
 
 // remove_one_system! (ewald.jl:794-810, :404-413): sums[:,1] -= sums[:,ij+1]; the LAST molecule takes index `molecule`
 // (its structure factor column and the molecule id of its atoms); the atom slots of the removed molecule become free
-__global__ __launch_bounds__(MC_THREADS) void k_mc_remove(McView v, int32_t molecule, int32_t last)
+__global__ __launch_bounds__(MC_THREADS) void k_mc_remove(McView v, int32_t molecule, int32_t last, McCellOps ops)
 {
     const int tid = threadIdx.x;
     const int2 gone = v.mol[molecule], moved = v.mol[last];
@@ -385,7 +459,15 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_remove(McView v, int32_t mole
         v.atoms[moved.x + tid - 64] = A;
     }
     __syncthreads();
+    if (v.use_cells) apply_cell_ops(v, ops, tid);
     if (tid == 0 && last != molecule) v.mol[molecule] = moved;
+}
+
+// cells[i] = atoms[map[i]] for every occupied entry (map[i] >= 0): the whole structure from the host's cell lists
+__global__ void k_mc_cells_fill(McView v, const int32_t* __restrict__ map, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && map[i] >= 0) v.cells[i] = v.atoms[map[i]];
 }
 
 int merr(int code, const char* msg)
@@ -416,6 +498,88 @@ bool upload(T** dst, const T* src, size_t n)
     return n == 0 || hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice) == hipSuccess;
 }
 
+// Host mirror of the cell lists (which atom slot sits where); the device holds the records themselves.  Every update is
+// worked out here first and shipped to the device as a handful of "copy atom record `src` to cell entry `dst`" operations
+// inside the update kernel's arguments, so the bookkeeping costs no extra launch, no upload and no device-side search.
+struct CellMirror {
+    bool on = false;
+    int nb[3] = {1, 1, 1};
+    int cap = 0;
+    double invmat[9];
+    ceg_consumers::CellBins bins{};
+    std::vector<std::vector<int32_t>> members;          // [ncells] atom slots
+    std::vector<int32_t> cell_of, idx_of;               // per atom slot; cell_of < 0: not in any cell
+    std::vector<std::pair<int32_t, int32_t>> touched;   // (cell, entry) whose content changed
+    std::vector<int32_t> touched_cells;
+    int max_fill = 0;
+
+    int ncells() const { return nb[0] * nb[1] * nb[2]; }
+    int bin_of(const double* p) const { return ceg_consumers::cell_of_position(bins, invmat, p); }
+    void begin() { touched.clear(); touched_cells.clear(); }
+    void touch(int32_t c, int32_t i)
+    {
+        for (const auto& t : touched)
+            if (t.first == c && t.second == i) return;
+        touched.emplace_back(c, i);
+    }
+    void touch_cell(int32_t c)
+    {
+        if (std::find(touched_cells.begin(), touched_cells.end(), c) == touched_cells.end()) touched_cells.push_back(c);
+    }
+    void ensure_slot(int64_t slot)
+    {
+        if ((int64_t)cell_of.size() <= slot) { cell_of.resize((size_t)slot + 1, -1); idx_of.resize((size_t)slot + 1, -1); }
+    }
+    void take_out(int32_t slot)
+    {
+        const int32_t c = cell_of[slot], i = idx_of[slot];
+        if (c < 0) return;
+        std::vector<int32_t>& mem = members[c];
+        const int32_t moved = mem.back();
+        mem[i] = moved;
+        idx_of[moved] = i;
+        mem.pop_back();
+        cell_of[slot] = -1; idx_of[slot] = -1;
+        touch(c, i);
+        touch_cell(c);
+    }
+    void put_in(int32_t slot, int32_t c)
+    {
+        ensure_slot(slot);
+        std::vector<int32_t>& mem = members[c];
+        mem.push_back(slot);
+        cell_of[slot] = c; idx_of[slot] = (int32_t)mem.size() - 1;
+        max_fill = std::max(max_fill, (int)mem.size());
+        touch(c, idx_of[slot]);
+        touch_cell(c);
+    }
+    void refresh(int32_t slot)
+    {
+        if (cell_of[slot] >= 0) touch(cell_of[slot], idx_of[slot]);
+    }
+    // false: an entry beyond the capacity is in use (or too many operations): the caller rebuilds the device arrays
+    bool finish(McCellOps& ops) const
+    {
+        ops.nops = 0; ops.ncnt = 0;
+        if (max_fill > cap) return false;
+        for (const auto& t : touched) {
+            const std::vector<int32_t>& mem = members[t.first];
+            if (t.second >= (int32_t)mem.size()) continue;           // the entry fell off the end of its list
+            if (ops.nops == MC_MAX_CELL_OPS) return false;
+            ops.dst[ops.nops] = t.first * cap + t.second;
+            ops.src[ops.nops] = mem[t.second];
+            ++ops.nops;
+        }
+        for (int32_t c : touched_cells) {
+            if (ops.ncnt == MC_MAX_CELL_OPS) return false;
+            ops.cell[ops.ncnt] = c;
+            ops.count[ops.ncnt] = (int32_t)members[c].size();
+            ++ops.ncnt;
+        }
+        return true;
+    }
+};
+
 }  // namespace
 
 struct ceg_mc {
@@ -435,12 +599,19 @@ struct ceg_mc {
     int64_t atoms_cap = 0, mol_cap = 0;
     std::vector<int2> h_mol;                     // host copy of (start, count) per molecule
     std::vector<std::vector<int32_t>> free_runs; // free_runs[m]: starts of free runs of m atom slots
+    CellMirror cm;                               // neighbour cells of the guest atoms (when the MC cell is large enough to gain)
+    double4* d_cells = nullptr;
+    int32_t* d_cell_count = nullptr;
     int stride = 0;
     // pinned, device-mapped staging for small batches; device scratch for large ones
     double *h_in = nullptr, *h_out = nullptr, *dm_in = nullptr, *dm_out = nullptr;
     double *d_in = nullptr, *d_out = nullptr;
     size_t d_in_cap = 0, d_out_cap = 0;
 };
+
+namespace {
+int rebuild_cells(ceg_mc* h);
+}
 
 extern "C" int ceg_mc_create(ceg_mc_t** handle, int32_t device, ceg_interp_t* const* vdw_grids, ceg_interp_t* coulomb_grid,
                              const double* kind_charge, int32_t nkinds, const double mat[9], const double invmat[9], double cutoff2,
@@ -522,6 +693,18 @@ extern "C" int ceg_mc_create(ceg_mc_t** handle, int32_t device, ceg_interp_t* co
     }
     v.vdw = h->d_vdw; v.kind_charge = h->d_charge; v.rules = h->d_rules; v.rule_offset = h->d_offset;
     v.ijk = h->d_ijk; v.kf = h->d_kf; v.sf_fw = h->d_fw; v.sf_tot = h->d_tot;
+    {
+        CellMirror& cm = h->cm;
+        cm.bins = ceg_consumers::choose_cell_bins(invmat, cutoff);
+        for (int i = 0; i < 3; ++i) { cm.nb[i] = cm.bins.nb[i]; v.nb[i] = cm.bins.nb[i]; v.hfrac[i] = cm.bins.hfrac[i]; }
+        for (int a = 0; a < 9; ++a) cm.invmat[a] = invmat[a];
+        cm.on = cm.bins.on != 0;
+        v.use_cells = cm.on ? 1 : 0;
+        if (cm.on) {
+            cm.members.assign((size_t)cm.ncells(), {});
+            if (int rc = rebuild_cells(h)) { ceg_mc_destroy(h); return rc; }
+        }
+    }
     *handle = h;
     return CEG_OK;
 }
@@ -533,7 +716,7 @@ extern "C" int ceg_mc_destroy(ceg_mc_t* h)
     if (guard.ok) {
         if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
         for (void* p : {(void*)h->d_vdw, (void*)h->d_charge, (void*)h->d_rules, (void*)h->d_offset, (void*)h->d_ijk, (void*)h->d_kf,
-                        (void*)h->d_fw, (void*)h->d_tot, (void*)h->d_mol, (void*)h->d_atoms, (void*)h->d_molidx, (void*)h->d_in, (void*)h->d_out})
+                        (void*)h->d_fw, (void*)h->d_tot, (void*)h->d_mol, (void*)h->d_atoms, (void*)h->d_molidx, (void*)h->d_in, (void*)h->d_out, (void*)h->d_cells, (void*)h->d_cell_count})
             if (p) (void)hipFree(p);
         if (h->h_in) (void)hipHostFree(h->h_in);
         if (h->h_out) (void)hipHostFree(h->h_out);
@@ -580,6 +763,43 @@ int ensure_capacity(ceg_mc* h, int64_t natoms, int64_t nmol)
     }
     h->v.atoms = h->d_atoms; h->v.mol = h->d_molidx; h->v.sf_mol = h->d_mol;
     return CEG_OK;
+}
+
+// the device cell arrays from the host lists (first fill, or after a cell outgrew the capacity); atoms[] must be current in
+// stream order.  The stream is idle when this returns.
+int rebuild_cells(ceg_mc* h)
+{
+    CellMirror& cm = h->cm;
+    if (!cm.on) return CEG_OK;
+    const int ncells = cm.ncells();
+    int cap = std::max(cm.cap, 8);
+    while (cap < cm.max_fill + cm.max_fill / 2 + 2) cap *= 2;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return merr(CEG_ERR_HIP, "stream synchronisation failed");
+    if (cap != cm.cap || !h->d_cells) {
+        if (h->d_cells) (void)hipFree(h->d_cells);
+        h->d_cells = nullptr;
+        if (hipMalloc((void**)&h->d_cells, sizeof(double4) * (size_t)ncells * cap) != hipSuccess) return merr(CEG_ERR_HIP, "could not allocate the neighbour cells");
+        cm.cap = cap;
+    }
+    if (!h->d_cell_count && hipMalloc((void**)&h->d_cell_count, sizeof(int32_t) * (size_t)ncells) != hipSuccess)
+        return merr(CEG_ERR_HIP, "could not allocate the neighbour cells");
+    std::vector<int32_t> map((size_t)ncells * cap, -1), count((size_t)ncells);
+    for (int c = 0; c < ncells; ++c) {
+        count[c] = (int32_t)cm.members[c].size();
+        std::copy(cm.members[c].begin(), cm.members[c].end(), map.begin() + (size_t)c * cap);
+    }
+    int32_t* d_map = nullptr;
+    if (hipMalloc((void**)&d_map, sizeof(int32_t) * map.size()) != hipSuccess) return merr(CEG_ERR_HIP, "hipMalloc failed");
+    bool ok = hipMemcpy(d_map, map.data(), sizeof(int32_t) * map.size(), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(h->d_cell_count, count.data(), sizeof(int32_t) * count.size(), hipMemcpyHostToDevice) == hipSuccess;
+    h->v.cells = h->d_cells; h->v.cell_count = h->d_cell_count; h->v.cell_cap = cm.cap;
+    if (ok) {
+        const int64_t n = (int64_t)map.size();
+        hipLaunchKernelGGL(k_mc_cells_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->v, d_map, n);
+        ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess;
+    }
+    (void)hipFree(d_map);
+    return ok ? CEG_OK : merr(CEG_ERR_HIP, "could not fill the neighbour cells");
 }
 
 size_t tables_bytes(const ceg_mc* h, int m) { return sizeof(double2) * (size_t)m * (size_t)h->stride; }
@@ -686,6 +906,16 @@ extern "C" int ceg_mc_set_guests(ceg_mc_t* h, const double* positions, const int
     h->free_runs.assign(MC_MAX_ATOMS + 1, {});
     McView& v = h->v;
     v.natoms = (int32_t)natoms; v.nmol = nmol;
+    if (h->cm.on) {
+        CellMirror& cm = h->cm;
+        cm.members.assign((size_t)cm.ncells(), {});
+        cm.cell_of.assign((size_t)natoms, -1);
+        cm.idx_of.assign((size_t)natoms, -1);
+        cm.max_fill = 0;
+        cm.begin();
+        for (int64_t l = 0; l < natoms; ++l) cm.put_in((int32_t)l, cm.bin_of(positions + 3 * l));
+        if (int rc = rebuild_cells(h)) return rc;
+    }
     if (v.nk > 0) {
         if (nmol > 0)
             hipLaunchKernelGGL(k_mc_sf_molecules, dim3((unsigned)nmol), dim3(MC_THREADS), tables_bytes(h, max_m), h->stream, v, h->stride);
@@ -720,8 +950,23 @@ extern "C" int ceg_mc_accept(ceg_mc_t* h, int32_t molecule, const double* positi
     for (int t = 0; t < 3 * m; ++t) np.xyz[t] = positions[t];
     Guard guard(h->device);
     if (!guard.ok) return merr(CEG_ERR_HIP, "hipSetDevice failed");
-    hipLaunchKernelGGL(k_mc_accept, dim3(1), dim3(MC_THREADS), tables_bytes(h, m), h->stream, h->v, molecule, np, h->stride);
+    McCellOps ops{};
+    bool rebuild = false;
+    if (h->cm.on) {
+        CellMirror& cm = h->cm;
+        const int first = h->h_mol[molecule].x;
+        cm.begin();
+        for (int a = 0; a < m; ++a) {
+            const int c = cm.bin_of(positions + 3 * a);
+            if (c == cm.cell_of[first + a]) { cm.refresh(first + a); continue; }     // same cell: new coordinates in place
+            cm.take_out(first + a);
+            cm.put_in(first + a, c);
+        }
+        rebuild = !cm.finish(ops);
+    }
+    hipLaunchKernelGGL(k_mc_accept, dim3(1), dim3(MC_THREADS), tables_bytes(h, m), h->stream, h->v, molecule, np, ops, h->stride);
     if (hipGetLastError() != hipSuccess) return merr(CEG_ERR_HIP, "accept kernel launch failed");
+    if (rebuild) return rebuild_cells(h);
     return CEG_OK;                      // asynchronous: the next call on this handle is ordered behind it
 }
 
@@ -749,9 +994,18 @@ extern "C" int ceg_mc_insert(ceg_mc_t* h, const int32_t* kinds, int32_t m, const
     for (int t = 0; t < 3 * m; ++t) np.xyz[t] = positions[t];
     h->v.nmol += 1;
     h->h_mol.push_back(make_int2(first, m));
-    hipLaunchKernelGGL(k_mc_insert, dim3(1), dim3(MC_THREADS), tables_bytes(h, m), h->stream, h->v, molecule, first, nm, np, h->stride);
+    McCellOps ops{};
+    bool rebuild = false;
+    if (h->cm.on) {
+        CellMirror& cm = h->cm;
+        cm.begin();
+        for (int a = 0; a < m; ++a) cm.put_in(first + a, cm.bin_of(positions + 3 * a));
+        rebuild = !cm.finish(ops);
+    }
+    hipLaunchKernelGGL(k_mc_insert, dim3(1), dim3(MC_THREADS), tables_bytes(h, m), h->stream, h->v, molecule, first, nm, np, ops, h->stride);
     if (hipGetLastError() != hipSuccess) return merr(CEG_ERR_HIP, "insert kernel launch failed");
     if (molecule_out) *molecule_out = molecule;
+    if (rebuild) return rebuild_cells(h);
     return CEG_OK;
 }
 
@@ -762,8 +1016,19 @@ extern "C" int ceg_mc_remove(ceg_mc_t* h, int32_t molecule, int32_t* moved_out)
     Guard guard(h->device);
     if (!guard.ok) return merr(CEG_ERR_HIP, "hipSetDevice failed");
     const int32_t last = h->v.nmol - 1;
-    hipLaunchKernelGGL(k_mc_remove, dim3(1), dim3(MC_THREADS), 0, h->stream, h->v, molecule, last);
+    McCellOps ops{};
+    bool rebuild = false;
+    if (h->cm.on) {
+        CellMirror& cm = h->cm;
+        cm.begin();
+        for (int a = 0; a < h->h_mol[molecule].y; ++a) cm.take_out(h->h_mol[molecule].x + a);
+        if (last != molecule)                                  // the records of the renumbered molecule carry its new index
+            for (int a = 0; a < h->h_mol[last].y; ++a) cm.refresh(h->h_mol[last].x + a);
+        rebuild = !cm.finish(ops);
+    }
+    hipLaunchKernelGGL(k_mc_remove, dim3(1), dim3(MC_THREADS), 0, h->stream, h->v, molecule, last, ops);
     if (hipGetLastError() != hipSuccess) return merr(CEG_ERR_HIP, "remove kernel launch failed");
+    if (rebuild) { if (int rc = rebuild_cells(h)) return rc; }
     if (h->free_runs.empty()) h->free_runs.assign(MC_MAX_ATOMS + 1, {});
     h->free_runs[h->h_mol[molecule].y].push_back(h->h_mol[molecule].x);
     if (last != molecule) h->h_mol[molecule] = h->h_mol[last];
@@ -771,6 +1036,15 @@ extern "C" int ceg_mc_remove(ceg_mc_t* h, int32_t molecule, int32_t* moved_out)
     h->v.nmol = last;
     if (moved_out) *moved_out = last;     // like remove_one_system! (ewald.jl:404-413): the molecule that was `last` is now `molecule`
     return CEG_OK;
+}
+
+extern "C" int ceg_mc_neighbour_cells(ceg_mc_t* h, int32_t nb[3], int32_t* capacity)
+{
+    if (!h) return merr(CEG_ERR_INVALID, "bad argument");
+    for (int i = 0; i < 3; ++i)
+        if (nb) nb[i] = h->cm.on ? h->cm.nb[i] : 0;
+    if (capacity) *capacity = h->cm.on ? h->cm.cap : 0;
+    return h->cm.on ? 1 : 0;
 }
 
 extern "C" int ceg_mc_get_state(ceg_mc_t* h, double* positions, double* sf_total_re, double* sf_total_im)

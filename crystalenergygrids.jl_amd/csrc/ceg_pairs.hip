@@ -4,7 +4,9 @@
 // src/interactions.jl:367-406 / :589-595.
 //
 // One wave64 per placement: lanes stride over the guest atoms of the system (coalesced 32-B reads),
-// each lane loops over the <= 16 atoms of the molecule, wave reduction at the end.  The pair table
+// each lane loops over the <= 16 atoms of the molecule, wave reduction at the end.  In MC cells much larger than
+// the cutoff sphere the atoms are kept sorted by neighbour cell (ceg_consumers.h; the reference's CellListMap
+// branch, energy.jl:399-404) and the lanes stride over the cell rows the molecule can reach instead.  The pair table
 // is small (kinds^2 rule runs) and read through the scalar/L1 path.  FP64 throughout, libm-grade
 // exp/erfc (ocml): this is a consumer kernel of a few thousand atoms, not the grid build.
 #include <hip/hip_runtime.h>
@@ -34,12 +36,15 @@ struct PairsGeom {
     double cutoff2, coulombic;
     int32_t nkinds, m, exclude;
     int32_t kinds[PAIRS_MAX_ATOMS];
+    int32_t nb[3];                       // neighbour cells (CELLS): bins per fractional axis, z fastest in cell_start
+    double hfrac[3];
 };
 
-template <bool FAST, bool TABLE_IN_LDS>
+template <bool FAST, bool TABLE_IN_LDS, bool CELLS>
 __global__ __launch_bounds__(64 * PAIRS_WAVES) void k_pairs(PairsGeom g, const DevRule* __restrict__ g_rules,
                                                              const int32_t* __restrict__ g_offset, int32_t nrules,
                                                              const double4* __restrict__ atoms,      // x, y, z, (kind | molecule) bits
+                                                             const int32_t* __restrict__ cell_start, // CELLS: atoms sorted by cell, [ncells + 1]
                                                              int64_t natoms, const double* __restrict__ trial, int64_t n,
                                                              double* __restrict__ out)
 {
@@ -94,10 +99,7 @@ __global__ __launch_bounds__(64 * PAIRS_WAVES) void k_pairs(PairsGeom g, const D
         __builtin_amdgcn_wave_barrier();
         qn = 0;
     };
-    for (int64_t l0 = 0; l0 < natoms; l0 += 64) {
-        const int64_t l = l0 + lane;
-        const bool have = l < natoms;
-        const double4 A = atoms[have ? l : 0];
+    auto process = [&](const double4 A, const bool have) __attribute__((always_inline)) {
         const long long bits = __double_as_longlong(A.w);
         const int kind1 = (int)(bits & 0xffffffffll), mol = (int)(bits >> 32);
         const bool live = have && mol != g.exclude;
@@ -130,6 +132,61 @@ __global__ __launch_bounds__(64 * PAIRS_WAVES) void k_pairs(PairsGeom g, const D
             }
             qn += cnt;
         }
+    };
+    if (!CELLS) {
+        for (int64_t l0 = 0; l0 < natoms; l0 += 64) {
+            const int64_t l = l0 + lane;
+            const bool have = l < natoms;
+            process(atoms[have ? l : 0], have);
+        }
+    } else {
+        // The atoms are sorted by cell with z fastest: the cells (c0, c1, z-range) the molecule can reach are one or (across the
+        // periodic boundary) two contiguous runs of the atom array per (c0, c1).  Lane r takes run r, a wave scan turns the run
+        // lengths into offsets, then the lanes stride over the concatenation of the runs.
+        __shared__ int32_t s_run[PAIRS_WAVES][64], s_off[PAIRS_WAVES][65];
+        int32_t* run = s_run[wave];
+        int32_t* off = s_off[wave];
+        int first = 0, nbin = 1;
+        if (lane < 3) ceg_consumers::cell_range(I, t3, g.m, lane, g.nb[lane], g.hfrac[lane], first, nbin);
+        const int b0 = __shfl(first, 0), b1 = __shfl(first, 1), b2 = __shfl(first, 2);
+        const int n0 = __shfl(nbin, 0), n1 = __shfl(nbin, 1), n2 = __shfl(nbin, 2);
+        const int wrapped = b2 + n2 > g.nb[2] ? 1 : 0;                 // the z range crosses the boundary: two runs per row
+        const int nruns = n0 * n1 * (1 + wrapped);
+        for (int rbase = 0; rbase < nruns; rbase += 64) {
+            const int r = rbase + lane;
+            int start = 0, len = 0;
+            if (r < nruns) {
+                const int row = wrapped ? (r >> 1) : r, part = wrapped ? (r & 1) : 0;
+                int c0 = b0 + row / n1, c1 = b1 + row % n1;
+                if (c0 >= g.nb[0]) c0 -= g.nb[0];
+                if (c1 >= g.nb[1]) c1 -= g.nb[1];
+                const int rowbase = (c0 * g.nb[1] + c1) * g.nb[2];
+                const int zlo = part ? 0 : b2, zhi = part ? b2 + n2 - g.nb[2] : (wrapped ? g.nb[2] : b2 + n2);   // [zlo, zhi)
+                start = cell_start[rowbase + zlo];
+                len = cell_start[rowbase + zhi] - start;
+            }
+            int incl = len;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_up(incl, o);
+                if (lane >= o) incl += up;
+            }
+            const int total = __shfl(incl, 63);
+            __builtin_amdgcn_wave_barrier();
+            run[lane] = start;
+            off[lane] = incl - len;
+            __builtin_amdgcn_wave_barrier();
+            for (int l0 = 0; l0 < total; l0 += 64) {
+                const int l = l0 + lane;
+                const bool have = l < total;
+                int j = 0;                                             // last run whose first entry is <= l
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1)
+                    if (off[j + step] <= l) j += step;
+                process(atoms[have ? run[j] + (l - off[j]) : 0], have);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
     }
     flush();
 #pragma unroll
@@ -156,6 +213,8 @@ struct ceg_pairs {
     int32_t* d_offset = nullptr;
     double4* d_atoms = nullptr;
     int64_t natoms = 0, cap = 0;
+    ceg_consumers::CellBins bins{};     // neighbour cells: the atoms are uploaded sorted by cell when bins.on
+    int32_t* d_cell_start = nullptr;
 };
 
 extern "C" int ceg_pairs_create(ceg_pairs_t** handle, int32_t device, const double mat[9], const double invmat[9], double cutoff2,
@@ -191,6 +250,7 @@ extern "C" int ceg_pairs_create(ceg_pairs_t** handle, int32_t device, const doub
     h->device = device;
     for (int a = 0; a < 9; ++a) { h->mat[a] = mat[a]; h->invmat[a] = invmat[a]; }
     h->cutoff2 = cutoff2; h->coulombic = coulombic; h->nkinds = nkinds; h->fast = fast; h->nrules = nr;
+    h->bins = ceg_consumers::choose_cell_bins(invmat, cutoff);
     bool ok = hipMalloc((void**)&h->d_rules, dr.size() * sizeof(DevRule)) == hipSuccess &&
               hipMalloc((void**)&h->d_offset, (size_t)(nt + 1) * sizeof(int32_t)) == hipSuccess;
     ok = ok && hipMemcpy(h->d_rules, dr.data(), dr.size() * sizeof(DevRule), hipMemcpyHostToDevice) == hipSuccess &&
@@ -213,6 +273,7 @@ extern "C" int ceg_pairs_destroy(ceg_pairs_t* h)
         (void)hipFree(h->d_rules);
         (void)hipFree(h->d_offset);
         (void)hipFree(h->d_atoms);
+        (void)hipFree(h->d_cell_start);
     }
     if (prev >= 0) (void)hipSetDevice(prev);
     delete h;
@@ -232,6 +293,21 @@ extern "C" int ceg_pairs_set_atoms(ceg_pairs_t* h, const double* positions, cons
         memcpy(&w, &bits, sizeof(w));
         host[l] = make_double4(positions[3 * l], positions[3 * l + 1], positions[3 * l + 2], w);
     }
+    std::vector<int32_t> cell_start;
+    if (h->bins.on) {                    // counting sort by cell (z fastest): the kernel walks contiguous runs of cells
+        const int ncells = h->bins.nb[0] * h->bins.nb[1] * h->bins.nb[2];
+        cell_start.assign((size_t)ncells + 1, 0);
+        std::vector<int32_t> cell((size_t)(natoms > 0 ? natoms : 1));
+        for (int64_t l = 0; l < natoms; ++l) {
+            cell[l] = ceg_consumers::cell_of_position(h->bins, h->invmat, positions + 3 * l);
+            ++cell_start[(size_t)cell[l] + 1];
+        }
+        for (int c = 0; c < ncells; ++c) cell_start[(size_t)c + 1] += cell_start[c];
+        std::vector<int32_t> next(cell_start.begin(), cell_start.end() - 1);
+        std::vector<double4> sorted(host.size());
+        for (int64_t l = 0; l < natoms; ++l) sorted[(size_t)next[cell[l]]++] = host[l];
+        host.swap(sorted);
+    }
     int prev = -1;
     (void)hipGetDevice(&prev);
     if (hipSetDevice(h->device) != hipSuccess) return perr(CEG_ERR_HIP, "hipSetDevice failed");
@@ -244,6 +320,10 @@ extern "C" int ceg_pairs_set_atoms(ceg_pairs_t* h, const double* positions, cons
         if (!ok) h->cap = 0;
     }
     if (ok && natoms > 0) ok = hipMemcpy(h->d_atoms, host.data(), (size_t)natoms * sizeof(double4), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && h->bins.on) {
+        if (!h->d_cell_start) ok = hipMalloc((void**)&h->d_cell_start, cell_start.size() * sizeof(int32_t)) == hipSuccess;
+        ok = ok && hipMemcpy(h->d_cell_start, cell_start.data(), cell_start.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
+    }
     if (prev >= 0) (void)hipSetDevice(prev);
     if (!ok) return perr(CEG_ERR_HIP, "could not upload the guest atoms");
     h->natoms = natoms;
@@ -263,6 +343,8 @@ extern "C" int ceg_pairs_energy_device(ceg_pairs_t* h, const double* d_trial, co
         if (trial_kinds[a] < 0 || trial_kinds[a] >= h->nkinds) return perr(CEG_ERR_INVALID, "trial atom kind outside the pair table");
         g.kinds[a] = trial_kinds[a];
     }
+    for (int i = 0; i < 3; ++i) { g.nb[i] = h->bins.nb[i]; g.hfrac[i] = h->bins.hfrac[i]; }
+    const bool cells = h->bins.on && h->d_cell_start && h->natoms > 0;
     const int64_t nblocks = (n + PAIRS_WAVES - 1) / PAIRS_WAVES;
     if (nblocks > 0x7fffffffLL) return perr(CEG_ERR_INVALID, "too many placements");
     int prev = -1;
@@ -273,16 +355,30 @@ extern "C" int ceg_pairs_energy_device(ceg_pairs_t* h, const double* d_trial, co
     const size_t lds = in_lds ? table_bytes : 0;
     const dim3 grid((unsigned)nblocks), block(64 * PAIRS_WAVES);
     hipStream_t st = (hipStream_t)stream;
-#define CEG_PAIRS_LAUNCH(F, L) hipLaunchKernelGGL((k_pairs<F, L>), grid, block, lds, st, g, h->d_rules, h->d_offset, h->nrules, h->d_atoms, h->natoms, d_trial, n, d_out)
-    if (h->fast && in_lds) CEG_PAIRS_LAUNCH(true, true);
-    else if (h->fast) CEG_PAIRS_LAUNCH(true, false);
-    else if (in_lds) CEG_PAIRS_LAUNCH(false, true);
-    else CEG_PAIRS_LAUNCH(false, false);
+#define CEG_PAIRS_LAUNCH(F, L, CL) hipLaunchKernelGGL((k_pairs<F, L, CL>), grid, block, lds, st, g, h->d_rules, h->d_offset, h->nrules, h->d_atoms, h->d_cell_start, h->natoms, d_trial, n, d_out)
+#define CEG_PAIRS_PICK(CL)                                    \
+    do {                                                      \
+        if (h->fast && in_lds) CEG_PAIRS_LAUNCH(true, true, CL);   \
+        else if (h->fast) CEG_PAIRS_LAUNCH(true, false, CL);       \
+        else if (in_lds) CEG_PAIRS_LAUNCH(false, true, CL);        \
+        else CEG_PAIRS_LAUNCH(false, false, CL);                   \
+    } while (0)
+    if (cells) CEG_PAIRS_PICK(true);
+    else CEG_PAIRS_PICK(false);
+#undef CEG_PAIRS_PICK
 #undef CEG_PAIRS_LAUNCH
     const hipError_t e = hipGetLastError();
     if (prev >= 0) (void)hipSetDevice(prev);
     if (e != hipSuccess) return perr(CEG_ERR_HIP, hipGetErrorString(e));
     return CEG_OK;
+}
+
+extern "C" int ceg_pairs_neighbour_cells(ceg_pairs_t* h, int32_t nb[3])
+{
+    if (!h) return perr(CEG_ERR_INVALID, "bad argument");
+    for (int i = 0; i < 3; ++i)
+        if (nb) nb[i] = h->bins.on ? h->bins.nb[i] : 0;
+    return h->bins.on ? 1 : 0;
 }
 
 extern "C" int ceg_pairs_energy(ceg_pairs_t* h, const double* trial, const int32_t* trial_kinds, int32_t m, int64_t n,

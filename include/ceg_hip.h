@@ -330,6 +330,10 @@ CEG_API int ceg_pairs_energy(ceg_pairs_t* handle, const double* trial, const int
 /* trial / out in device memory, asynchronous on `stream` */
 CEG_API int ceg_pairs_energy_device(ceg_pairs_t* handle, const double* d_trial, const int32_t* trial_kinds,
                                     int32_t m, int64_t n, int32_t exclude_molecule, double* d_out, void* stream);
+/* 1 when the atoms are kept sorted by neighbour cell (MC cells much larger than the cutoff sphere: the reference's
+ * CellListMap branch, energy.jl:399-404; CEG_HIP_MC_CELLS=1|0 forces the choice at create time), with the bins per
+ * fractional axis; 0 for the exhaustive loop.  Same sums either way. */
+CEG_API int ceg_pairs_neighbour_cells(ceg_pairs_t* handle, int32_t nb[3]);
 
 /* ---- device-resident Monte-Carlo energy state (BASELINE config 5: f1 + f2 + f3 in one launch) ---- */
 /*
@@ -383,6 +387,11 @@ CEG_API int ceg_mc_insert(ceg_mc_t* handle, const int32_t* kinds, int32_t m, con
 CEG_API int ceg_mc_remove(ceg_mc_t* handle, int32_t molecule, int32_t* moved_out);
 /* read back (any pointer may be NULL): positions [3*natoms] in molecule order, total guest structure factor sums[:, 1] as re / im [nk] */
 CEG_API int ceg_mc_get_state(ceg_mc_t* handle, double* positions, double* sf_total_re, double* sf_total_im);
+/* The guest-guest sum runs over neighbour cells (the reference's CellListMap branch, energy.jl:341-349,399-404) when the MC
+ * cell is large enough for that to pay: fractional bins of the cell kept current on the device by accept / insert / remove.
+ * Returns 1 with the bin counts and the per-cell capacity when the cells are in use, 0 (and zeros) for the exhaustive loop;
+ * the energies are the same sums either way.  Environment: CEG_HIP_MC_CELLS=1|0 forces the choice, CEG_HIP_MC_BIN = bin width, A. */
+CEG_API int ceg_mc_neighbour_cells(ceg_mc_t* handle, int32_t nb[3], int32_t* capacity);
 
 /* ---- blocking masks on the grid lattice ----------------------------- */
 /*

@@ -306,3 +306,242 @@ def test_mc_insertions_and_removals(hip_lib, tmp_path):
         dev.close()
     finally:
         ceg.setdir_RASPA(Path(__file__).parent / "golden" / "raspa")
+
+
+# ------------------------------------------------------------------ neighbour cells of the device-resident MC state
+class _RawMc:
+    """ceg_mc_* through the C ABI on explicit tables: no framework grids, no Ewald summation -- the guest-guest term alone."""
+
+    def __init__(self, lib, mat, cutoff2, rules, offsets, nkinds, coulombic):
+        self.lib = lib
+        matT = np.ascontiguousarray(np.asarray(mat, dtype=np.float64).T.reshape(9))
+        invT = np.ascontiguousarray(np.linalg.inv(np.asarray(mat, dtype=np.float64)).T.reshape(9))
+        self.h = C.c_void_p()
+        charge = np.zeros(nkinds)
+        self._keep = (rules, np.ascontiguousarray(offsets, dtype=np.int32))
+        _abi.check(lib, lib.ceg_mc_create(C.byref(self.h), 0, None, None, _abi.dptr(charge), int(nkinds), _abi.dptr(matT), _abi.dptr(invT),
+                                          float(cutoff2), rules.ctypes.data, _abi.i32ptr(self._keep[1]), float(coulombic),
+                                          None, None, None, None, 0, None, None))
+
+    def cells(self):
+        nb = np.zeros(3, dtype=np.int32)
+        cap = C.c_int32(0)
+        rc = self.lib.ceg_mc_neighbour_cells(self.h, _abi.i32ptr(nb), C.byref(cap))
+        assert rc in (0, 1)
+        return (tuple(int(x) for x in nb), int(cap.value)) if rc else None
+
+    def set_guests(self, pos, kinds, first):
+        p = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1)
+        _abi.check(self.lib, self.lib.ceg_mc_set_guests(self.h, _abi.dptr(p), _abi.i32ptr(np.ascontiguousarray(kinds, dtype=np.int32)),
+                                                        _abi.i32ptr(np.ascontiguousarray(first, dtype=np.int32)), len(first) - 1))
+
+    def trial(self, molecule, trial):
+        t = np.ascontiguousarray(trial, dtype=np.float64)
+        out = np.empty((len(t) + 1, 4))
+        _abi.check(self.lib, self.lib.ceg_mc_trial(self.h, int(molecule), _abi.dptr(t.reshape(-1)), len(t), _abi.dptr(out.reshape(-1))))
+        return out[:, 2]
+
+    def trial_insert(self, kinds, trial):
+        t = np.ascontiguousarray(trial, dtype=np.float64)
+        k = np.ascontiguousarray(kinds, dtype=np.int32)
+        out = np.empty((len(t), 4))
+        _abi.check(self.lib, self.lib.ceg_mc_trial_insert(self.h, _abi.i32ptr(k), len(k), _abi.dptr(t.reshape(-1)), len(t), _abi.dptr(out.reshape(-1))))
+        return out[:, 2]
+
+    def accept(self, molecule, pos):
+        _abi.check(self.lib, self.lib.ceg_mc_accept(self.h, int(molecule), _abi.dptr(np.ascontiguousarray(pos, dtype=np.float64).reshape(-1))))
+
+    def insert(self, kinds, pos):
+        k = np.ascontiguousarray(kinds, dtype=np.int32)
+        out = C.c_int32(-1)
+        _abi.check(self.lib, self.lib.ceg_mc_insert(self.h, _abi.i32ptr(k), len(k), _abi.dptr(np.ascontiguousarray(pos, dtype=np.float64).reshape(-1)), C.byref(out)))
+        return int(out.value)
+
+    def remove(self, molecule):
+        moved = C.c_int32(-1)
+        _abi.check(self.lib, self.lib.ceg_mc_remove(self.h, int(molecule), C.byref(moved)))
+        return int(moved.value)
+
+    def positions(self, natoms):
+        pos = np.empty((natoms, 3))
+        _abi.check(self.lib, self.lib.ceg_mc_get_state(self.h, _abi.dptr(pos.reshape(-1)), None, None))
+        return pos
+
+    def close(self):
+        self.lib.ceg_mc_destroy(self.h)
+
+
+def test_mc_neighbour_cells(hip_lib, oracle, forcefield, monkeypatch):
+    """The guest-guest sum of the device-resident MC state over neighbour cells (the reference's CellListMap branch,
+    energy.jl:341-349,399-404) in an MC cell of 5-7 cutoffs: 4500+ guest atoms, displacements within and across the periodic
+    boundary, jumps, insertions into one spot until its cells outgrow their capacity, removals that renumber molecules --
+    every energy against the exhaustive loop of a second handle (same pair tests, another summation order: 1e-10) and
+    against oracle_single_contribution_vdw on samples (1e-9), with 4 A and 2.2 A bins."""
+    ff = forcefield
+    rng = np.random.default_rng(11)
+    co2 = ceg.load_molecule_RASPA("CO2", "TraPPE", "BoulfelfelSholl2021")
+    base = np.asarray(co2.position, dtype=np.float64).reshape(-1, 3)
+    ids = [ff.sdict[a] - 1 for a in co2.atomic_symbol]
+    na_id = [ff.sdict["Na"] - 1]
+    mat = np.array([[72.0, 0, 0], [9.0, 66.0, 0], [-7.0, 11.0, 84.0]]).T
+    inv = np.linalg.inv(mat)
+    rules, offsets = ff.pair_table()
+    table = (mat, ff.cutoff ** 2, rules, offsets, ff.nkinds, COULOMBIC_CONVERSION_FACTOR)
+    # host copy of the state: list of (kinds, positions) in device molecule order
+    mols = []
+    for c in (rng.uniform(0, 1, (1500, 3)) @ mat.T):
+        mols.append((ids, c + base @ _rotation(rng).T))
+    for c in (rng.uniform(-0.5, 1.5, (24, 3)) @ mat.T):            # some guests listed outside the unit cell
+        mols.append((na_id, c[None].copy()))
+
+    def flat():
+        pos = np.concatenate([p for _k, p in mols])
+        kinds = np.array([k for ks, _p in mols for k in ks], dtype=np.int32)
+        first = np.concatenate([[0], np.cumsum([len(ks) for ks, _p in mols])]).astype(np.int32)
+        mol = np.repeat(np.arange(len(mols)), [len(ks) for ks, _p in mols]).astype(np.int32)
+        return pos, kinds, first, mol
+
+    handles = {}
+    for name, env in (("exhaustive", {"CEG_HIP_MC_CELLS": "0"}), ("cells 4 A", {}), ("cells 2.2 A", {"CEG_HIP_MC_BIN": "2.2"})):
+        monkeypatch.delenv("CEG_HIP_MC_CELLS", raising=False)
+        monkeypatch.delenv("CEG_HIP_MC_BIN", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        handles[name] = _RawMc(hip_lib, *table)
+    monkeypatch.delenv("CEG_HIP_MC_CELLS", raising=False)
+    monkeypatch.delenv("CEG_HIP_MC_BIN", raising=False)
+    try:
+        assert handles["exhaustive"].cells() is None
+        nb4, cap0 = handles["cells 4 A"].cells()
+        assert nb4 == (17, 16, 21), nb4                               # perpendicular widths / 4 A
+        pos, kinds, first, mol = flat()
+        for h in handles.values():
+            h.set_guests(pos, kinds, first)
+        hot = mat @ np.array([0.31, 0.77, 0.52])
+        worst = worst_oracle = 0.0
+        noracle = 0
+
+        def compare(rows, what):
+            nonlocal worst
+            ref = rows["exhaustive"]
+            for name, got in rows.items():
+                assert np.array_equal(np.isfinite(got), np.isfinite(ref)), (what, name)
+                fin = np.isfinite(ref)
+                assert np.array_equal(got[~fin], ref[~fin]), (what, name)
+                err = np.abs(got[fin] - ref[fin]) / (np.abs(ref[fin]) + 1e-3)
+                worst = max(worst, float(err.max()) if fin.any() else 0.0)
+                assert (err <= 1e-10).all(), (what, name, float(err.max()))
+
+        for step in range(360):
+            op = step % 6
+            if op in (0, 1, 3, 4):                                     # displacement batch of one molecule
+                j = int(rng.integers(len(mols)))
+                ks, cur = mols[j]
+                trial = cur[None] + rng.uniform(-0.5, 0.5, (8, 1, 3))
+                trial[1] = cur + mat @ rng.uniform(-1.5, 1.5, 3)                       # a jump, possibly far outside the cell
+                trial[2] = cur - cur[len(ks) // 2] + mat @ np.array([0.9999, 0.0001, 0.5])   # next to the cell boundary
+                trial[3] = cur - cur[len(ks) // 2] + hot + rng.uniform(-1, 1, 3)       # into the crowded spot
+                if len(ks) > 1:
+                    trial[4] = trial[4][len(ks) // 2] + (trial[4] - trial[4][len(ks) // 2]) @ _rotation(rng).T
+                rows = {name: h.trial(j, trial) for name, h in handles.items()}
+                compare(rows, ("trial", step))
+                if step % 30 == 0:
+                    p, k, _f, m = flat()
+                    ref = oracle.single_contribution_vdw_raw(mat, inv, *table[1:], p, k, m, np.concatenate([cur[None], trial]), ks, j)
+                    worst_oracle = max(worst_oracle, _assert_energies(rows["cells 4 A"], ref, f"cells vs oracle, step {step}"))
+                    noracle += 1
+                pick = int(rng.integers(8))
+                if step % 4 != 1:
+                    for h in handles.values():
+                        h.accept(j, trial[pick])
+                    mols[j] = (ks, trial[pick].copy())
+            elif op == 2:                                              # insertion next to the crowded spot
+                ks = ids if step % 12 == 2 else na_id
+                shape = base @ _rotation(rng).T if ks is ids else np.zeros((1, 3))
+                trial = (hot + rng.uniform(-1.6, 1.6, (4, 3)))[:, None, :] + shape[None]
+                rows = {name: h.trial_insert(ks, trial) for name, h in handles.items()}
+                compare(rows, ("insert", step))
+                new = {h.insert(ks, trial[1]) for h in handles.values()}
+                assert new == {len(mols)}
+                mols.append((ks, trial[1].copy()))
+            else:                                                      # removal: the last molecule takes the index
+                j = int(rng.integers(len(mols)))
+                moved = {h.remove(j) for h in handles.values()}
+                assert moved == {len(mols) - 1}
+                mols[j] = mols[-1]
+                mols.pop()
+        assert noracle >= 8
+        _nb, cap1 = handles["cells 4 A"].cells()
+        assert cap1 > cap0, (cap0, cap1)                               # the crowded spot outgrew the first capacity
+        pos, kinds, first, mol = flat()
+        for name, h in handles.items():
+            assert np.array_equal(h.positions(len(pos)), pos), name
+        # a large batch through the device buffers (not the mapped ones), every 64th row against the oracle
+        j = 700
+        ks, cur = mols[j]
+        trial = (rng.uniform(0, 1, (20000, 3)) @ mat.T)[:, None, :] + (cur - cur[1])[None]
+        rows = {name: h.trial(j, trial) for name, h in handles.items()}
+        compare(rows, "batch")
+        ref = oracle.single_contribution_vdw_raw(mat, inv, *table[1:], pos, kinds, mol, trial[::64], ks, j)
+        _assert_energies(rows["cells 4 A"][1::64], ref, "cells vs oracle, batch")
+        print(f"neighbour cells: worst deviation from the exhaustive loop {worst:.1e}, from the oracle {worst_oracle:.1e}; capacity {cap0} -> {cap1}")
+    finally:
+        for h in handles.values():
+            h.close()
+
+
+def test_pairs_neighbour_cells(hip_lib, oracle, forcefield, monkeypatch):
+    """Row f3 with the atoms sorted by neighbour cell (ceg_pairs_set_atoms; the reference's CellListMap branch,
+    energy.jl:399-404) in an MC cell of 5-7 cutoffs: 6157 guest atoms incl. a dense cluster, 8192 placements (inside, across the
+    periodic boundary, far outside the cell, into the cluster), excluded molecule, 4 A and 2.2 A bins -- against the oracle
+    (1e-9) and against the exhaustive loop (same pairs, another order)."""
+    ff = forcefield
+    rng = np.random.default_rng(23)
+    _m, pos, kinds, mol, base, ids = _config5_guests(ff, rng)
+    mat = np.array([[72.0, 0, 0], [9.0, 66.0, 0], [-7.0, 11.0, 84.0]]).T
+    extra = rng.uniform(-0.3, 1.3, (1000, 3)) @ mat.T                   # 1000 more CO2 anywhere in (and around) the big cell
+    pos = np.concatenate([pos] + [c + base for c in extra])
+    kinds = np.concatenate([kinds, np.tile(ids, 1000)]).astype(np.int32)
+    mol = np.concatenate([mol, np.repeat(np.arange(2000, 3000), 3)]).astype(np.int32)
+    assert len(pos) == 6157
+    n = 8192
+    trial = (rng.uniform(0, 1, (n, 3)) @ mat.T)[:, None, :] + base[None]
+    trial[: n // 8] = (rng.uniform(0, 6.0, (n // 8, 3)) + np.array([17.0, 21.0, 9.0]))[:, None, :] + base[None]       # into the cluster
+    trial[n // 8: n // 4] += 2.0 * (mat[:, 0] - mat[:, 2])[None, None, :]                                           # far outside the cell
+    edge = rng.uniform(0, 1, (n // 8, 3))
+    edge[np.arange(n // 8), rng.integers(0, 3, n // 8)] = rng.choice([1e-7, 1 - 1e-7, 0.0, 1.0], n // 8)
+    trial[n // 4: n // 4 + n // 8] = (edge @ mat.T)[:, None, :] + base[None]                                        # on the cell faces
+    rules, offsets = ff.pair_table()
+    args = (mat, ff.cutoff ** 2, rules, offsets, ff.nkinds, COULOMBIC_CONVERSION_FACTOR, pos, kinds, mol, trial, ids, 500)
+    ref = oracle.single_contribution_vdw_raw(args[0], np.linalg.inv(mat), *args[1:])
+    monkeypatch.setenv("CEG_HIP_MC_CELLS", "0")
+    exhaustive = _pairs_gpu(hip_lib, *args)
+    _assert_energies(exhaustive, ref, "exhaustive, large cell")
+    for env in ({}, {"CEG_HIP_MC_BIN": "2.2"}):
+        monkeypatch.delenv("CEG_HIP_MC_CELLS", raising=False)
+        monkeypatch.delenv("CEG_HIP_MC_BIN", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        h = C.c_void_p()                                                 # the library picks the cells by itself here
+        matT = np.ascontiguousarray(mat.T.reshape(9)); invT = np.ascontiguousarray(np.linalg.inv(mat).T.reshape(9))
+        _abi.check(hip_lib, hip_lib.ceg_pairs_create(C.byref(h), 0, _abi.dptr(matT), _abi.dptr(invT), ff.cutoff ** 2, rules.ctypes.data,
+                                                     _abi.i32ptr(np.ascontiguousarray(offsets, dtype=np.int32)), ff.nkinds, COULOMBIC_CONVERSION_FACTOR))
+        nb = np.zeros(3, dtype=np.int32)
+        assert hip_lib.ceg_pairs_neighbour_cells(h, _abi.i32ptr(nb)) == 1 and tuple(nb) == ((17, 16, 21) if not env else (32, 29, 38))
+        hip_lib.ceg_pairs_destroy(h)
+        got = _pairs_gpu(hip_lib, *args)
+        _assert_energies(got, ref, f"cells {env}")
+        fin = np.isfinite(exhaustive)
+        assert np.array_equal(got[~fin], exhaustive[~fin])
+        assert np.all(np.abs(got[fin] - exhaustive[fin]) <= 1e-10 * (np.abs(exhaustive[fin]) + 1e-3))
+        _assert_energies(_pairs_gpu(hip_lib, *args[:-1], -1), oracle.single_contribution_vdw_raw(args[0], np.linalg.inv(mat), *args[1:-1], -1),
+                         f"cells {env}, none excluded")
+    # the fixtures' own cells keep the exhaustive loop
+    monkeypatch.delenv("CEG_HIP_MC_BIN", raising=False)
+    small = np.array([[40.0, 0, 0], [3.0, 40.0, 0], [-2.0, 4.0, 40.0]]).T
+    h = C.c_void_p()
+    _abi.check(hip_lib, hip_lib.ceg_pairs_create(C.byref(h), 0, _abi.dptr(np.ascontiguousarray(small.T.reshape(9))),
+                                                 _abi.dptr(np.ascontiguousarray(np.linalg.inv(small).T.reshape(9))), ff.cutoff ** 2, rules.ctypes.data,
+                                                 _abi.i32ptr(np.ascontiguousarray(offsets, dtype=np.int32)), ff.nkinds, COULOMBIC_CONVERSION_FACTOR))
+    assert hip_lib.ceg_pairs_neighbour_cells(h, None) == 0
+    hip_lib.ceg_pairs_destroy(h)

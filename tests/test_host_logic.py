@@ -362,6 +362,6 @@ def test_bench_cpu_baseline_leg(monkeypatch):
         cb = bench.cpu_baseline(w, mode, -1)
         assert cb["kind"] == "port" and cb["unit"] == "grid-points/s" and cb["value"] > 0
         from oracle import oracle as O
-        assert cb["cores"] == O.usable_cpus() and 0.05 < cb["parallel_efficiency"] < 1.5      # not 1 after the single-thread probe
+        assert cb["cores"] == O.usable_cpus() and 0.01 < cb["parallel_efficiency"] < 4.0      # not 1 after the single-thread probe
         assert cb["pair_checks_per_s_per_thread"] == pytest.approx(cb["pair_checks_per_s"] / cb["cores"])
         assert "preallocated" in cb["sample"]
