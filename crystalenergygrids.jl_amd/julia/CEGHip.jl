@@ -325,6 +325,15 @@ function mc_remove(h::Ptr{Cvoid}, ij::Int)
     Int(moved[]) + 1
 end
 
+"(bins per axis, capacity) of the guest neighbour cells (the CellListMap branch of src/energy.jl:399-404), or `nothing` when the MC cell is small enough for the exhaustive loop"
+function mc_neighbour_cells(h::Ptr{Cvoid})
+    nb = zeros(Int32, 3)
+    cap = Ref{Int32}(0)
+    rc = ccall((:ceg_mc_neighbour_cells, LIB[]), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ref{Int32}), h, nb, cap)
+    rc < 0 && _check(rc)
+    rc == 1 ? (Tuple(Int.(nb)), Int(cap[])) : nothing
+end
+
 
 # ------------------------------------------------------------------ blocking masks (SURVEY 8f row f4)
 _to_bitarray(mask::Vector{UInt8}, a, b, c) = BitArray(permutedims(reshape(mask, c, b, a), (3, 2, 1)) .!= 0)
