@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -41,6 +42,17 @@ PROTOTYPES = {
         C.c_int32, C.c_double, C.c_double, C.c_double,
         c_int32_p, c_double_p, c_double_p, c_double_p,
         C.c_double, C.c_double, c_float_p, C.c_int32]),
+    "ceg_grid_vdw_device": (C.c_int, [
+        c_double_p, c_int64_p, C.c_int64, c_double_p, c_double_p,
+        C.c_int32, C.c_double, C.c_double,
+        C.c_void_p, c_int32_p, C.c_int32,
+        c_int32_p, c_double_p, c_double_p, c_double_p,
+        C.c_double, C.c_double, C.c_void_p, C.c_int32, C.c_int32]),
+    "ceg_grid_coulomb_device": (C.c_int, [
+        c_double_p, c_double_p, C.c_int64, c_double_p, c_double_p,
+        C.c_int32, C.c_double, C.c_double, C.c_double,
+        c_int32_p, c_double_p, c_double_p, c_double_p,
+        C.c_double, C.c_double, C.c_void_p, C.c_int32, C.c_int32]),
     "ceg_grid_vdw_file": (C.c_int, [
         c_double_p, c_int64_p, C.c_int64, c_double_p, c_double_p,
         C.c_int32, C.c_double, C.c_double,
@@ -139,6 +151,14 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
         raise ImportError(
             f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the grid build.")
+    if "torch" not in sys.modules and not os.environ.get("CEG_HIP_NO_TORCH"):
+        # PyTorch ships its own HIP runtime; when this package hands device memory to / takes it from torch (plan builds into
+        # tensors, ceg_grid_*_device, torch.distributed ranks) that runtime must be the one the process loads first, or torch's
+        # lazy initialisation later finds no device.  A pure C-ABI user without torch is unaffected.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(str(p))
     for name, (restype, argtypes) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported

@@ -153,6 +153,48 @@ def build_coulomb_array(probe: ProbeSystem, alpha: float, cset: GridCoordinatesS
     return grid
 
 
+def build_vdw_device(probe: ProbeSystem, cset: GridCoordinatesSetup, ngpus: int = 1, device: int = 0):
+    """``ceg_grid_vdw_device``: the same build with the assembled grid left on the GPU -> ``torch.float32[8, nx, ny, nz]`` on
+    ``cuda:device`` (x-slabs built on ``ngpus`` devices of this process, gathered by peer copies)."""
+    import torch
+    lib = _abi.load_library()
+    ff = probe.forcefield
+    ff.check_vdw_grid(probe.probe, np.unique(probe.atomkinds))
+    rules, offsets = ff.rule_table(probe.probe)
+    ortho, safemin2 = probe.periodic_setup()
+    lam, thr = vdw_scaling()
+    dims, size, shift, delta = _grid_args(cset)
+    nx, ny, nz = cset.npoints
+    grid = torch.empty((8, nx, ny, nz), dtype=torch.float32, device=f"cuda:{device}")
+    pos = np.ascontiguousarray(probe.positions, dtype=np.float64)
+    kinds = np.ascontiguousarray(probe.atomkinds, dtype=np.int64)
+    mat, invmat = _matT(probe.mat), _matT(probe.invmat)
+    torch.cuda.synchronize(device)
+    _abi.check(lib, lib.ceg_grid_vdw_device(_abi.dptr(pos), _abi.i64ptr(kinds), len(kinds), _abi.dptr(mat), _abi.dptr(invmat), int(ortho), safemin2,
+                                            probe.cutoff2, rules.ctypes.data, _abi.i32ptr(offsets), ff.nkinds, _abi.i32ptr(dims), _abi.dptr(size),
+                                            _abi.dptr(shift), _abi.dptr(delta), lam, thr, grid.data_ptr(), device, ngpus))
+    return grid
+
+
+def build_coulomb_device(probe: ProbeSystem, alpha: float, cset: GridCoordinatesSetup, ngpus: int = 1, device: int = 0):
+    """``ceg_grid_coulomb_device`` -> ``torch.float32[8, nx, ny, nz]`` on ``cuda:device``."""
+    import torch
+    lib = _abi.load_library()
+    ortho, safemin2 = probe.periodic_setup()
+    lam, thr = coulomb_scaling()
+    dims, size, shift, delta = _grid_args(cset)
+    nx, ny, nz = cset.npoints
+    grid = torch.empty((8, nx, ny, nz), dtype=torch.float32, device=f"cuda:{device}")
+    pos = np.ascontiguousarray(probe.positions, dtype=np.float64)
+    q = np.ascontiguousarray(probe.charges, dtype=np.float64)
+    mat, invmat = _matT(probe.mat), _matT(probe.invmat)
+    torch.cuda.synchronize(device)
+    _abi.check(lib, lib.ceg_grid_coulomb_device(_abi.dptr(pos), _abi.dptr(q), len(q), _abi.dptr(mat), _abi.dptr(invmat), int(ortho), safemin2,
+                                                probe.cutoff2, alpha, _abi.i32ptr(dims), _abi.dptr(size), _abi.dptr(shift), _abi.dptr(delta),
+                                                lam, thr, grid.data_ptr(), device, ngpus))
+    return grid
+
+
 def write_grid_file(file, cset: GridCoordinatesSetup, num_unitcell, grid: np.ndarray,
                     ewald_precision: Optional[float] = None) -> None:
     """File body of grids.jl:151-155 / :178-183."""

@@ -1282,7 +1282,126 @@ int oneshot(int mode, const double* pos, const int64_t* atomkind, const double* 
     return CEG_OK;
 }
 
+// One slab of the device-resident one-shot build: slab 0 is built straight into the assembled grid on the target device; the other
+// slabs are built on their own devices and travel to the target chunk by chunk with hipMemcpyPeerAsync (xGMI between the GPUs of a
+// node) while the later chunks are still being computed.
+int resident_pipeline(int mode, int slab_index, int d, int target, int b, int e, int nx, int64_t plane, const double* pos,
+                      const int64_t* atomkind, const double* charge, int64_t natoms, const double* mat, const double* invmat,
+                      int32_t ortho, double safemin2, double cutoff2, const ceg_rule_t* rules, const int32_t* rule_offset,
+                      int32_t nkinds, double alpha, const int32_t* dims, const double* size, const double* shift,
+                      const double* delta, double lambda, double threshold, float* d_grid, std::string* err)
+{
+    auto bad = [&](int code, const char* what) {
+        *err = std::string(what) + " (device " + std::to_string(d) + "): " + hipGetErrorString(hipGetLastError());
+        return code;
+    };
+    const int64_t npts = plane * nx;
+    const int64_t slab_pts = (int64_t)(e - b) * plane;
+    if (slab_pts <= 0) return CEG_OK;
+    if (hipSetDevice(d) != hipSuccess) return bad(CEG_ERR_HIP, "hipSetDevice failed");
+    ceg_plan* plan = nullptr;
+    int rc = ceg_plan_create(&plan, d, pos, atomkind, charge, natoms, mat, invmat, ortho, safemin2, cutoff2, rules, rule_offset,
+                             nkinds, alpha, dims, size, shift, delta);
+    if (rc) { *err = g_err; return rc; }
+    hipStream_t s_comp = nullptr, s_copy = nullptr;
+    if (!streams_acquire(d, &s_comp, &s_copy)) { ceg_plan_destroy(plan); return bad(CEG_ERR_HIP, "stream creation failed"); }
+    const bool direct = slab_index == 0;
+    int cx = (int)std::max<int64_t>(4, ((32ll << 20) / (plane * 8 * (int64_t)sizeof(float))) / 4 * 4);
+    cx = std::min(cx, (e - b + 3) / 4 * 4);
+    const int nchunks = (e - b + cx - 1) / cx;
+    float* d_out = nullptr;
+    hipEvent_t ev = nullptr;
+    if (!direct) {
+        if (d != target) (void)hipDeviceEnablePeerAccess(target, 0);        // already enabled / not possible: the copy still works
+        (void)hipGetLastError();
+        d_out = static_cast<float*>(device_acquire(d, sizeof(float) * 8 * slab_pts));
+        if (!d_out || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) rc = bad(CEG_ERR_HIP, "allocation of the slab buffer failed");
+    }
+    for (int j = 0; j < nchunks && !rc; ++j) {
+        const int cb = b + j * cx, ce = std::min(e, cb + cx);
+        float* out = direct ? d_grid : d_out;
+        const int64_t stride = direct ? npts : slab_pts;
+        const int origin = direct ? 0 : b;
+        rc = (mode == MODE_VDW) ? ceg_plan_build_vdw(plan, lambda, threshold, cb, ce, out, stride, origin, CEG_ALGO_AUTO, s_comp)
+                                : ceg_plan_build_coulomb(plan, lambda, threshold, cb, ce, out, stride, origin, CEG_ALGO_AUTO, s_comp);
+        if (rc) { *err = g_err; break; }
+        if (direct) continue;
+        if (hipEventRecord(ev, s_comp) != hipSuccess || hipStreamWaitEvent(s_copy, ev, 0) != hipSuccess) { rc = bad(CEG_ERR_HIP, "event failed"); break; }
+        const size_t cpts = (size_t)(ce - cb) * plane;
+        for (int c = 0; c < 8 && !rc; ++c)
+            if (hipMemcpyPeerAsync(d_grid + (size_t)c * npts + (size_t)cb * plane, target, d_out + (size_t)c * slab_pts + (size_t)(cb - b) * plane, d,
+                                   sizeof(float) * cpts, s_copy) != hipSuccess)
+                rc = bad(CEG_ERR_HIP, "hipMemcpyPeerAsync failed");
+    }
+    if (hipStreamSynchronize(s_comp) != hipSuccess && !rc) rc = bad(CEG_ERR_HIP, "kernel execution failed");
+    if (hipStreamSynchronize(s_copy) != hipSuccess && !rc) rc = bad(CEG_ERR_HIP, "peer copy failed");
+    if (ev) (void)hipEventDestroy(ev);
+    if (d_out) device_release(d_out);
+    streams_release(s_comp);
+    ceg_plan_destroy(plan);
+    return rc;
+}
+
+int oneshot_resident(int mode, const double* pos, const int64_t* atomkind, const double* charge, int64_t natoms, const double* mat,
+                     const double* invmat, int32_t ortho, double safemin2, double cutoff2, const ceg_rule_t* rules,
+                     const int32_t* rule_offset, int32_t nkinds, double alpha, const int32_t* dims, const double* size,
+                     const double* shift, const double* delta, double lambda, double threshold, float* d_grid, int32_t target,
+                     int32_t ngpus)
+{
+    if (!d_grid) return fail(CEG_ERR_INVALID, "d_grid is NULL");
+    if (int rc = check_common(pos, natoms, mat, invmat, dims, size, shift, delta)) return rc;
+    const int ndev = ceg_device_count();
+    if (ndev <= 0) return fail(CEG_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (target < 0 || target >= ndev) return fail(CEG_ERR_NO_DEVICE, "target device %d not present (%d devices)", target, ndev);
+    const bool oversubscribe = std::getenv("CEG_HIP_OVERSUBSCRIBE") != nullptr;      // rehearsal on one card, as in oneshot()
+    if (ngpus < 1 || (ngpus > ndev && !oversubscribe))
+        return fail(CEG_ERR_NO_DEVICE, "ngpus = %d but %d HIP devices are present", ngpus, ndev);
+    const int nx = dims[0] + 1;
+    const int64_t plane = (int64_t)(dims[1] + 1) * (dims[2] + 1);
+    ngpus = std::min(ngpus, nx);
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    std::vector<int> rcs(ngpus, CEG_OK);
+    std::vector<std::string> errs(ngpus);
+    auto run = [&](int slab_index) {
+        int b, e;
+        slab(nx, ngpus, slab_index, &b, &e);
+        rcs[slab_index] = resident_pipeline(mode, slab_index, (target + slab_index) % ndev, target, b, e, nx, plane, pos, atomkind, charge, natoms, mat,
+                                            invmat, ortho, safemin2, cutoff2, rules, rule_offset, nkinds, alpha, dims, size, shift, delta, lambda,
+                                            threshold, d_grid, &errs[slab_index]);
+    };
+    std::vector<std::thread> workers;
+    for (int t = 1; t < ngpus; ++t) workers.emplace_back(run, t);
+    run(0);
+    for (auto& w : workers) w.join();
+    if (prev >= 0) (void)hipSetDevice(prev);
+    for (int t = 0; t < ngpus; ++t)
+        if (rcs[t]) return fail(rcs[t], "%s", errs[t].c_str());
+    return CEG_OK;
+}
+
 }  // namespace
+
+extern "C" int ceg_grid_vdw_device(const double* pos, const int64_t* atomkind, int64_t natoms, const double mat[9], const double invmat[9],
+                                   int32_t ortho, double safemin2, double cutoff2, const ceg_rule_t* rules, const int32_t* rule_offset,
+                                   int32_t nkinds, const int32_t dims[3], const double size[3], const double shift[3],
+                                   const double delta[3], double lambda, double threshold, float* d_grid, int32_t target_device,
+                                   int32_t ngpus)
+{
+    if (!rules || !rule_offset || !atomkind || nkinds <= 0) return fail(CEG_ERR_INVALID, "rule table / atomkind missing");
+    return oneshot_resident(MODE_VDW, pos, atomkind, nullptr, natoms, mat, invmat, ortho, safemin2, cutoff2, rules, rule_offset, nkinds, 0.0,
+                            dims, size, shift, delta, lambda, threshold, d_grid, target_device, ngpus);
+}
+
+extern "C" int ceg_grid_coulomb_device(const double* pos, const double* charge, int64_t natoms, const double mat[9], const double invmat[9],
+                                       int32_t ortho, double safemin2, double cutoff2, double alpha, const int32_t dims[3],
+                                       const double size[3], const double shift[3], const double delta[3], double lambda,
+                                       double threshold, float* d_grid, int32_t target_device, int32_t ngpus)
+{
+    if (!charge) return fail(CEG_ERR_INVALID, "charge is NULL");
+    return oneshot_resident(MODE_COULOMB, pos, nullptr, charge, natoms, mat, invmat, ortho, safemin2, cutoff2, nullptr, nullptr, 0, alpha, dims,
+                            size, shift, delta, lambda, threshold, d_grid, target_device, ngpus);
+}
 
 extern "C" int ceg_release_cached_buffers(void)
 {

@@ -163,6 +163,23 @@ CEG_API int ceg_grid_coulomb_file(const double* pos, const double* charge, int64
  * whatever is idle; safe to call at any time, never required. */
 CEG_API int ceg_release_cached_buffers(void);
 
+/* The same builds with the assembled grid left in DEVICE memory: d_grid [8*(dims[0]+1)*(dims[1]+1)*(dims[2]+1)] floats on
+ * `target_device`, layout as above -- for callers that feed the grid consumers (ceg_scale_grid_device + ceg_interp_create with
+ * grid_on_device = 1, then ceg_mc_create) without a trip through host memory.  The x-slabs are spread over `ngpus` devices starting
+ * at the target; the target's slab is built in place, the others travel chunk by chunk with hipMemcpyPeerAsync (xGMI inside a
+ * node) while later chunks are still being computed: the single-process counterpart of the all-gather that bench.py / the
+ * torch.distributed ranks do with RCCL.  Synchronous: d_grid is complete on return. */
+CEG_API int ceg_grid_vdw_device(const double* pos, const int64_t* atomkind, int64_t natoms,
+                                const double mat[9], const double invmat[9], int32_t ortho, double safemin2, double cutoff2,
+                                const ceg_rule_t* rules, const int32_t* rule_offset, int32_t nkinds,
+                                const int32_t dims[3], const double size[3], const double shift[3], const double delta[3],
+                                double lambda, double threshold, float* d_grid, int32_t target_device, int32_t ngpus);
+CEG_API int ceg_grid_coulomb_device(const double* pos, const double* charge, int64_t natoms,
+                                    const double mat[9], const double invmat[9], int32_t ortho, double safemin2, double cutoff2,
+                                    double alpha,
+                                    const int32_t dims[3], const double size[3], const double shift[3], const double delta[3],
+                                    double lambda, double threshold, float* d_grid, int32_t target_device, int32_t ngpus);
+
 /* ---- resident-plan API (device buffers, caller-owned stream) ---------------- */
 /*
  * A plan is one ProbeSystem + one GridCoordinatesSetup made resident on one

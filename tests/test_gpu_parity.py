@@ -621,6 +621,42 @@ def test_multi_device_oneshot(hip_lib, oracle, monkeypatch):
         assert ei.value.code == -2
 
 
+def test_device_resident_oneshot(hip_lib, monkeypatch):
+    """ceg_grid_vdw_device / ceg_grid_coulomb_device: the one-shot build with the assembled grid left in device memory (slab 0
+    built in place, the other slabs gathered by hipMemcpyPeerAsync) is bit-identical to the host one-shot array, for 1 and
+    (oversubscribed onto one card where there is only one) 2-4 slabs incl. uneven splits; and the grid goes on to the
+    interpolation consumer without leaving the GPU (ceg_scale_grid_device + ceg_interp_create on the device pointer)."""
+    import torch
+    from ceg_hip.constants import GRID_TO_KELVIN
+    from ceg_hip.interp import GridInterpolator
+    n = hip_lib.ceg_device_count()
+    w = W.fixture_workload("CIT-7", "Ar", 0.6)
+    host_v = G.build_vdw_array(w.probe_vdw, w.cset)
+    host_c = G.build_coulomb_array(w.probe_coulomb, w.alpha, w.cset)
+    dev_v = G.build_vdw_device(w.probe_vdw, w.cset)
+    assert dev_v.is_cuda and np.array_equal(dev_v.cpu().numpy(), host_v, equal_nan=True)
+    if n < 2:
+        monkeypatch.setenv("CEG_HIP_OVERSUBSCRIBE", "1")
+    for ng in (2, 3, 4) if n < 2 else (min(n, 4),):
+        assert np.array_equal(G.build_vdw_device(w.probe_vdw, w.cset, ngpus=ng).cpu().numpy(), host_v, equal_nan=True), ng
+        assert np.array_equal(G.build_coulomb_device(w.probe_coulomb, w.alpha, w.cset, ngpus=ng).cpu().numpy(), host_c, equal_nan=True), ng
+    if n < 2:
+        monkeypatch.delenv("CEG_HIP_OVERSUBSCRIBE")
+        with pytest.raises(_abi.CegError):
+            G.build_vdw_device(w.probe_vdw, w.cset, ngpus=2)
+    # build -> parse_grid's scaling -> interpolation handle, all on the device, against the host route
+    _abi.check(hip_lib, hip_lib.ceg_scale_grid_device(dev_v.data_ptr(), dev_v.numel(), GRID_TO_KELVIN, 0, None))
+    torch.cuda.synchronize()
+    scaled = host_v.copy()
+    np.multiply(scaled, GRID_TO_KELVIN, out=scaled, dtype=np.float64, casting="same_kind")       # as parse_grid does (grids.jl:78)
+    g = G.EnergyGrid(w.cset, (1, 1, 1), float("inf"), True, scaled)
+    pts = np.random.default_rng(3).uniform(-5, 40, (4096, 3))
+    on_dev, on_host = GridInterpolator(g, 0, device_ptr=dev_v.data_ptr()), GridInterpolator(g, 0)
+    a, b = on_dev(pts), on_host(pts)
+    assert np.array_equal(a, b)
+    on_dev.close(); on_host.close()
+
+
 # ------------------------------------------------------------------ row f2: batched reciprocal Ewald + energy_grid
 def test_reciprocal_batch_vs_oracle(hip_lib, oracle):
     """ceg_recip_* (sincospi tables in LDS, one wave per placement) against the literal oracle."""
