@@ -201,7 +201,7 @@ int convert_rules(ceg_plan* p, const ceg_rule_t* rules, const int32_t* rule_offs
         int nlj = 0, nbuck = 0, nhs = 0, nother = 0;
         for (int32_t t = b; t < e; ++t) {
             const DevRule& r = p->h_rules[t];
-            if (r.kind == CEG_LENNARDJONES) { ++nlj; f.p0 = 4.0 * r.p0; f.p1 = r.p1; f.shift += r.shift; }
+            if (r.kind == CEG_LENNARDJONES) { ++nlj; f.p0 = 4.0 * r.p0; f.p1 = r.p1; f.p2 = r.p1 * r.p1 * r.p1; f.shift += r.shift; }
             else if (r.kind == CEG_BUCKINGHAM) { ++nbuck; f.p0 = r.p0; f.p1 = r.p1; f.p2 = r.p2; f.shift += r.shift; }
             else if (r.kind == CEG_HARDSPHERE) { ++nhs; f.shift += r.shift; if (present[k]) hs_max2 = std::max(hs_max2, r.p0); }
             else ++nother;

@@ -93,7 +93,7 @@ struct ImageBins {
 // Plan constants resident in device memory (uploaded once per plan): the culled kernel reads
 // them through a pointer so that only what the hot loop needs lives in scalar registers.
 // Per-kind record of the fast VdW classes of k_culled: cls 0 none, 1 Lennard-Jones
-// {4 eps, sigma^2, -, shift}, 2 Buckingham {A, B, C, shift} (hard spheres inside r_exact ignored).
+// {4 eps, sigma^2, sigma^6, shift}, 2 Buckingham {A, B, C, shift} (hard spheres inside r_exact ignored).
 struct FastVdw {
     double p0, p1, p2, shift;
     int32_t cls;

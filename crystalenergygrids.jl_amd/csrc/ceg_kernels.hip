@@ -408,8 +408,8 @@ __device__ __forceinline__ void slow_pairs(const PlanConst* __restrict__ pc, uns
             const int kd = mt & META_KINDMASK;
             double v, p1, p2, p3;
             vdw_terms<LJSLOW>(pc->rt.rules, pc->rt.offset[kd], pc->rt.offset[kd + 1], r2, v, p1, p2, p3);
-            if (LJSLOW) {        // the LJ-only hot loop accumulates p1/-12, p2/168, p3/-2688 (scaled once per tile at the end)
-                p1 *= -1.0 / 12.0; p2 *= 1.0 / 168.0; p3 *= -1.0 / 2688.0;
+            if (LJSLOW) {        // the LJ-only hot loop accumulates p1/-6, p2/48, p3/-480 (scaled once per tile at the end)
+                p1 *= -1.0 / 6.0; p2 *= 1.0 / 48.0; p3 *= -1.0 / 480.0;
             }
             accum_add(av, v, p1, p2, p3, dx, dy, dz);
         }
@@ -828,18 +828,20 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
                         p3 = __builtin_fma(mul_sc(x6, 480.0), inv2 * inv,
                                            -((Bxe * rinv3) * inv) * __builtin_fma(Br, add_sc(Br, 3.0), 3.0));
                       } else {
-                        // derivativesGrid, LJ branch (src/interactions.jl:434-441), with 1/r2 shared
-                        const Quad L = s_rec[q].lj;            // 4 eps, sigma^2, -, shift
-                        const double sx = L.y * inv;
-                        const double x6 = sx * sx * sx;
-                        const double t1 = L.x * x6;                        // 4 eps x6
-                        const double t1i = t1 * inv, t1ii = t1i * inv, inv2 = inv * inv;
-                        v = __builtin_fma(t1, x6, -t1) - L.w;              // 4 eps x6 (x6 - 1) - shift
-                        p1 = t1i * (x6 - 0.5);                                               // 24 eps x6 (1 - 2 x6)/r^2   / -12
-                        p2 = t1ii * add_sc(x6, -2.0 / 7.0);                                  // 96 eps x6 (7 x6 - 2)/r^4   / 168
-                        p3 = (t1ii * inv2) * add_sc(x6, -5.0 / 28.0);                        // 384 eps x6 (5 - 28 x6)/r^8 / -2688
+                        // derivativesGrid, LJ branch (src/interactions.jl:434-441), with 1/r2 shared.  In terms of
+                        // w = 4 eps x6 and u = 4 eps x6^2 (x6 = sigma^6/r^6, sigma^6 formed once per kind on the host):
+                        //   v = u - w - shift,  p1 = -6 (2u - w)/r^2,  p2 = 48 (3.5u - w)/r^4,  p3 = -480 (5.6u - w)/r^8
+                        const Quad L = s_rec[q].lj;            // 4 eps, sigma^2, sigma^6, shift
+                        const double inv2 = inv * inv;
+                        const double x6 = L.z * (inv2 * inv);
+                        const double w = L.x * x6;
+                        const double u = w * x6;
+                        v = (u - w) - L.w;
+                        p1 = __builtin_fma(u, 2.0, -w) * inv;                                // / -6
+                        p2 = fms_vsv(u, 3.5, w) * inv2;                                      // / 48
+                        p3 = fms_vsv(u, 5.6, w) * (inv2 * inv2);                             // / -480
                         if (VDWK != 1) {     // mixed classes share the accumulators: scale per pair.  LJ-only plans scale once per tile
-                            p1 = mul_sc(p1, -12.0); p2 = mul_sc(p2, 168.0); p3 = mul_sc(p3, -2688.0);
+                            p1 = mul_sc(p1, -6.0); p2 = mul_sc(p2, 48.0); p3 = mul_sc(p3, -480.0);
                         }
                       }
                     } else {
@@ -941,9 +943,9 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
         }
     }
     if (VDWK == 1 && MODE != MODE_COULOMB) {      // constant factors of the LJ derivative channels, deferred out of the hot loop
-        av.d1x *= -12.0; av.d1y *= -12.0; av.d1z *= -12.0;
-        av.d2xy *= 168.0; av.d2xz *= 168.0; av.d2yz *= 168.0;
-        av.d3 *= -2688.0;
+        av.d1x *= -6.0; av.d1y *= -6.0; av.d1z *= -6.0;
+        av.d2xy *= 48.0; av.d2xz *= 48.0; av.d2yz *= 48.0;
+        av.d3 *= -480.0;
     }
     if (POINTS) {
         if (valid) write_results<MODE>(g, out, true, pidx, i, j, k, av, ac, smallest_d2);

@@ -58,6 +58,14 @@ __device__ __forceinline__ double fma_vsv(double a, double b, double c)
     return r;
 }
 
+// a*b - c with b in a scalar pair (3-address, no copy)
+__device__ __forceinline__ double fms_vsv(double a, double b, double c)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, -%3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
+
 // min of two non-NaN doubles in one instruction (fmin() adds two canonicalising v_max_f64)
 __device__ __forceinline__ double min_nonan(double a, double b)
 {
