@@ -760,7 +760,8 @@ extern "C" int ceg_plan_create(ceg_plan_t** plan, int32_t device,
                 hc.erfcx_mx0_inv_h = mx0;
                 p->fast_ewald = want_ewald;
             }
-            hc.two_alpha2 = 2.0 * alpha * alpha;
+            hc.ew_k3 = 2.0 * alpha * alpha / 3.0;
+            hc.ew_k15 = 4.0 * (alpha * alpha) * (alpha * alpha) / 15.0;
             if (ok && want_ewald && !rc && !std::getenv("CEG_HIP_NO_EW2")) {
                 std::vector<double> t2;
                 int32_t base = 0, ni = 0;

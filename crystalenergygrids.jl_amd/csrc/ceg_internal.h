@@ -116,7 +116,7 @@ struct PlanConst {
     const double* ew2_tab;
     int32_t ew2_ni;            // intervals in the table (<= CEG_EW2_NI_MAX)
     int32_t ew2_base;          // key of the first interval: hi32(r_exact2) >> CEG_EW2_SHIFT
-    double two_alpha2;         // 2 alpha^2
+    double ew_k3, ew_k15;      // 2 alpha^2 / 3, 4 alpha^4 / 15: constants of the B_n recurrence in the r^2-table loop
     // single Buckingham class (VDWK = 3): G0(s) = A exp(-B sqrt(s)) on r^2 intervals of its own (CEG_BK2_LOGM), [bk2_ni][CEG_BK2_STRIDE]
     const double* bk2_tab;
     int32_t bk2_ni, bk2_base;

@@ -386,7 +386,7 @@ struct __attribute__((aligned(16))) CandRec {
 // position, invmat*d, wrap, mat*f, neighbour search (periodic_distance2_literal) -- and evaluated
 // with the literal radial formulas.  Runs after the hot loop so that its registers do not
 // overlap the hot loop's.
-template <int MODE, bool FASTEW, bool LJSLOW, typename Rec>
+template <int MODE, bool FASTEW, bool LJSLOW, bool EWSCALED, typename Rec>
 __device__ __forceinline__ void slow_pairs(const PlanConst* __restrict__ pc, unsigned long long cands, int lane,
                                            double px, double py, double pz,
                                            const Rec* s_rec,
@@ -420,6 +420,9 @@ __device__ __forceinline__ void slow_pairs(const PlanConst* __restrict__ pc, uns
                 ewald_terms_poly(g.alpha, O.w, r2, v, p1, p2, p3);
             else
                 ewald_terms(g.alpha, O.w, r2, v, p1, p2, p3);
+            if (EWSCALED) {      // the r^2-table hot loop accumulates p2/3 and p3/15 (scaled once per tile at the end)
+                p2 *= 1.0 / 3.0; p3 *= 1.0 / 15.0;
+            }
             accum_add(ac, v, p1, p2, p3, dx, dy, dz);
         }
     }
@@ -624,7 +627,7 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
     const int ew2_off = EW2 ? __builtin_amdgcn_readfirstlane(-pc->ew2_base * (CEG_EW2_STRIDE * 8)) : 0;
     int ew2_stride = CEG_EW2_STRIDE * 8;              // kept in a VGPR: v_mad_u32_u24 reads one scalar operand (ew2_off)
     asm volatile("" : "+v"(ew2_stride));
-    const double two_alpha2 = pc->two_alpha2;
+    const double ew_k3 = pc->ew_k3, ew_k15 = pc->ew_k15;       // 2 alpha^2 / 3, 4 alpha^4 / 15
     const bool all_simple = __builtin_amdgcn_readfirstlane(pc->all_simple) != 0;
     const int bk2_off = BK2 ? __builtin_amdgcn_readfirstlane(-pc->bk2_base * (CEG_BK2_STRIDE * 8)) : 0;
     int bk2_stride = CEG_BK2_STRIDE * 8;
@@ -880,12 +883,11 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
                         cc = __builtin_fma(cc, t, c12.x);
                         b0 = __builtin_fma(b0, t, a01.x);
                         cc = __builtin_fma(cc, t, a6c0.y);
+                        // accumulated as B2/3 and B3/15 (one FMA + one product per step); the factors are applied once per tile
                         const double qb0 = A.w * b0, qc = A.w * cc;
                         const double b1 = (qb0 + qc) * inv;
-                        const double c2 = mul_sc(qc, two_alpha2);
-                        const double b2 = fma_vsv(b1, 3.0, c2) * inv;
-                        const double c3 = mul_sc(c2, two_alpha2);
-                        const double b3 = fma_vsv(b2, 5.0, c3) * inv;
+                        const double b2 = fma_vsv(qc, ew_k3, b1) * inv;        // B2/3  = (B1 + (2 alpha^2/3) C)/s
+                        const double b3 = fma_vsv(qc, ew_k15, b2) * inv;       // B3/15 = (B2/3 + (4 alpha^4/15) C)/s
                         v = qb0; p1 = -b1; p2 = b2; p3 = -b3;
                     } else if (FASTEW) {
                         // derivatives_ewald (src/ewald.jl:299-312): erfc(x) = exp(-x^2) erfcx(x)
@@ -938,7 +940,7 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
             // -- the pairs set aside above, one per lane per round
             if (slow != 0ull) {
                 __builtin_amdgcn_wave_barrier();
-                slow_pairs<MODE, FASTEW, VDWK == 1>(pc, slow, lane, px, py, pz, s_rec, s_odd, av, ac, smallest_d2);
+                slow_pairs<MODE, FASTEW, VDWK == 1, EW2>(pc, slow, lane, px, py, pz, s_rec, s_odd, av, ac, smallest_d2);
             }
         }
     }
@@ -946,6 +948,10 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
         av.d1x *= -6.0; av.d1y *= -6.0; av.d1z *= -6.0;
         av.d2xy *= 48.0; av.d2xz *= 48.0; av.d2yz *= 48.0;
         av.d3 *= -480.0;
+    }
+    if (EW2) {                                    // constant factors of the B_n recurrence, deferred out of the hot loop
+        ac.d2xy *= 3.0; ac.d2xz *= 3.0; ac.d2yz *= 3.0;
+        ac.d3 *= 15.0;
     }
     if (POINTS) {
         if (valid) write_results<MODE>(g, out, true, pidx, i, j, k, av, ac, smallest_d2);
