@@ -623,6 +623,7 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
     const int hi_top = __builtin_amdgcn_readfirstlane(__double2hiint(reg_hi));
     const unsigned hi_span = hi_top > hi_lo ? (unsigned)(hi_top - hi_lo) : 0u;
     const int hi_cut = __builtin_amdgcn_readfirstlane(__double2hiint(cut_hi));
+    const double int_lo = uniform(r_exact2 * (1.0 + 4e-6)), int_hi = uniform(reg_hi * (1.0 - 4e-6));
     // r^2-indexed tables: record of the interval with key k starts at s_ew2 + (k - ew2_base) * STRIDE
     const int ew2_off = EW2 ? __builtin_amdgcn_readfirstlane(-pc->ew2_base * (CEG_EW2_STRIDE * 8)) : 0;
     int ew2_stride = CEG_EW2_STRIDE * 8;              // kept in a VGPR: v_mad_u32_u24 reads one scalar operand (ew2_off)
@@ -670,7 +671,7 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
         for (int cbase = 0; cbase < total; cbase += 64) {
             // -- stage: lane loads one image of the flattened row list and tests it against the tile
             const int t = cbase + lane;
-            bool keep = false;
+            bool keep = false, interior = false;
             double4 P = make_double4(0, 0, 0, 0);
             double4 LJ = make_double4(0, 0, 0, 0);
             int meta = 0, aidx = 0;
@@ -689,7 +690,13 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
                 const double qx = fmax(0.0, fabs(cx - P.x) - hx);
                 const double qy = fmax(0.0, fabs(cy - P.y) - hy);
                 const double qz = fmax(0.0, fabs(cz - P.z) - hz);
-                keep = (qx * qx + qy * qy + qz * qz) < rc2;
+                const double dmin2 = qx * qx + qy * qy + qz * qz;
+                keep = dmin2 < rc2;
+                // every point of the tile sees this image at a regular distance (beyond the exact-path radius, below the
+                // threshold band of the cutoff, 4e-6 inside both: the hot loop's tests look at the high word of r^2 only):
+                // such candidates run without any range test
+                const double fx = fabs(cx - P.x) + hx, fy = fabs(cy - P.y) + hy, fz = fabs(cz - P.z) + hz;
+                interior = dmin2 > int_lo && (fx * fx + fy * fy + fz * fz) < int_hi;
                 bool hasvdw = false;
                 int vclass = 0;
                 if (MODE != MODE_COULOMB && kd >= 0) {
@@ -717,22 +724,28 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
                 meta = (kd & META_KINDMASK) | (simple ? META_SIMPLE : 0) | (hasvdw ? META_HASVDW : 0) |
                        (vclass == 2 ? META_BUCK : 0);
             }
-            // Kept candidates are compacted into three consecutive groups, so that the hot loops below run without a
+            // Kept candidates are compacted into five consecutive groups, so that the hot loops below run without a
             // per-candidate class test (no record flag to read, no scalar branch around the VdW part):
-            //   [0, nv)         image provably the wrapped one for the whole tile, kind has a VdW rule
-            //   [nv, nreg)      same, no VdW rule (fused mode only: Coulomb term alone)
+            //   [0, nvi)        image provably the wrapped one for the whole tile, kind has a VdW rule, interior (see above)
+            //   [nvi, nv)       same, but some points may be out of range or on the exact path: range tests in the loop
+            //   [nv, nni)       wrapped image, no VdW rule (fused mode only: Coulomb term alone), interior
+            //   [nni, nreg)     same with range tests
             //   [nreg, nkeep)   image near a cell-wrap boundary of this tile: every lane takes the exact path
             const bool simple_c = (meta & META_SIMPLE) != 0;
             const bool withv = MODE != MODE_COULOMB && (meta & META_HASVDW) != 0;
-            const unsigned long long mask_v = __builtin_amdgcn_ballot_w64(keep && simple_c && withv);
-            const unsigned long long mask_n = __builtin_amdgcn_ballot_w64(keep && simple_c && !withv);
+            const bool ks = keep && simple_c;
+            const unsigned long long mask_vi = __builtin_amdgcn_ballot_w64(ks && withv && interior);
+            const unsigned long long mask_vb = __builtin_amdgcn_ballot_w64(ks && withv && !interior);
+            const unsigned long long mask_ni = __builtin_amdgcn_ballot_w64(ks && !withv && interior);
+            const unsigned long long mask_nb = __builtin_amdgcn_ballot_w64(ks && !withv && !interior);
             const unsigned long long mask_x = __builtin_amdgcn_ballot_w64(keep && !simple_c);
-            const int nv = __popcll(mask_v), nreg = nv + __popcll(mask_n), nkeep = nreg + __popcll(mask_x);
+            const int nvi = __popcll(mask_vi), nv = nvi + __popcll(mask_vb), nni = nv + __popcll(mask_ni), nreg = nni + __popcll(mask_nb),
+                      nkeep = nreg + __popcll(mask_x);
             __builtin_amdgcn_wave_barrier();                   // previous chunk's readers are done
             if (keep) {
-                const unsigned long long mine = !simple_c ? mask_x : (withv ? mask_v : mask_n);
-                const int slot = (!simple_c ? nreg : (withv ? 0 : nv)) +
-                                 __builtin_amdgcn_mbcnt_hi((unsigned)(mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mine, 0));
+                const unsigned long long mine = !simple_c ? mask_x : (withv ? (interior ? mask_vi : mask_vb) : (interior ? mask_ni : mask_nb));
+                const int first = !simple_c ? nreg : (withv ? (interior ? 0 : nvi) : (interior ? nv : nni));
+                const int slot = first + __builtin_amdgcn_mbcnt_hi((unsigned)(mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mine, 0));
                 s_rec[slot].xyzq = Quad{P.x, P.y, P.z, P.w};
                 if constexpr (HAS_LJ) s_rec[slot].lj = Quad{LJ.x, LJ.y, LJ.z, LJ.w};
                 s_rec[slot].meta = meta;
@@ -746,8 +759,9 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
             //    Anything else is recorded in a per-lane bit mask and redone after the loop with
             //    the reference's literal arithmetic (slow_pairs).
             unsigned long long slow = 0ull;     // wave-uniform: candidates with at least one odd lane
-            auto pair_body = [&](const int q, auto with_vdw_tag) __attribute__((always_inline)) {
+            auto pair_body = [&](const int q, auto with_vdw_tag, auto interior_tag) __attribute__((always_inline)) {
                 constexpr bool WITH_VDW = decltype(with_vdw_tag)::value;
+                constexpr bool INTERIOR = decltype(interior_tag)::value;
                 const Quad A = s_rec[q].xyzq;
                 double dx = px - A.x, dy = py - A.y, dz = pz - A.z;
                 const double r2 = dx * dx + dy * dy + dz * dz;
@@ -758,14 +772,16 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
                 // (32-bit integer compares issue at twice the FP64 rate).  hi_lo / hi_lo + hi_span are rounded inwards,
                 // hi_cut outwards: a pair within 2^-20 relative of a threshold takes the exact path, which decides.
                 const int hi = __double2hiint(r2);
-                // lane masks straight out of the two compares (ICMP_ULT = 36, ICMP_SLE = 41)
-                const unsigned long long m_in = __builtin_amdgcn_uicmp((unsigned)(hi - hi_lo), hi_span, 36);
-                const unsigned long long oddlanes = __builtin_amdgcn_sicmp(hi, hi_cut, 41) & ~m_in;
-                if (oddlanes != 0ull) {              // scalar branch, rarely taken
-                    slow |= 1ull << q;
-                    if (lane == 0) s_odd[q] = oddlanes;
+                if constexpr (!INTERIOR) {
+                    // lane masks straight out of the two compares (ICMP_ULT = 36, ICMP_SLE = 41)
+                    const unsigned long long m_in = __builtin_amdgcn_uicmp((unsigned)(hi - hi_lo), hi_span, 36);
+                    const unsigned long long oddlanes = __builtin_amdgcn_sicmp(hi, hi_cut, 41) & ~m_in;
+                    if (oddlanes != 0ull) {              // scalar branch, rarely taken
+                        slow |= 1ull << q;
+                        if (lane == 0) s_odd[q] = oddlanes;
+                    }
+                    if (!((unsigned)(hi - hi_lo) < hi_span)) return;
                 }
-                if (!((unsigned)(hi - hi_lo) < hi_span)) return;
 
                 // ---- regular pair: 2 A <= r < cutoff
                 const double dxy = dx * dy, dxz = dx * dz, dyz = dy * dz;
@@ -921,10 +937,14 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
                     ac.d3 = __builtin_fma(p3, dxyz, ac.d3);
                 }
             };
-            if (MODE != MODE_COULOMB)
-                for (int q = 0; q < nv; ++q) pair_body(q, std::true_type{});
-            if (MODE != MODE_VDW)
-                for (int q = (MODE == MODE_COULOMB ? 0 : nv); q < nreg; ++q) pair_body(q, std::false_type{});
+            if (MODE != MODE_COULOMB) {
+                for (int q = 0; q < nvi; ++q) pair_body(q, std::true_type{}, std::true_type{});
+                for (int q = nvi; q < nv; ++q) pair_body(q, std::true_type{}, std::false_type{});
+            }
+            if (MODE != MODE_VDW) {
+                for (int q = (MODE == MODE_COULOMB ? 0 : nv); q < nni; ++q) pair_body(q, std::false_type{}, std::true_type{});
+                for (int q = nni; q < nreg; ++q) pair_body(q, std::false_type{}, std::false_type{});
+            }
             // third group: the lanes within the cutoff of THIS image go to the exact path (which works from the atom and finds
             // its nearest image itself -- two images of one atom are never both inside the cutoff of a point)
             for (int q = nreg; q < nkeep; ++q) {
