@@ -937,6 +937,10 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
                     ac.d3 = __builtin_fma(p3, dxyz, ac.d3);
                 }
             };
+#ifdef CEG_STAGING_ONLY          // measurement aid: what the kernel costs without its hot loops (results are garbage)
+            if (nkeep == 12345) { av.v += s_rec[0].xyzq.x; ac.v += s_rec[1].xyzq.y; }
+            continue;
+#endif
             if (MODE != MODE_COULOMB) {
                 for (int q = 0; q < nvi; ++q) pair_body(q, std::true_type{}, std::true_type{});
                 for (int q = nvi; q < nv; ++q) pair_body(q, std::true_type{}, std::false_type{});
