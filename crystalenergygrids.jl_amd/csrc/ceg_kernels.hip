@@ -654,17 +654,21 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
                 count = ib.bin_start[rowbase + bz1 + 1] - start;
             }
         }
-        // inclusive scan of counts over the wave
+        // inclusive scan of counts over the wave.  The lane id is made opaque here: the permute addresses and the two LDS
+        // addresses below are loop invariants that the compiler otherwise hoists out of the tile loop and, at the VGPR limit
+        // of the hot loops, parks in scratch (stores + reloads per tile that showed up as HBM traffic)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
         int incl = count;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const int up = __shfl_up(incl, o);
-            if (lane >= o) incl += up;
+            const int up = __builtin_amdgcn_ds_bpermute((ln - o) << 2, incl);      // lanes < o read a wrapped lane and ignore it
+            if (ln >= o) incl += up;
         }
         __builtin_amdgcn_wave_barrier();                       // previous batch's readers are done
-        s_rowstart[lane] = start;
-        s_rowprefix[lane + 1] = incl;
-        if (lane == 0) s_rowprefix[0] = 0;
+        s_rowstart[ln] = start;
+        s_rowprefix[ln + 1] = incl;
+        if (ln == 0) s_rowprefix[0] = 0;
         __builtin_amdgcn_wave_barrier();
         const int total = __builtin_amdgcn_readfirstlane(s_rowprefix[64]);
 
