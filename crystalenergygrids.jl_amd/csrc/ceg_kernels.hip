@@ -76,7 +76,12 @@ __device__ __forceinline__ double grid_coord(int i, double size, int dims, doubl
 // ------------------------------------------------------------------ pair potentials
 // derivativesGrid over the rule run of one atom kind (src/interactions.jl:432-472,599-610).
 // `rb`,`re` are wave-uniform.
-template <bool LJONLY = false>
+// exp for the exact path of k_culled: out of line, so that its polynomial constants stay inside the call instead of being
+// hoisted to the top of the kernel and parked in scratch once per tile (they were 64 of the 128 B per lane of the fused
+// Buckingham variants)
+__device__ __attribute__((noinline)) double exp_out_of_line(double x) { return exp(x); }
+
+template <bool LJONLY = false, bool COLD = false>
 __device__ __forceinline__ void vdw_terms(const DevRule* __restrict__ rules, int rb, int re, double r2,
                                           double& v_out, double& p1_out, double& p2_out, double& p3_out)
 {
@@ -101,7 +106,7 @@ __device__ __forceinline__ void vdw_terms(const DevRule* __restrict__ rules, int
             const double r = sqrt(r2);
             const double r6 = r4 * r2;
             const double x6 = C / r6;
-            const double xe = A * exp(-B * r);
+            const double xe = A * (COLD ? exp_out_of_line(-B * r) : exp(-B * r));
             tv = xe - x6;
             t1 = -B * xe / r + 6.0 * x6 / r2;
             t2 = -48.0 * x6 / r4 + B * xe * (1.0 + B * r) / (r2 * r);
@@ -407,7 +412,7 @@ __device__ __forceinline__ void slow_pairs(const PlanConst* __restrict__ pc, uns
         if (MODE != MODE_COULOMB && (mt & META_HASVDW)) {
             const int kd = mt & META_KINDMASK;
             double v, p1, p2, p3;
-            vdw_terms<LJSLOW>(pc->rt.rules, pc->rt.offset[kd], pc->rt.offset[kd + 1], r2, v, p1, p2, p3);
+            vdw_terms<LJSLOW, true>(pc->rt.rules, pc->rt.offset[kd], pc->rt.offset[kd + 1], r2, v, p1, p2, p3);
             if (LJSLOW) {        // the LJ-only hot loop accumulates p1/-6, p2/48, p3/-480 (scaled once per tile at the end)
                 p1 *= -1.0 / 6.0; p2 *= 1.0 / 48.0; p3 *= -1.0 / 480.0;
             }
@@ -439,11 +444,15 @@ __device__ __forceinline__ int mad_u24(int a, int b, int c)
 // A wave-uniform FP64 value held in an SGPR pair.  gfx950 has no scalar FP64 ALU, so the compiler keeps
 // every FP64 result in VGPRs even when all lanes hold the same number; for values that stay live across
 // the hot loop (tile box, thresholds) that costs two VGPRs each and, at 4 waves per SIMD, spills.
+// (the halves pass through an empty asm first: the compiler folds __builtin_amdgcn_readfirstlane of a value it can prove
+// uniform and then keeps that value in a VGPR pair -- which is what this function exists to avoid; the builtin itself stays,
+// so that the compiler knows the instruction it is scheduling)
 __device__ __forceinline__ double uniform(double x)
 {
-    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
-    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
-    return __hiloint2double(hi, lo);
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    asm("" : "+v"(lo));
+    asm("" : "+v"(hi));
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(hi), __builtin_amdgcn_readfirstlane(lo));
 }
 
 __device__ __forceinline__ double wave_min(double x)
