@@ -19,7 +19,9 @@
 //    been expanded on the host into explicit lattice images binned on a cartesian
 //    lattice; the wave gathers the images whose bin rows intersect the tile's cutoff
 //    neighbourhood, prunes them against the tile box, compacts the survivors into LDS
-//    grouped by class (VdW-active / Coulomb only / near a cell-wrap boundary) and every lane
+//    grouped by class (VdW-active / Coulomb only, each split into candidates the whole tile sees at a
+//    regular distance -- no range test in their loop -- and the rest; plus images near a cell-wrap
+//    boundary) and every lane
 //    then loops over the same (broadcast) candidate, one branch-free loop per class.  For each
 //    (point, image) pair inside the cutoff the reference's *selection rule* (is this
 //    image the one periodic_distance2! would return?) is evaluated exactly, including
