@@ -179,9 +179,10 @@ def main():
     full_c = torch.empty((8, nx, ny, nz), dtype=torch.float32, device=dev) if need_c else None
     if not multi:
         loc_v, loc_c = full_v, full_c
-    elif cyc is not None:      # one compact [8, m, ny, nz] block per chunk
-        loc_v = torch.empty((cyc.nchunks, 8, cyc.m, ny, nz), dtype=torch.float32, device=dev) if need_v else None
-        loc_c = torch.empty((cyc.nchunks, 8, cyc.m, ny, nz), dtype=torch.float32, device=dev) if need_c else None
+    elif cyc is not None:      # one compact [8, m, ny, nz] block per chunk and grid, the grids of a chunk adjacent (one collective)
+        joint = torch.empty((cyc.nchunks, int(need_v) + int(need_c), 8, cyc.m, ny, nz), dtype=torch.float32, device=dev)
+        loc_v = joint[:, 0] if need_v else None
+        loc_c = joint[:, 1 if need_v else 0] if need_c else None
     else:
         loc_v = torch.empty((8, n_local, ny, nz), dtype=torch.float32, device=dev) if need_v else None
         loc_c = torch.empty((8, n_local, ny, nz), dtype=torch.float32, device=dev) if need_c else None
@@ -200,7 +201,8 @@ def main():
 
     fulls = [t for t in (full_v, full_c) if t is not None]
     locs = [t for t in (loc_v, loc_c) if t is not None]
-    pipe = PipelinedGather(cyc, fulls, locs, mode=args.gather, force_collectives=args.force_exchange) if cyc is not None else None
+    pipe = PipelinedGather(cyc, fulls, locs, mode=args.gather, force_collectives=args.force_exchange,
+                           joint=joint if cyc is not None and multi else None) if cyc is not None else None
 
     def launch_chunk(j, ib, ie, blocks):
         it = iter(blocks)

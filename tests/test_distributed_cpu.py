@@ -56,6 +56,21 @@ def _worker(rank, world, port, spacing, outdir):
 
                 PipelinedGather(cyc, [full2], [loc], mode=mode).run(launch)
                 np.save(os.path.join(outdir, f"rank{rank}_cyclic_{mode}.npy"), full2.numpy())
+            # two grids whose blocks are slices of one joint tensor: ONE collective per chunk (bench.py's fused build)
+            joint = torch.full((cyc.nchunks, 2, 8, cyc.m, ny, nz), float("nan"), dtype=torch.float32)
+            fa = torch.full((8, nx, ny, nz), float("nan"), dtype=torch.float32)
+            fb = torch.full((8, nx, ny, nz), float("nan"), dtype=torch.float32)
+
+            def launch2(j, ib, ie, blocks):
+                gg, _ = O.grid_vdw(w.probe_vdw, w.cset, lam, thr, ib, ie, nthreads=2)
+                blocks[0].copy_(torch.from_numpy(gg[:, ib:ie]))
+                blocks[1].copy_(torch.from_numpy(-2.0 * gg[:, ib:ie]))
+
+            pg = PipelinedGather(cyc, [fa, fb], [joint[:, 0], joint[:, 1]], mode="staged", joint=joint)
+            assert pg.joint is not None
+            pg.run(launch2)
+            np.save(os.path.join(outdir, f"rank{rank}_cyclic_joint_a.npy"), fa.numpy())
+            np.save(os.path.join(outdir, f"rank{rank}_cyclic_joint_b.npy"), fb.numpy())
     finally:
         dist.destroy_process_group()
 
@@ -78,7 +93,12 @@ def test_slab_gather_gloo(tmp_path, world, spacing, oracle):
             if f.exists():
                 np.testing.assert_array_equal(np.load(f), ref)
                 ncyc += 1
-    assert ncyc in (0, 3 * world)
+        fa = tmp_path / f"rank{r}_cyclic_joint_a.npy"
+        if fa.exists():
+            np.testing.assert_array_equal(np.load(fa), ref)
+            np.testing.assert_array_equal(np.load(tmp_path / f"rank{r}_cyclic_joint_b.npy"), -2.0 * ref)
+            ncyc += 1
+    assert ncyc in (0, 4 * world)
 
 
 def test_cyclic_plan_shapes():
