@@ -977,6 +977,9 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
                 }
             }
             // -- the pairs set aside above, one per lane per round
+#ifdef CEG_NO_EXACT_PATH          // measurement aid: what the exact path costs (results are wrong near atoms and thresholds)
+            slow = 0ull;
+#endif
             if (slow != 0ull) {
                 __builtin_amdgcn_wave_barrier();
                 slow_pairs<MODE, FASTEW, VDWK == 1, EW2>(pc, slow, lane, px, py, pz, s_rec, s_odd, av, ac, smallest_d2);
