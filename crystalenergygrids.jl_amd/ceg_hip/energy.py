@@ -335,10 +335,14 @@ class DeviceMonteCarlo:
         self._slot[i].append(int(mol.value))
         return len(self._slot[i]) - 1
 
-    def remove(self, idx) -> None:
-        """remove_one_system! on the device; the host-side indices behave like ``del positions[i][j]``."""
+    def remove(self, idx) -> int:
+        """remove_one_system!(mc, i, j) on the device; the host-side indices behave like the reference's (montecarlo.jl:798-808):
+        the last molecule of kind ``i`` takes index ``j``; returns its old index."""
         i, j = idx
-        d = self._slot[i].pop(j)
+        d = self._slot[i][j]
+        last = len(self._slot[i]) - 1
+        self._slot[i][j] = self._slot[i][last]
+        self._slot[i].pop()
         moved = C.c_int32(-1)
         _abi.check(self._lib, self._lib.ceg_mc_remove(self._h, d, C.byref(moved)))
         if moved.value != d:                         # the device moved its last molecule into the hole
@@ -346,6 +350,7 @@ class DeviceMonteCarlo:
                 for q, v in enumerate(kind):
                     if v == moved.value:
                         kind[q] = d
+        return last
 
     def baseline_energy(self):
         """baseline_energy (montecarlo.jl:530-542) from the device-resident state: framework and guest-guest terms from row 0 of one

@@ -298,7 +298,8 @@ def insertion_energy(mc: MonteCarloSetup, i: int, positions) -> MCEnergyReport:
 
 
 def add_molecule(mc: MonteCarloSetup, i: int, positions) -> int:
-    """add_one_system! (montecarlo.jl:615-621, ewald.jl:775-792): append a molecule of kind ``i``; returns its index in the kind."""
+    """add_one_system! (montecarlo.jl:835-861, ewald.jl:775-792): append a molecule of kind ``i``; returns its index in the kind;
+    the tail correction follows the new species count."""
     pos = np.array(positions, dtype=np.float64).reshape(-1, 3)
     j = len(mc.positions[i])
     if mc.ewald.alpha != 0.0:
@@ -307,19 +308,28 @@ def add_molecule(mc: MonteCarloSetup, i: int, positions) -> int:
         new = _molecule_sf(mc, mc.ffidx[i], pos)
         mc.sums = np.insert(mc.sums, col, new, axis=1)
         mc.sums[:, 0] += new
+    if mc.tail_cross is not None:                                  # modify_species!(mc.tailcorrection, i, 1), montecarlo.jl:858
+        mc.tailcorrection += modify_species_dryrun(mc.tail_framework, mc.tail_cross, [len(k) for k in mc.positions], i, 1)
     mc.positions[i].append(pos)
     return j
 
 
-def remove_molecule(mc: MonteCarloSetup, idx: Tuple[int, int]) -> None:
-    """remove_one_system! (ewald.jl:794-810): the molecule leaves; later molecules of its kind move down by one."""
+def remove_molecule(mc: MonteCarloSetup, idx: Tuple[int, int]) -> int:
+    """remove_one_system!(mc, i, j) (montecarlo.jl:756-817, ewald.jl:794-810): the molecule leaves and the LAST molecule of its
+    kind takes index ``j`` (montecarlo.jl:798-808); returns that molecule's old index (== ``j`` when it was the last one),
+    like the reference's ``lastj``."""
     i, j = idx
-    if mc.ewald.alpha != 0.0:
-        assert mc.sums is not None
-        col = 1 + mc.flat_index(i, j)
+    last = len(mc.positions[i]) - 1
+    if mc.ewald.alpha != 0.0 and mc.sums is not None:        # an uninitialised Ewald state stays uninitialised (ewald.jl:794-797)
+        col, col_last = 1 + mc.flat_index(i, j), 1 + mc.flat_index(i, last)
         mc.sums[:, 0] -= mc.sums[:, col]
-        mc.sums = np.delete(mc.sums, col, axis=1)
-    del mc.positions[i][j]
+        mc.sums[:, col] = mc.sums[:, col_last]
+        mc.sums = np.delete(mc.sums, col_last, axis=1)
+    if mc.tail_cross is not None:                                  # modify_species!(mc.tailcorrection, i, -1), montecarlo.jl:814
+        mc.tailcorrection += modify_species_dryrun(mc.tail_framework, mc.tail_cross, [len(k) for k in mc.positions], i, -1)
+    mc.positions[i][j] = mc.positions[i][last]
+    mc.positions[i].pop()
+    return last
 
 
 def setup_montecarlo(framework, pff, systems: Sequence[RASPASystem], *, blockfiles=None, gridstep: float = 0.15,

@@ -283,8 +283,7 @@ def test_mc_insertions_and_removals(hip_lib, tmp_path):
                 j = int(rng.integers(len(mc.positions[kind])))
                 row = dev.trial((kind, j), np.empty((0, len(mc.ffidx[kind]), 3)))[0]
                 check(row, M.movement_energy(mc, (kind, j)), ("delete", step))
-                dev.remove((kind, j))
-                M.remove_molecule(mc, (kind, j))
+                assert dev.remove((kind, j)) == M.remove_molecule(mc, (kind, j))     # the last molecule of the kind takes index j
                 nrem += 1
             else:                                                    # displacement
                 if not mc.positions[kind]:

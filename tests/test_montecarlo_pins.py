@@ -193,6 +193,56 @@ def test_restart_co2_in_cha_na(oracle_grids):
     assert base == pytest.approx(-14128.88426348615, rel=1e-9)
 
 
+def test_deletion_and_addition(oracle_grids):
+    """The reference's "Deletion and addition" testset, runtests.jl:302-352: remove_one_system! / add_one_system! / update_mc! /
+    movement_energy for every order in which the species can be listed -- in particular the INDEX semantics of a removal (the last
+    molecule of the kind takes the freed index, montecarlo.jl:798-808) and removal before the Ewald state exists."""
+    import copy
+    co2_1 = [[4.221014336721, 2.235273775272, 5.118873160667], [4.915895823098, 3.103469549355, 4.829776606287],
+             [5.610777309474, 3.971665323438, 4.540680051907]]
+    co2_2 = [[13.732840754800, 5.744459327798, 8.119705823930], [13.418141549103, 6.398573841906, 7.229032139371],
+             [13.103442343406, 7.052688356015, 6.338358454812]]
+    co2_3 = [[21.473519181736, 19.719777629492, 13.809504713725], [21.888511731126, 20.756701257738, 13.539742646090],
+             [22.303504280517, 21.793624885985, 13.269980578454]]
+    pos_x = [[5.488965064161, 14.335087694715, 16.087580364999], [4.887655471102, 13.508430918264, 15.562922050243],
+             [4.286345878043, 12.681774141812, 15.038263735487]]
+    fw = "CHA_1.4_3b4eeb96_Na_11812"
+    ar = ceg.load_molecule_RASPA("Ar", "TraPPE", FFNAME)
+    m1, m2, m3 = _mol("CO2", co2_1), _mol("CO2", co2_2), _mol("CO2", co2_3)
+    pos1, pos2 = np.array(co2_1), np.array(co2_2)
+
+    def same(a, b):
+        return float(a) == pytest.approx(float(b), rel=1e-9, abs=1e-7)
+
+    ref = M.setup_montecarlo(fw, FFNAME, [m1, m3, ar])
+    base_ref = M.baseline_energy(ref)
+    move_ref = M.movement_energy(ref, (0, 0), pos2)
+    M.update_mc(ref, (0, 0), pos2)
+    othermove_ref = M.movement_energy(ref, (0, 1), pos_x)
+    # (species as listed, kind of the CO2 0-based, index of the CO2 that is removed first 0-based)
+    for mols, i, j in (([ar, m1, m2, m3], 1, 1), ([ar, m2, m1, m3], 1, 0), ([m1, m2, m3, ar], 0, 1), ([m2, m1, m3, ar], 0, 0)):
+        other = 1 - j
+        mc_a = M.setup_montecarlo(fw, FFNAME, mols)
+        mc_b = copy.deepcopy(mc_a)
+        M.remove_molecule(mc_a, (i, j))                       # before any baseline_energy: no Ewald state yet
+        assert same(M.baseline_energy(mc_a), base_ref)
+        assert same(M.movement_energy(mc_a, (i, other), pos2), move_ref)
+        M.update_mc(mc_a, (i, other), pos2)
+        assert same(M.movement_energy(mc_a, (i, j), pos_x), othermove_ref)
+        assert M.add_molecule(mc_a, i, pos1) == 2             # `== 3` in the reference's 1-based count
+        M.remove_molecule(mc_a, (i, other))
+        assert same(M.movement_energy(mc_a, (i, other), pos2), move_ref)
+
+        M.baseline_energy(mc_b)
+        M.remove_molecule(mc_b, (i, j))
+        assert same(M.movement_energy(mc_b, (i, other), pos2), move_ref)
+        M.update_mc(mc_b, (i, other), pos2)
+        assert same(M.movement_energy(mc_b, (i, j), pos_x), othermove_ref)
+        assert M.add_molecule(mc_b, i, pos1) == 2
+        M.remove_molecule(mc_b, (i, other))
+        assert same(M.movement_energy(mc_b, (i, other), pos2), move_ref)
+
+
 def _trio(M_):
     na = [[3.019388765467742, 0.8997706038543032, 26.11901621898599]]
     co2_1 = [[11.93940309885289, 8.48657378465003, 2.135736631609201], [11.10485516124311, 7.710040763525694, 1.991767166323031],
