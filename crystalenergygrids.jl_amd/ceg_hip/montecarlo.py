@@ -124,6 +124,7 @@ class MonteCarloSetup:
     tail_framework: List[float] = field(default_factory=list)
     tail_cross: Optional[np.ndarray] = None
     sums: Optional[np.ndarray] = None     # complex[num_kvecs, 1 + nmolecules], set by baseline_energy
+    models: List[np.ndarray] = field(default_factory=list)   # per kind: atom positions of the model molecule (mc.models)
 
     # ---- flat views
     def molecules(self):
@@ -297,13 +298,12 @@ def insertion_energy(mc: MonteCarloSetup, i: int, positions) -> MCEnergyReport:
     return MCEnergyReport(fv, fd, single_contribution_vdw(mc, idx, poss), rec)
 
 
-def add_molecule(mc: MonteCarloSetup, i: int, positions) -> int:
+def add_molecule(mc: MonteCarloSetup, i: int, positions=None) -> int:
     """add_one_system! (montecarlo.jl:835-861, ewald.jl:775-792): append a molecule of kind ``i``; returns its index in the kind;
     the tail correction follows the new species count."""
-    pos = np.array(positions, dtype=np.float64).reshape(-1, 3)
+    pos = np.array(mc.models[i] if positions is None else positions, dtype=np.float64).reshape(-1, 3)    # montecarlo.jl:844
     j = len(mc.positions[i])
-    if mc.ewald.alpha != 0.0:
-        assert mc.sums is not None, "Please call baseline_energy(mc) first"
+    if mc.ewald.alpha != 0.0 and mc.sums is not None:         # an uninitialised Ewald state stays uninitialised
         col = 1 + mc.flat_index(i, j)
         new = _molecule_sf(mc, mc.ffidx[i], pos)
         mc.sums = np.insert(mc.sums, col, new, axis=1)
@@ -350,17 +350,21 @@ def setup_montecarlo(framework, pff, systems: Sequence[RASPASystem], *, blockfil
     if np.any(perpendicular_lengths(cellmat) <= 24.0):
         raise ValueError("The current cell has at least one perpendicular length lower than 24.0Å: please use a larger supercell")
 
-    mols = [default_system(s, pff) for s in systems]
+    # a system is a molecule, or a pair (molecule, n): n copies at the model's positions (n = 0: the kind exists, empty;
+    # montecarlo.jl:234-236)
+    pairs = [(default_system(s[0] if isinstance(s, tuple) else s, pff), int(s[1]) if isinstance(s, tuple) else 1) for s in systems]
+    mols = [s for s, _n in pairs]
     kinds: List[Tuple[str, ...]] = []
     positions: List[List[np.ndarray]] = []
     models: List[RASPASystem] = []
-    for s in mols:
+    for s, n in pairs:
         key = tuple(s.atomic_symbol)
         if key not in kinds:
             kinds.append(key)
             positions.append([])
             models.append(s)
-        positions[kinds.index(key)].append(np.array(s.position, dtype=np.float64).reshape(-1, 3))
+        for _ in range(n):
+            positions[kinds.index(key)].append(np.array(s.position, dtype=np.float64).reshape(-1, 3))
     ffidx = [[ff.sdict[get_atom_name(a)] if a not in ff.sdict else ff.sdict[a] for a in key] for key in kinds]
     charges = np.full(len(ff.sdict) + 1, np.nan)
     for ids, model in zip(ffidx, models):
@@ -391,4 +395,4 @@ def setup_montecarlo(framework, pff, systems: Sequence[RASPASystem], *, blockfil
     lam = 2 * math.pi / float(np.linalg.det(cellmat))
     value, tframework, tcross = tail_correction(ff, ffidx, num_framework_atoms, lam, [len(p) for p in positions])
     return MonteCarloSetup(ff, cellmat, np.linalg.inv(cellmat), ffidx, charges, positions, ewald, coulomb, grids, value,
-                           tframework, tcross)
+                           tframework, tcross, models=[np.array(m.position, dtype=np.float64).reshape(-1, 3) for m in models])

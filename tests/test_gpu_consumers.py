@@ -544,3 +544,67 @@ def test_pairs_neighbour_cells(hip_lib, oracle, forcefield, monkeypatch):
                                                  _abi.i32ptr(np.ascontiguousarray(offsets, dtype=np.int32)), ff.nkinds, COULOMBIC_CONVERSION_FACTOR))
     assert hip_lib.ceg_pairs_neighbour_cells(h, None) == 0
     hip_lib.ceg_pairs_destroy(h)
+
+
+def test_incremental_ewald_context_testset(hip_lib, monkeypatch):
+    """The reference's "IncrementalEwaldContext" testset, runtests.jl:61-121, on the device-resident state: the flat index a
+    removal returns (the last species takes the freed index, ewald.jl:403-431), the index an addition returns, and after every
+    step the total guest structure factor (hence compute_ewald) equal to that of the equivalent system built from scratch."""
+    from ceg_hip import grids as G, montecarlo as M
+    from ceg_hip.energy import DeviceMonteCarlo
+    monkeypatch.setattr(M, "retrieve_or_create_grid", lambda *a, **k: G.EnergyGrid.trivial(True))      # Ewald only: no grids
+    na = ceg.load_molecule_RASPA("Na", "TraPPE", "BoulfelfelSholl2021")
+    co2 = ceg.load_molecule_RASPA("CO2", "TraPPE", "BoulfelfelSholl2021")
+    pos1, pos2, pos3 = np.array([[1.0, 2.5, 1.7]]), np.array([[6.2, 5.1, 3.0]]), np.array([[4.1, 3.7, 2.2]])
+    pco2 = np.asarray(co2.position, dtype=np.float64).reshape(-1, 3)
+    co2_2 = np.array([[5.491645446274333, 8.057854365959964, 8.669190836544463], [6.335120278303245, 7.462084936052019, 9.172986424179925],
+                      [7.178595110332157, 6.866315506144074, 9.676782011815387]])
+    mc = M.setup_montecarlo("CHA_1.4_3b4eeb96", "BoulfelfelSholl2021", [na.with_positions(pos1), na.with_positions(pos2), co2])
+    M.compute_ewald_mc(mc)
+    dev = DeviceMonteCarlo(mc)
+    lib, h = dev._lib, dev._h
+    kinds = [np.ascontiguousarray([k - 1 for k in ids], dtype=np.int32) for ids in mc.ffidx]      # 0: Na, 1: CO2
+    state = [(0, pos1), (0, pos2), (1, pco2)]                                                      # device order (flat index ij - 1)
+
+    def remove(ij):          # 1-based like the reference; returns the reference's return value
+        moved = C.c_int32(-1)
+        _abi.check(lib, lib.ceg_mc_remove(h, ij - 1, C.byref(moved)))
+        state[ij - 1] = state[-1]
+        state.pop()
+        return moved.value + 1
+
+    def add(i, pos):
+        out = C.c_int32(-1)
+        p = np.ascontiguousarray(pos, dtype=np.float64)
+        _abi.check(lib, lib.ceg_mc_insert(h, _abi.i32ptr(kinds[i - 1]), len(kinds[i - 1]), _abi.dptr(p.reshape(-1)), C.byref(out)))
+        state.append((i - 1, p))
+        return out.value + 1
+
+    def total_sf():
+        re, im = np.empty(len(mc.ewald.kfactors)), np.empty(len(mc.ewald.kfactors))
+        _abi.check(lib, lib.ceg_mc_get_state(h, None, _abi.dptr(re), _abi.dptr(im)))
+        return re + 1j * im
+
+    def expected_sf():
+        return sum(M._molecule_sf(mc, mc.ffidx[i], p) for i, p in state)
+
+    def check():
+        ref = expected_sf()
+        assert np.abs(total_sf() - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+
+    check()
+    assert remove(3) == 3 and add(2, pco2) == 3; check()                      # :81-83
+    assert remove(2) == 3 and add(1, pos2) == 3; check()                      # :85-87
+    assert remove(2) == 3 and add(2, pco2) == 3; check()                      # :91-93
+    assert remove(2) == 3 and remove(1) == 2                                  # :95-96
+    assert add(1, pos2) == 2 and add(1, pos1) == 3; check()                   # :97-99
+    # move_one_system!(ctx, 3, pos3) (:103) = trial + accept on the device state
+    _abi.check(lib, lib.ceg_mc_accept(h, 2, _abi.dptr(np.ascontiguousarray(pos3).reshape(-1))))
+    state[2] = (state[2][0], pos3)
+    check()
+    assert remove(3) == 3 and add(1, pos3) == 3; check()                      # :105-107
+    assert add(2, co2_2) == 4; check()                                        # :112
+    # the same species listed in another order give the same energy (:113-120): the structure factor is a plain sum
+    other = sum(M._molecule_sf(mc, mc.ffidx[i], p) for i, p in ((1, co2_2), (1, pco2), (0, pos3), (0, pos2)))
+    assert np.abs(total_sf() - other).max() <= 1e-10 * max(1.0, np.abs(other).max())
+    dev.close()

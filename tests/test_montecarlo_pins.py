@@ -193,6 +193,43 @@ def test_restart_co2_in_cha_na(oracle_grids):
     assert base == pytest.approx(-14128.88426348615, rel=1e-9)
 
 
+def test_montecarlo_setup_testset(oracle_grids):
+    """The reference's "MonteCarloSetup" testset, runtests.jl:126-161: which terms of baseline_energy / movement_energy depend on
+    an uncharged / a charged guest's position, movement_energy at the current position == with the position given, the
+    baseline of the moved system == baseline - before + after, and a kind listed with zero molecules + add_one_system!."""
+    co2 = ceg.load_molecule_RASPA("CO2", "TraPPE", FFNAME)
+    pos1, pos2 = [[0.0, 2.0, 4.0]], [[1.0, 3.0, 1.0]]
+    fw = "CHA_1.4_3b4eeb96"
+    ar1 = M.setup_montecarlo(fw, FFNAME, [co2, _mol("Ar", pos1)])
+    ar2 = M.setup_montecarlo(fw, FFNAME, [co2, _mol("Ar", pos2)])
+    b1, b2 = M.baseline_energy(ar1), M.baseline_energy(ar2)
+    mov1 = M.movement_energy(ar1, (1, 0))
+    assert b1.reciprocal == b2.reciprocal and b1.framework_direct == b2.framework_direct             # :140-141
+    assert b1.inter != b2.inter and b1.framework_vdw != b2.framework_vdw                             # :142-143
+    assert mov1.reciprocal == 0.0 and mov1.framework_direct == 0.0                                   # :144
+    again = M.movement_energy(ar1, (1, 0), pos1)
+    assert (mov1.framework_vdw, mov1.framework_direct, mov1.inter, mov1.reciprocal) == \
+           (again.framework_vdw, again.framework_direct, again.inter, again.reciprocal)               # :145
+    assert float(b2) == pytest.approx(float(b1) - float(mov1) + float(M.movement_energy(ar1, (1, 0), pos2)), rel=1e-9)   # :146
+
+    na1 = M.setup_montecarlo(fw, FFNAME, [co2, _mol("Na", pos1)])
+    na2 = M.setup_montecarlo(fw, FFNAME, [co2, _mol("Na", pos2)])
+    bn1 = M.baseline_energy(na1)
+    m11, m12 = M.movement_energy(na1, (1, 0)), M.movement_energy(na1, (1, 0), pos2)
+    a = M.movement_energy(na1, (1, 0), pos1)
+    assert float(m11) == pytest.approx(float(a), rel=1e-12, abs=1e-9)                                # :152 (== in the reference)
+    assert float(M.baseline_energy(na2)) == pytest.approx(float(bn1) - float(m11) + float(m12), rel=1e-9)          # :153
+
+    # handling of empty systems (:155-160)
+    empty = M.setup_montecarlo("CIT-7", FFNAME, [(co2, 0)])
+    assert float(M.baseline_energy(empty)) == 0.0
+    one = M.setup_montecarlo("CIT-7", FFNAME, [co2.with_positions(empty.models[0])])
+    assert M.add_molecule(empty, 0) == 0
+    be, bo = M.baseline_energy(empty), M.baseline_energy(one)
+    for name in ("framework_vdw", "framework_direct", "inter", "reciprocal", "tailcorrection"):
+        assert getattr(be, name) == pytest.approx(getattr(bo, name), rel=1e-12, abs=1e-9), name
+
+
 def test_deletion_and_addition(oracle_grids):
     """The reference's "Deletion and addition" testset, runtests.jl:302-352: remove_one_system! / add_one_system! / update_mc! /
     movement_energy for every order in which the species can be listed -- in particular the INDEX semantics of a removal (the last
