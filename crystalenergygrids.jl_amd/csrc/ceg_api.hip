@@ -226,7 +226,7 @@ int convert_rules(ceg_plan* p, const ceg_rule_t* rules, const int32_t* rule_offs
             if (first) { p->bk[0] = f.p0; p->bk[1] = f.p1; p->bk[2] = f.p2; p->bk[3] = f.shift; first = false; }
             else same = f.p0 == p->bk[0] && f.p1 == p->bk[1] && f.p2 == p->bk[2] && f.shift == p->bk[3];
         }
-        p->single_buck = same && !first && p->bk[1] > 0.0;
+        p->single_buck = same && !first && p->bk[1] > 0.0 && p->bk[2] != 0.0 && std::isfinite(1.0 / p->bk[2]);
     }
     // hard spheres must lie inside the exact-path radius for the fast Buckingham class
     p->r_exact2 = std::max(CEG_R_EXACT2, hs_max2 * (1.0 + 1e-9) + 1e-9);
@@ -777,12 +777,16 @@ extern "C" int ceg_plan_create(ceg_plan_t** plan, int32_t device,
         if (!rc && p->vdwk == 2 && p->single_buck && !std::getenv("CEG_HIP_NO_BK2")) {
             std::vector<double> tb;
             int32_t base = 0, ni = 0;
-            if (build_bk2_table(p->bk[0], p->bk[1], p->bk[2], p->r_exact2, cutoff2, tb, &base, &ni)) {
+            // the table holds G0/C: the hot loop accumulates the channels divided by C, 6C, -48C, 480C (ceg_kernels.hip)
+            if (build_bk2_table(p->bk[0] / p->bk[2], p->bk[1], 1.0, p->r_exact2, cutoff2, tb, &base, &ni)) {
                 rc = upload(&p->d_bk2, tb.data(), tb.size());
                 hc.bk2_tab = p->d_bk2;
                 hc.bk2_ni = ni;
                 hc.bk2_base = base;
-                hc.bk_B = p->bk[1]; hc.bk_C = p->bk[2]; hc.bk_shift = p->bk[3];
+                const double B = p->bk[1], C = p->bk[2];
+                hc.bk_B = B; hc.bk_C = C; hc.bk_invC = 1.0 / C; hc.bk_nshift = -p->bk[3] / C;
+                hc.bk_c1 = -B / 6.0; hc.bk_c2 = -B / 48.0; hc.bk_c3 = B * B / 3.0; hc.bk_c4 = -B / 160.0;
+                hc.bk_s1 = 1.0 / (6.0 * C); hc.bk_s2 = -1.0 / (48.0 * C); hc.bk_s3 = 1.0 / (480.0 * C);
                 if (!rc) p->vdwk = 3;
             }
         }

@@ -120,7 +120,9 @@ struct PlanConst {
     // single Buckingham class (VDWK = 3): G0(s) = A exp(-B sqrt(s)) on r^2 intervals of its own (CEG_BK2_LOGM), [bk2_ni][CEG_BK2_STRIDE]
     const double* bk2_tab;
     int32_t bk2_ni, bk2_base;
-    double bk_B, bk_C, bk_shift;
+    double bk_B, bk_C, bk_invC;                       // single tabulated Buckingham class: B, C, 1/C and the constants of the
+    double bk_nshift, bk_c1, bk_c2, bk_c3, bk_c4;      // scaled hot loop: -shift/C, -B/6, -B/48, B^2/3, -B/160
+    double bk_s1, bk_s2, bk_s3;                        // exact path: 1/(6C), -1/(48C), 1/(480C)
     int32_t all_simple;        // grid mode: every image a tile can keep is provably the fractionally wrapped one (no per-candidate test)
     int32_t _pad2;
 };

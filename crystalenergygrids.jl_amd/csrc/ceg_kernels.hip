@@ -393,7 +393,7 @@ struct __attribute__((aligned(16))) CandRec {
 // position, invmat*d, wrap, mat*f, neighbour search (periodic_distance2_literal) -- and evaluated
 // with the literal radial formulas.  Runs after the hot loop so that its registers do not
 // overlap the hot loop's.
-template <int MODE, bool FASTEW, bool LJSLOW, bool EWSCALED, typename Rec>
+template <int MODE, bool FASTEW, bool LJSLOW, bool EWSCALED, bool BKSCALED, typename Rec>
 __device__ __forceinline__ void slow_pairs(const PlanConst* __restrict__ pc, unsigned long long cands, int lane,
                                            double px, double py, double pz,
                                            const Rec* s_rec,
@@ -417,6 +417,10 @@ __device__ __forceinline__ void slow_pairs(const PlanConst* __restrict__ pc, uns
             vdw_terms<LJSLOW, true>(pc->rt.rules, pc->rt.offset[kd], pc->rt.offset[kd + 1], r2, v, p1, p2, p3);
             if (LJSLOW) {        // the LJ-only hot loop accumulates p1/-6, p2/48, p3/-480 (scaled once per tile at the end)
                 p1 *= -1.0 / 6.0; p2 *= 1.0 / 48.0; p3 *= -1.0 / 480.0;
+            }
+            if (BKSCALED) {      // the single-Buckingham hot loop accumulates v/C, p1/(6C), p2/(-48C), p3/(480C)
+                v *= pc->bk_invC; p1 *= pc->bk_s1; p2 *= pc->bk_s2; p3 *= pc->bk_s3;       // (constants from memory, not literals:
+                                                                                        //  literals get hoisted into VGPRs)
             }
             accum_add(av, v, p1, p2, p3, dx, dy, dz);
         }
@@ -615,6 +619,7 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
     const int by0 = bin_of(bly - rc, 1), by1 = bin_of(bhy + rc, 1);
     const int nry = by1 - by0 + 1;
     const int nrows = active ? (bx1 - bx0 + 1) * nry : 0;
+    const float inv_nry = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(1.0f / (float)nry)));
 
     Accum av, ac;
     accum_zero(av);
@@ -644,14 +649,17 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
     const int bk2_off = BK2 ? __builtin_amdgcn_readfirstlane(-pc->bk2_base * (CEG_BK2_STRIDE * 8)) : 0;
     int bk2_stride = CEG_BK2_STRIDE * 8;
     asm volatile("" : "+v"(bk2_stride));
-    const double bk_B = pc->bk_B, bk_C = pc->bk_C, bk_shift = pc->bk_shift;
+    const double bk_B = pc->bk_B, bk_nshift = pc->bk_nshift, bk_c1 = pc->bk_c1, bk_c2 = pc->bk_c2, bk_c3 = pc->bk_c3, bk_c4 = pc->bk_c4;
 
     for (int rbase = 0; rbase < nrows; rbase += 64) {
         // -- one row per lane: image range [start, start+count)
         int count = 0, start = 0;
         const int r = rbase + lane;
         if (r < nrows) {
-            const int bx = bx0 + r / nry, by = by0 + r % nry;
+            // r / nry without the integer-division sequence (whose per-tile magic number the compiler keeps in a VGPR across the
+            // hot loops): r < 2^12 and nry < 2^7, so (r + 1/2) / nry in float is at least 1/(2 nry) away from an integer
+            const int rq = (int)(((float)r + 0.5f) * inv_nry);
+            const int bx = bx0 + rq, by = by0 + (r - rq * nry);
             const double colx0 = ib.lo[0] + bx * ib.bin[0], colx1 = colx0 + ib.bin[0];
             const double coly0 = ib.lo[1] + by * ib.bin[1], coly1 = coly0 + ib.bin[1];
             const double gx = fmax(0.0, fmax(blx - colx1, colx0 - bhx));
@@ -835,16 +843,19 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
                         g0 = __builtin_fma(g0, tb, g23.x);
                         g0 = __builtin_fma(g0, tb, g01.y);
                         g0 = __builtin_fma(g0, tb, g01.x);
+                        // The table holds G' = G0/C and the channels are accumulated as v/C, p1/(6C), p2/(-48C), p3/(480C): the
+                        // dispersion parts are then bare powers of 1/r^2 and every constant sits in ONE fma per channel
+                        // (factors applied once per tile).  With u = G'/r, w = B G' + u:
+                        //   v/C = G' - y3 - shift/C,  p1/(6C) = y4 - (B/6) u,  p2/(-48C) = y5 - (B/48) w/r^2,
+                        //   p3/(480C) = y6 - (B/160) (w/r^2 + (B^2/3) u)/r^2,     y_n = r^(-2n)
                         const double u = g0 * rinv;
-                        const double inv2 = inv * inv, inv3 = inv2 * inv;
-                        const double x6 = mul_sc(inv3, bk_C);
-                        const double w = fma_vsv(g0, bk_B, u);                 // B G0 + u
+                        const double inv2 = inv * inv, y3 = inv2 * inv;
+                        const double w = fma_vsv(g0, bk_B, u);
                         const double wi = w * inv;
-                        const double Bu = mul_sc(u, bk_B);
-                        v = add_sc(g0 - x6, -bk_shift);
-                        p1 = __builtin_fma(mul_sc(x6, 6.0), inv, -Bu);
-                        p2 = __builtin_fma(mul_sc(x6, -48.0), inv2, mul_sc(wi, bk_B));
-                        p3 = __builtin_fma(mul_sc(x6, 480.0), inv3, -(mul_sc(fma_vsv(Bu, bk_B, 3.0 * wi), bk_B) * inv));
+                        v = add_sc(g0 - y3, bk_nshift);
+                        p1 = fma_vsv(u, bk_c1, y3 * inv);
+                        p2 = fma_vsv(wi, bk_c2, y3 * inv2);
+                        p3 = fma_vsv(fma_vsv(u, bk_c3, wi) * inv, bk_c4, y3 * y3);
                     } else if constexpr (HAS_LJ) {
                       if (VDWK == 2 && (__builtin_amdgcn_readfirstlane(s_rec[q].meta) & META_BUCK)) {
                         // derivativesGrid, Buckingham branch (src/interactions.jl:447-457); a hard
@@ -982,7 +993,7 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
 #endif
             if (slow != 0ull) {
                 __builtin_amdgcn_wave_barrier();
-                slow_pairs<MODE, FASTEW, VDWK == 1, EW2>(pc, slow, lane, px, py, pz, s_rec, s_odd, av, ac, smallest_d2);
+                slow_pairs<MODE, FASTEW, VDWK == 1, EW2, VDWK == 3 && MODE != MODE_COULOMB>(pc, slow, lane, px, py, pz, s_rec, s_odd, av, ac, smallest_d2);
             }
         }
     }
@@ -990,6 +1001,13 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
         av.d1x *= -6.0; av.d1y *= -6.0; av.d1z *= -6.0;
         av.d2xy *= 48.0; av.d2xz *= 48.0; av.d2yz *= 48.0;
         av.d3 *= -480.0;
+    }
+    if (VDWK == 3 && MODE != MODE_COULOMB) {      // constant factors of the single Buckingham class
+        const double C = pc->bk_C;
+        av.v *= C;
+        av.d1x *= 6.0 * C; av.d1y *= 6.0 * C; av.d1z *= 6.0 * C;
+        av.d2xy *= -48.0 * C; av.d2xz *= -48.0 * C; av.d2yz *= -48.0 * C;
+        av.d3 *= 480.0 * C;
     }
     if (EW2) {                                    // constant factors of the B_n recurrence, deferred out of the hot loop
         ac.d2xy *= 3.0; ac.d2xz *= 3.0; ac.d2yz *= 3.0;
