@@ -341,6 +341,14 @@ int build_images(ceg_plan* p)
     const double* M = g.mat;
     const double* I = g.invmat;
     for (int64_t a = 0; a < p->natoms; ++a) {
+        if (p->has_rules && !p->has_charge) {
+            // a VdW-only plan (create_grid_vdw: one probe atom against the framework): atoms whose kind has no rule for the probe
+            // contribute exact zeros (an empty rule run, src/interactions.jl:599-610) -- they need not be staged at all
+            // (Si / Al against Ar or Na in the fixture force field: a third of the framework)
+            const int32_t k = p->h_kind[a];
+            const bool hasvdw = k >= 0 && k + 1 < (int32_t)p->h_offset.size() && p->h_offset[k + 1] > p->h_offset[k];
+            if (!hasvdw) continue;
+        }
         const double pa[3] = {p->h_pos[3 * a], p->h_pos[3 * a + 1], p->h_pos[3 * a + 2]};
         double fmin[3] = {1e300, 1e300, 1e300}, fmax[3] = {-1e300, -1e300, -1e300};
         for (int c = 0; c < 8; ++c) {
