@@ -142,3 +142,54 @@ def test_julia_shim_does_not_strip_units_off_unitless_constants():
     assert 'ustrip(u"K*Å/e_au^2", COULOMBIC_CONVERSION_FACTOR)/GRID_TO_KELVIN' in text      # grids.jl:169
     # unitful fields must be made unitless before they reach a Float64 buffer (ewald.jl:42-44, coordinates.jl:15-23)
     assert "vec(ef.invmat))" not in text and 'NoUnits(ewald.α*u"Å")' in text
+
+
+def test_julia_shim_is_structurally_sound():
+    """No Julia in the image: the least a reader of julia/CEGHip.jl is owed is that it parses at the block level -- brackets balance
+    and every block opener (function / if / for / while / let / do / begin / struct / module / try / quote / macro) outside
+    brackets has its `end` (strings and comments stripped; `end` inside brackets is indexing, `for` / `if` inside brackets a
+    generator)."""
+    src = (Path(__file__).resolve().parent.parent / "crystalenergygrids.jl_amd" / "julia" / "CEGHip.jl").read_text()
+    out, i, n = [], 0, len(src)
+    while i < n:
+        if src.startswith('"""', i):
+            j = src.find('"""', i + 3)
+            assert j >= 0, "unterminated docstring"
+            out.append('""'); i = j + 3
+        elif src[i] == '"':
+            j = i + 1
+            while j < n and src[j] != '"':
+                j += 2 if src[j] == "\\" else 1
+            assert j < n, "unterminated string"
+            out.append('""'); i = j + 1
+        elif src.startswith("#=", i):
+            j = src.find("=#", i + 2)
+            assert j >= 0, "unterminated block comment"
+            i = j + 2
+        elif src[i] == "#":
+            j = src.find("\n", i)
+            i = j if j >= 0 else n
+        else:
+            out.append(src[i]); i += 1
+    text = "".join(out)
+    stack, pairs = [], {")": "(", "]": "[", "}": "{"}
+    for k, c in enumerate(text):
+        if c in "([{":
+            stack.append(c)
+        elif c in ")]}":
+            assert stack and stack[-1] == pairs[c], f"unbalanced {c!r} near: {text[max(0, k - 60):k + 10]!r}"
+            stack.pop()
+    assert not stack
+    opens = ends = depth = 0
+    for m in re.finditer(r"[\[\]\(\)]|\b(function|if|for|while|let|do|begin|struct|module|try|quote|macro|end)\b", text):
+        w = m.group(0)
+        if w in "[(":
+            depth += 1
+        elif w in "])":
+            depth -= 1
+        elif depth == 0:
+            if w == "end":
+                ends += 1
+            else:
+                opens += 1
+    assert opens == ends and opens > 30, (opens, ends)
