@@ -49,6 +49,15 @@ def test_no_device_is_an_error_not_a_fallback():
     assert ei.value.code == -2 and "no HIP device" in str(ei.value)
     with pytest.raises(_abi.CegError):
         G.build_coulomb_array(w.probe_coulomb, w.alpha, w.cset)
+    # the device-resident variants: NULL output rejected before anything else, then the same "no device" error
+    dims, size, shift, delta = G._grid_args(w.cset)
+    pos = np.ascontiguousarray(w.probe_coulomb.positions, dtype=np.float64)
+    q = np.ascontiguousarray(w.probe_coulomb.charges, dtype=np.float64)
+    mat, inv = G._matT(w.probe_coulomb.mat), G._matT(w.probe_coulomb.invmat)
+    common = (_abi.dptr(pos), _abi.dptr(q), len(q), _abi.dptr(mat), _abi.dptr(inv), 0, 1e9, 144.0, w.alpha,
+              _abi.i32ptr(dims), _abi.dptr(size), _abi.dptr(shift), _abi.dptr(delta), 1.0, 1e7)
+    assert lib.ceg_grid_coulomb_device(*common, None, 0, 1) == -1 and b"d_grid" in lib.ceg_last_error()
+    assert lib.ceg_grid_coulomb_device(*common, 4096, 0, 1) == -2 and b"no HIP device" in lib.ceg_last_error()
 
 
 def test_consumer_entry_points_reject_bad_arguments_and_have_no_cpu_path():
