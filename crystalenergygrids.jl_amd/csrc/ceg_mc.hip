@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -148,7 +149,8 @@ __device__ __forceinline__ double2 molecule_sf(const McView& v, const double2* t
 // pair sum, rest = framework + sums[:, 1]
 template <bool FAST, bool INSERT>
 __global__ __launch_bounds__(MC_THREADS) void k_mc_trial(McView v, int32_t molecule, McMolecule nm, const double* __restrict__ trial, int64_t n,
-                                                          double* __restrict__ out, int stride)
+                                                          double* __restrict__ out, int stride, unsigned* done, unsigned long long* flag,
+                                                          unsigned long long seq)
 {
     // dynamic LDS: [m][stride] double2 tables, then (table_in_lds) the pair table
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
@@ -320,6 +322,16 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_trial(McView v, int32_t molec
         o[1] = tot[1];
         o[2] = tot[2];
         o[3] = 2.0 * tot[3] + tot[4];
+        // small batches: the rows sit in mapped host memory and the host polls `flag` instead of going through
+        // hipStreamSynchronize (whose wake-up costs about as much as this kernel); the last workgroup to finish raises it
+        if (flag) {
+            __threadfence_system();
+            if (atomicAdd(done, 1u) == gridDim.x - 1) {
+                *done = 0u;
+                __threadfence_system();
+                __atomic_store_n(flag, seq, __ATOMIC_RELEASE);
+            }
+        }
     }
 }
 
@@ -607,6 +619,10 @@ struct ceg_mc {
     double *h_in = nullptr, *h_out = nullptr, *dm_in = nullptr, *dm_out = nullptr;
     double *d_in = nullptr, *d_out = nullptr;
     size_t d_in_cap = 0, d_out_cap = 0;
+    // completion flag of the mapped-buffer path (polled by the host) and the device-side count of finished workgroups
+    unsigned long long *h_flag = nullptr, *dm_flag = nullptr;
+    unsigned* d_done = nullptr;
+    unsigned long long seq = 0;
 };
 
 namespace {
@@ -684,9 +700,13 @@ extern "C" int ceg_mc_create(ceg_mc_t** handle, int32_t device, ceg_interp_t* co
     ok = ok && hipMemset(h->d_tot, 0, sizeof(double2) * (size_t)(nk > 0 ? nk : 1)) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&h->h_in, MC_MAPPED_BYTES, hipHostMallocMapped) == hipSuccess &&
-         hipHostMalloc((void**)&h->h_out, MC_MAPPED_BYTES, hipHostMallocMapped) == hipSuccess &&
+         hipHostMalloc((void**)&h->h_out, MC_MAPPED_BYTES, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
          hipHostGetDevicePointer((void**)&h->dm_in, h->h_in, 0) == hipSuccess &&
-         hipHostGetDevicePointer((void**)&h->dm_out, h->h_out, 0) == hipSuccess;
+         hipHostGetDevicePointer((void**)&h->dm_out, h->h_out, 0) == hipSuccess &&
+         hipHostMalloc((void**)&h->h_flag, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+         hipHostGetDevicePointer((void**)&h->dm_flag, h->h_flag, 0) == hipSuccess &&
+         hipMalloc((void**)&h->d_done, sizeof(unsigned)) == hipSuccess && hipMemset(h->d_done, 0, sizeof(unsigned)) == hipSuccess;
+    if (ok) *h->h_flag = 0ull;
     if (!ok) {
         ceg_mc_destroy(h);
         return merr(CEG_ERR_HIP, "could not allocate the Monte-Carlo state on the device");
@@ -720,6 +740,8 @@ extern "C" int ceg_mc_destroy(ceg_mc_t* h)
             if (p) (void)hipFree(p);
         if (h->h_in) (void)hipHostFree(h->h_in);
         if (h->h_out) (void)hipHostFree(h->h_out);
+        if (h->h_flag) (void)hipHostFree(h->h_flag);
+        if (h->d_done) (void)hipFree(h->d_done);
     }
     delete h;
     return CEG_OK;
@@ -843,13 +865,27 @@ int run_trial(ceg_mc* h, bool insert, int32_t molecule, const McMolecule& nm, in
     if (tables_bytes(h, m) + table_bytes > 64 * 1024) { v.table_in_lds = 0; table_bytes = 0; }   // pair table from global memory then
     const size_t lds = tables_bytes(h, m) + table_bytes;
     const dim3 grid((unsigned)rows), block(MC_THREADS);
-#define CEG_MC_LAUNCH(F, I) hipLaunchKernelGGL((k_mc_trial<F, I>), grid, block, lds, h->stream, v, molecule, nm, d_in, n, d_out, h->stride)
+    unsigned long long* flag = nullptr;
+    // (only for the latency-bound small batches: with ~1000 workgroups the fences and the shared counter cost more than the wake-up)
+    if (mapped && rows <= 64 && !getenv("CEG_HIP_MC_NO_POLL")) { flag = h->dm_flag; ++h->seq; }
+#define CEG_MC_LAUNCH(F, I) hipLaunchKernelGGL((k_mc_trial<F, I>), grid, block, lds, h->stream, v, molecule, nm, d_in, n, d_out, h->stride, h->d_done, flag, h->seq)
     if (insert) { if (v.fast) CEG_MC_LAUNCH(true, true); else CEG_MC_LAUNCH(false, true); }
     else { if (v.fast) CEG_MC_LAUNCH(true, false); else CEG_MC_LAUNCH(false, false); }
 #undef CEG_MC_LAUNCH
     if (hipGetLastError() != hipSuccess) return merr(CEG_ERR_HIP, "trial kernel launch failed");
     if (!mapped && hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return merr(CEG_ERR_HIP, "D2H failed");
-    if (hipStreamSynchronize(h->stream) != hipSuccess) return merr(CEG_ERR_HIP, "trial kernel failed");
+    bool seen = false;
+    if (flag) {                      // poll the completion flag; after ~20 ms without it fall back to the stream (a failed launch
+                                     // never raises the flag, and hipStreamSynchronize is what reports the error)
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spin = 0;; ++spin) {
+            if (__atomic_load_n(h->h_flag, __ATOMIC_ACQUIRE) == h->seq) { seen = true; break; }
+            if ((spin & 1023u) == 1023u &&
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 20.0) break;
+            __builtin_ia32_pause();
+        }
+    }
+    if (!seen && hipStreamSynchronize(h->stream) != hipSuccess) return merr(CEG_ERR_HIP, "trial kernel failed");
     if (mapped) memcpy(out, h->h_out, out_bytes);
     return CEG_OK;
 }
