@@ -41,6 +41,9 @@ namespace {
 
 constexpr int MC_MAX_ATOMS = 16;
 constexpr int MC_THREADS = 256;
+#ifndef MC_TRIAL_WAVES
+#define MC_TRIAL_WAVES 3          // waves per SIMD asked of the trial kernel (the neighbour-cell code had pushed it to 169 VGPRs = 2 waves)
+#endif
 constexpr int MC_MAX_TAB = 400;                // (kx+1) + (2ky+1) + (2kz+1)
 constexpr size_t MC_MAPPED_BYTES = 1 << 20;    // batches up to this size go through the pinned, device-mapped buffers
 
@@ -147,8 +150,8 @@ __device__ __forceinline__ double2 molecule_sf(const McView& v, const double2* t
 
 // INSERT: the molecule is described by `nm` and is not in the system -- no current-position row, nothing excluded from the
 // pair sum, rest = framework + sums[:, 1]
-template <bool FAST, bool INSERT>
-__global__ __launch_bounds__(MC_THREADS) void k_mc_trial(McView v, int32_t molecule, McMolecule nm, const double* __restrict__ trial, int64_t n,
+template <bool FAST, bool INSERT, bool CELLS>
+__global__ __launch_bounds__(MC_THREADS, MC_TRIAL_WAVES) void k_mc_trial(McView v, int32_t molecule, McMolecule nm, const double* __restrict__ trial, int64_t n,
                                                           double* __restrict__ out, int stride, unsigned* done, unsigned long long* flag,
                                                           unsigned long long seq)
 {
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_trial(McView v, int32_t molec
                 }
             }
         };
-        if (!v.use_cells) {
+        if (!CELLS) {
             for (int l = tid; l < v.natoms; l += MC_THREADS) pairs_with(v.atoms[l]);
         } else {
             // only the cells the cutoff spheres of the molecule's atoms can reach (ceg_consumers.h)
@@ -868,9 +871,15 @@ int run_trial(ceg_mc* h, bool insert, int32_t molecule, const McMolecule& nm, in
     unsigned long long* flag = nullptr;
     // (only for the latency-bound small batches: with ~1000 workgroups the fences and the shared counter cost more than the wake-up)
     if (mapped && rows <= 64 && !getenv("CEG_HIP_MC_NO_POLL")) { flag = h->dm_flag; ++h->seq; }
-#define CEG_MC_LAUNCH(F, I) hipLaunchKernelGGL((k_mc_trial<F, I>), grid, block, lds, h->stream, v, molecule, nm, d_in, n, d_out, h->stride, h->d_done, flag, h->seq)
-    if (insert) { if (v.fast) CEG_MC_LAUNCH(true, true); else CEG_MC_LAUNCH(false, true); }
-    else { if (v.fast) CEG_MC_LAUNCH(true, false); else CEG_MC_LAUNCH(false, false); }
+#define CEG_MC_LAUNCH(F, I, CL) hipLaunchKernelGGL((k_mc_trial<F, I, CL>), grid, block, lds, h->stream, v, molecule, nm, d_in, n, d_out, h->stride, h->d_done, flag, h->seq)
+#define CEG_MC_PICK(CL)                                                                       \
+    do {                                                                                      \
+        if (insert) { if (v.fast) CEG_MC_LAUNCH(true, true, CL); else CEG_MC_LAUNCH(false, true, CL); }   \
+        else { if (v.fast) CEG_MC_LAUNCH(true, false, CL); else CEG_MC_LAUNCH(false, false, CL); }        \
+    } while (0)
+    if (v.use_cells) CEG_MC_PICK(true);
+    else CEG_MC_PICK(false);
+#undef CEG_MC_PICK
 #undef CEG_MC_LAUNCH
     if (hipGetLastError() != hipSuccess) return merr(CEG_ERR_HIP, "trial kernel launch failed");
     if (!mapped && hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return merr(CEG_ERR_HIP, "D2H failed");
