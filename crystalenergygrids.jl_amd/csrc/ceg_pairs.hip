@@ -41,7 +41,7 @@ struct PairsGeom {
 };
 
 template <bool FAST, bool TABLE_IN_LDS, bool CELLS>
-__global__ __launch_bounds__(64 * PAIRS_WAVES) void k_pairs(PairsGeom g, const DevRule* __restrict__ g_rules,
+__global__ __launch_bounds__(64 * PAIRS_WAVES, 3) void k_pairs(PairsGeom g, const DevRule* __restrict__ g_rules,
                                                              const int32_t* __restrict__ g_offset, int32_t nrules,
                                                              const double4* __restrict__ atoms,      // x, y, z, (kind | molecule) bits
                                                              const int32_t* __restrict__ cell_start, // CELLS: atoms sorted by cell, [ncells + 1]
