@@ -50,7 +50,9 @@ def parse_args():
     ap.add_argument("--mode", choices=("fused", "vdw", "coulomb"), default="fused")
     ap.add_argument("--probe", default="Ar", help="probe atom of the VdW grid (Ar: LJ; Na: Buckingham + hard sphere)")
     ap.add_argument("--algo", choices=("auto", "bruteforce", "culled"), default="auto")
-    ap.add_argument("--gather", choices=("staged", "inplace", "p2p"), default="staged", help="how a gathered chunk is placed (N > 1)")
+    ap.add_argument("--gather", choices=("auto", "staged", "inplace", "p2p"), default="auto",
+                    help="how a gathered chunk is placed (N > 1); auto: staged and inplace are each timed on one untimed step and the "
+                         "faster one (max over ranks) is used")
     ap.add_argument("--chunks", type=int, default=8,
                     help="x-chunks per rank pipelined with the all-gather (N > 1); 8 from the exchange model of profiles/r02_rank_emulation.txt")
     ap.add_argument("--n", "--dims", dest="n", type=int, default=255, help="dims per axis (odd); grid has (n+1)^3 points")
@@ -201,8 +203,13 @@ def main():
 
     fulls = [t for t in (full_v, full_c) if t is not None]
     locs = [t for t in (loc_v, loc_c) if t is not None]
-    pipe = PipelinedGather(cyc, fulls, locs, mode=args.gather, force_collectives=args.force_exchange,
-                           joint=joint if cyc is not None and multi else None) if cyc is not None else None
+    gather_mode, autotune = args.gather, None
+
+    def make_pipe(mode):
+        return PipelinedGather(cyc, fulls, locs, mode=mode, force_collectives=args.force_exchange,
+                               joint=joint if cyc is not None and multi else None)
+
+    pipe = make_pipe("staged" if args.gather == "auto" else args.gather) if cyc is not None else None
 
     def launch_chunk(j, ib, ie, blocks):
         it = iter(blocks)
@@ -224,6 +231,28 @@ def main():
                 for full, loc in zip(fulls, locs):
                     allgather_grid(full, loc)
 
+    if pipe is not None and args.gather == "auto" and pipe.exchange:
+        # pick the placement of the gathered chunks on THIS node: one untimed step each (after one to warm the communicator up),
+        # max over the ranks; both candidates are plain all_gather_into_tensor calls (no point-to-point schedule to get wrong)
+        autotune = {}
+        step()
+        for mode in ("staged", "inplace"):
+            pipe = make_pipe(mode)
+            step()
+            torch.cuda.synchronize()
+            if multi and world > 1:
+                dist.barrier()
+            t_a = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            t = torch.tensor([time.perf_counter() - t_a], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            autotune[mode] = float(t[0]) * 1e3
+        gather_mode = min(autotune, key=autotune.get)
+        pipe = make_pipe(gather_mode)
+    elif args.gather == "auto":
+        gather_mode = "staged"
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -324,7 +353,7 @@ def main():
             "config": {"workload": w.name, "grid_points": npts, "framework_atoms": w.natoms,
                        "lattice_images": plan.num_images, "grids_per_step": ngrids, "mode": args.mode,
                        "algo": "culled" if (algo != _abi.ALGO_BRUTEFORCE and plan.can_cull) else "bruteforce",
-                       "parallelism": (f"block-cyclic x-chunks over {world} GPUs ({cyc.nchunks} chunks of {cyc.m} planes per rank), each chunk all-gathered over {transport} ({args.gather}) while the next is computed" if cyc is not None
+                       "parallelism": (f"block-cyclic x-chunks over {world} GPUs ({cyc.nchunks} chunks of {cyc.m} planes per rank), each chunk all-gathered over {transport} ({gather_mode}) while the next is computed" if cyc is not None
                                        else f"x-slab sharding over {world} GPU(s)" + (f", {transport} all-gather of slabs" if world > 1 else ""))},
             # neither HBM nor MFMA bounds this path (FP64 vector ALU does); `roofline` is the binding
             # one -- minimum-work flops / t against the FP64 vector peak -- and the HBM view sits alongside
@@ -353,7 +382,7 @@ def main():
         if multi:
             # gather time reported separately.  compute_ms = span of this rank's kernels
             # (max over ranks); what is left of the step is the part of the exchange that was not hidden
-            out["exchange"] = {"compute_ms": kern_ms, "exposed_ms": max(0.0, ms - kern_ms), "mode": args.gather if cyc is not None else "slab",
+            out["exchange"] = {"compute_ms": kern_ms, "exposed_ms": max(0.0, ms - kern_ms), "mode": gather_mode if cyc is not None else "slab", "autotune_ms": autotune,
                                "bytes_gathered_per_rank": 32.0 * npts * ngrids * (world - 1) / world, "backend": "nccl (RCCL over xGMI)" if args.backend == "nccl" else "gloo (rehearsal)"}
         if world == 1 and args.cpu_rows != 0:
             out["cpu_baseline"] = cpu_baseline(w, args.mode, args.cpu_rows)
