@@ -179,12 +179,16 @@ def main():
     # full grids live on every rank (that is what the gather produces); rank-local buffers
     full_v = torch.empty((8, nx, ny, nz), dtype=torch.float32, device=dev) if need_v else None
     full_c = torch.empty((8, nx, ny, nz), dtype=torch.float32, device=dev) if need_c else None
+    joint = None
+
+    def cyclic_buffers(c):     # one compact [8, m, ny, nz] block per chunk and grid, the grids of a chunk adjacent (one collective)
+        jt = torch.empty((c.nchunks, int(need_v) + int(need_c), 8, c.m, ny, nz), dtype=torch.float32, device=dev)
+        return jt, (jt[:, 0] if need_v else None), (jt[:, 1 if need_v else 0] if need_c else None)
+
     if not multi:
         loc_v, loc_c = full_v, full_c
-    elif cyc is not None:      # one compact [8, m, ny, nz] block per chunk and grid, the grids of a chunk adjacent (one collective)
-        joint = torch.empty((cyc.nchunks, int(need_v) + int(need_c), 8, cyc.m, ny, nz), dtype=torch.float32, device=dev)
-        loc_v = joint[:, 0] if need_v else None
-        loc_c = joint[:, 1 if need_v else 0] if need_c else None
+    elif cyc is not None:
+        joint, loc_v, loc_c = cyclic_buffers(cyc)
     else:
         loc_v = torch.empty((8, n_local, ny, nz), dtype=torch.float32, device=dev) if need_v else None
         loc_c = torch.empty((8, n_local, ny, nz), dtype=torch.float32, device=dev) if need_c else None
@@ -232,25 +236,41 @@ def main():
                     allgather_grid(full, loc)
 
     if pipe is not None and args.gather == "auto" and pipe.exchange:
-        # pick the placement of the gathered chunks on THIS node: one untimed step each (after one to warm the communicator up),
-        # max over the ranks; both candidates are plain all_gather_into_tensor calls (no point-to-point schedule to get wrong)
+        # pick, on THIS node, the number of chunks per rank and the placement of the gathered chunks: two untimed steps per
+        # candidate (the first warms it up), max over the ranks.  Fewer chunks = fewer, larger collectives and launches but a
+        # longer exposed first / last chunk; which side wins depends on the collective's launch latency, which only a real
+        # run on the links shows.  Both placements are plain all_gather_into_tensor calls (no point-to-point schedule).
         autotune = {}
         step()
-        for mode in ("staged", "inplace"):
-            pipe = make_pipe(mode)
-            step()
-            torch.cuda.synchronize()
-            if multi and world > 1:
-                dist.barrier()
-            t_a = time.perf_counter()
-            step()
-            torch.cuda.synchronize()
-            t = torch.tensor([time.perf_counter() - t_a], dtype=torch.float64, device=dev)
-            if world > 1:
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            autotune[mode] = float(t[0]) * 1e3
-        gather_mode = min(autotune, key=autotune.get)
+        tried = []
+        for nch in sorted({args.chunks, max(1, args.chunks // 2), max(1, args.chunks // 4)}, reverse=True):
+            cand = cyclic_plan(nx, world, rank, nchunks=nch)
+            if cand is None or cand.nchunks in tried:
+                continue
+            tried.append(cand.nchunks)
+            cyc = cand
+            joint, loc_v, loc_c = cyclic_buffers(cyc)
+            locs = [t for t in (loc_v, loc_c) if t is not None]
+            for mode in ("staged", "inplace"):
+                pipe = make_pipe(mode)
+                step()
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                t_a = time.perf_counter()
+                step()
+                torch.cuda.synchronize()
+                t = torch.tensor([time.perf_counter() - t_a], dtype=torch.float64, device=dev)
+                if world > 1:
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                autotune[f"{cyc.nchunks} chunks, {mode}"] = float(t[0]) * 1e3
+        best = min(autotune, key=autotune.get)
+        cyc = cyclic_plan(nx, world, rank, nchunks=int(best.split()[0]))
+        gather_mode = best.split(", ")[1]
+        joint, loc_v, loc_c = cyclic_buffers(cyc)
+        locs = [t for t in (loc_v, loc_c) if t is not None]
         pipe = make_pipe(gather_mode)
+        n_local = cyc.n_local
     elif args.gather == "auto":
         gather_mode = "staged"
     for _ in range(args.warmup):
