@@ -22,8 +22,9 @@ with open(out + "/summary.csv", "w") as fh:
         spans.sort()
         drop = 0
         if "k_culled" in name or "k_bruteforce" in name:
-            per_step = max(1, len(spans) // (warm + steps))
-            drop = warm * per_step
+            prewarm = 3                                   # bench.py's PREWARM_STEPS (untimed set-up launches)
+            per_step = max(1, len(spans) // (prewarm + warm + steps))
+            drop = (prewarm + warm) * per_step
         d = [(e - s) / 1e6 for s, e in spans[drop:]]
         if not d:
             continue
