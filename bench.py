@@ -51,9 +51,11 @@ def parse_args():
     ap.add_argument("--mode", choices=("fused", "vdw", "coulomb"), default="fused")
     ap.add_argument("--probe", default="Ar", help="probe atom of the VdW grid (Ar: LJ; Na: Buckingham + hard sphere)")
     ap.add_argument("--algo", choices=("auto", "bruteforce", "culled"), default="auto")
-    ap.add_argument("--gather", choices=("auto", "staged", "inplace", "p2p"), default="auto",
-                    help="how a gathered chunk is placed (N > 1); auto: staged and inplace are each timed on one untimed step and the "
-                         "faster one (max over ranks) is used")
+    ap.add_argument("--gather", choices=("auto", "staged", "inplace", "p2p"), default="staged",
+                    help="how a gathered chunk is placed (N > 1).  staged (default): one all_gather_into_tensor per chunk + one placement "
+                         "copy, --chunks as given -- the path every rehearsal has exercised.  auto: opt-in autotune over --chunks, half "
+                         "and a quarter of it x {staged, inplace}; a candidate that raises is skipped, the default always takes part "
+                         "(CEG_BENCH_NO_AUTOTUNE=1 turns auto back into staged)")
     ap.add_argument("--chunks", type=int, default=8,
                     help="x-chunks per rank pipelined with the all-gather (N > 1); 8 from the exchange model of profiles/r02_rank_emulation.txt")
     ap.add_argument("--n", "--dims", dest="n", type=int, default=255, help="dims per axis (odd); grid has (n+1)^3 points")
@@ -65,6 +67,45 @@ def parse_args():
     ap.add_argument("--force-exchange", action="store_true",
                     help="N = 1 only: run the N > 1 code path (RCCL group of one rank, chunked build, collectives issued) -- a rehearsal")
     return ap.parse_args()
+
+
+def csrc_sha256() -> str:
+    """Identity of the kernel sources the library was built from (same recipe as scripts/pmc.sh)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = ROOT / "crystalenergygrids.jl_amd" / "csrc"
+    for fn in sorted(os.listdir(csrc)):
+        if fn.endswith((".hip", ".h")) or fn == "Makefile":
+            h.update(fn.encode())
+            h.update((csrc / fn).read_bytes())
+    return h.hexdigest()
+
+
+def load_pmc_record(key: str):
+    """PMC-derived figures of `key` = mode/probe/n/world from profiles/pmc_summary.json, with their provenance; None if the file has
+    no record for this configuration.  A record taken on OTHER kernel sources is returned with only its provenance and
+    "stale": true -- none of its numbers is used."""
+    prof = ROOT / "profiles" / "pmc_summary.json"
+    try:
+        rec = json.loads(prof.read_text()).get(key)
+    except Exception:
+        return None
+    if not rec:
+        return None
+    out = {"source": "profiles/pmc_summary.json", "key": key, "collected_by": rec.get("command"), "host": rec.get("host"),
+           "csrc_sha256": rec.get("csrc_sha256"), "raw_summary": rec.get("source"),
+           "note": "separate rocprofv3 --pmc passes of the same bench command on another run (and possibly another box); timed launches only"}
+    if rec.get("csrc_sha256") != csrc_sha256():
+        out["stale"] = True
+        out["note"] = "profiles/pmc_summary.json was collected on different kernel sources: its numbers are not used"
+        return out
+    out["stale"] = False
+    for k in ("hbm_bytes_per_launch", "valu_issue_util", "lane_util", "frac_issue", "fp64_flops_per_launch", "fp64_insts_per_launch",
+              "fma_share_of_fp64_insts", "gpu_cycles_per_launch", "kernel_ms_in_profile", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64",
+              "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_LDS"):
+        if k in rec:
+            out[k] = rec[k]
+    return out
 
 
 def cpu_baseline(w, mode: str, rows: int):
@@ -158,7 +199,7 @@ def main():
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
     from ceg_hip import _abi, workloads as W
-    from ceg_hip.distributed import PipelinedGather, allgather_grid, cyclic_plan, slab_range
+    from ceg_hip.distributed import PipelinedGather, allgather_grid, autotune_exchange, cyclic_plan, slab_range
     from ceg_hip.plan import GridPlan
 
     w = W.roofline_workload(args.probe, args.n)
@@ -236,42 +277,45 @@ def main():
                 for full, loc in zip(fulls, locs):
                     allgather_grid(full, loc)
 
-    if pipe is not None and args.gather == "auto" and pipe.exchange:
-        # pick, on THIS node, the number of chunks per rank and the placement of the gathered chunks: two untimed steps per
-        # candidate (the first warms it up), max over the ranks.  Fewer chunks = fewer, larger collectives and launches but a
-        # longer exposed first / last chunk; which side wins depends on the collective's launch latency, which only a real
-        # run on the links shows.  Both placements are plain all_gather_into_tensor calls (no point-to-point schedule).
-        autotune = {}
-        step()
-        tried = []
+    want_autotune = args.gather == "auto" and os.environ.get("CEG_BENCH_NO_AUTOTUNE", "0") in ("", "0")
+    if pipe is not None and want_autotune and pipe.exchange:
+        # Opt-in: pick, on THIS node, the number of chunks per rank and the placement of the gathered chunks.  Fewer chunks =
+        # fewer, larger collectives and launches but a longer exposed first / last chunk; which side wins depends on the
+        # collective's launch latency, which only a real run on the links shows.  Every candidate runs after the clock ramp
+        # (PREWARM_STEPS), is timed over 3 steps (median, max over ranks) after one step of its own, and is dropped -- on all
+        # ranks -- if it raises anywhere (ceg_hip.distributed.autotune_exchange); the default (staged, --chunks) is the first
+        # candidate and the fallback.
+        for _ in range(PREWARM_STEPS):
+            step()
+        default_cfg = (cyc.nchunks, "staged")
+        cands = {}
         for nch in sorted({args.chunks, max(1, args.chunks // 2), max(1, args.chunks // 4)}, reverse=True):
             cand = cyclic_plan(nx, world, rank, nchunks=nch)
-            if cand is None or cand.nchunks in tried:
-                continue
-            tried.append(cand.nchunks)
-            cyc = cand
+            if cand is not None:
+                for mode in ("staged", "inplace"):
+                    cands.setdefault(f"{cand.nchunks} chunks, {mode}", (cand, mode))
+
+        def use(cfg_plan, mode):
+            nonlocal cyc, joint, loc_v, loc_c, locs, pipe, n_local
+            cyc = cfg_plan
             joint, loc_v, loc_c = cyclic_buffers(cyc)
             locs = [t for t in (loc_v, loc_c) if t is not None]
-            for mode in ("staged", "inplace"):
-                pipe = make_pipe(mode)
-                step()
-                torch.cuda.synchronize()
-                if world > 1:
-                    dist.barrier()
-                t_a = time.perf_counter()
-                step()
-                torch.cuda.synchronize()
-                t = torch.tensor([time.perf_counter() - t_a], dtype=torch.float64, device=dev)
-                if world > 1:
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                autotune[f"{cyc.nchunks} chunks, {mode}"] = float(t[0]) * 1e3
-        best = min(autotune, key=autotune.get)
-        cyc = cyclic_plan(nx, world, rank, nchunks=int(best.split()[0]))
-        gather_mode = best.split(", ")[1]
-        joint, loc_v, loc_c = cyclic_buffers(cyc)
-        locs = [t for t in (loc_v, loc_c) if t is not None]
-        pipe = make_pipe(gather_mode)
-        n_local = cyc.n_local
+            pipe = make_pipe(mode)
+            n_local = cyc.n_local
+
+        def setup_candidate(label):
+            if os.environ.get("CEG_BENCH_FAIL_CANDIDATE") == label:        # test hook: a candidate that raises
+                raise RuntimeError("injected failure (CEG_BENCH_FAIL_CANDIDATE)")
+            use(*cands[label])
+
+        best, autotune = autotune_exchange(list(cands), setup_candidate, step, torch.cuda.synchronize, dev)
+        if best is None:
+            print("[bench] autotune: no candidate completed; using the default", file=sys.stderr)
+            use(cyclic_plan(nx, world, rank, nchunks=default_cfg[0]), default_cfg[1])
+            gather_mode = default_cfg[1]
+        else:
+            use(*cands[best])
+            gather_mode = cands[best][1]
     elif args.gather == "auto":
         gather_mode = "staged"
     # (the first launches after the set-up phase run below the steady clock: 16-18, 14.1, 13.6 then 13.4 ms on an idle card,
@@ -300,6 +344,7 @@ def main():
 
     # built-in spot check against the oracle (a block of this rank's result), after timing
     check = None
+    selfcheck_failed = False
     if not args.no_check and rank == 0:
         from oracle import oracle as O
         from oracle.compare import compare_grids
@@ -322,19 +367,29 @@ def main():
                 runs[-1][1] = i + 1
             else:
                 runs.append([i, i + 1])
-        worst = 0.0
+        worst, failures = 0.0, []
         scratch = np.empty((8, nx, ny, nz), dtype=np.float32)
         for i0, i1 in runs:
-            if need_v:
-                lam, thr = G.vdw_scaling()
-                ref, _ = O.grid_vdw(w.probe_vdw, w.cset, lam, thr, i0, i1, j_begin=j0, j_end=j1, out=scratch)
-                worst = max(worst, compare_grids(full_v[:, i0:i1, j0:j1].cpu().numpy(), ref[:, i0:i1, j0:j1], f"bench/vdw planes {i0}:{i1}"))
-            if need_c:
-                lam, thr = G.coulomb_scaling()
-                ref, _ = O.grid_coulomb(w.probe_coulomb, w.alpha, w.cset, lam, thr, i0, i1, j_begin=j0, j_end=j1, out=scratch)
-                worst = max(worst, compare_grids(full_c[:, i0:i1, j0:j1].cpu().numpy(), ref[:, i0:i1, j0:j1], f"bench/coulomb planes {i0}:{i1}"))
+            for need, full, what in ((need_v, full_v, "vdw"), (need_c, full_c, "coulomb")):
+                if not need:
+                    continue
+                if what == "vdw":
+                    lam, thr = G.vdw_scaling()
+                    ref, _ = O.grid_vdw(w.probe_vdw, w.cset, lam, thr, i0, i1, j_begin=j0, j_end=j1, out=scratch)
+                else:
+                    lam, thr = G.coulomb_scaling()
+                    ref, _ = O.grid_coulomb(w.probe_coulomb, w.alpha, w.cset, lam, thr, i0, i1, j_begin=j0, j_end=j1, out=scratch)
+                try:       # a mismatch in ANY rank's block is recorded, the line is still printed and the process exits non-zero
+                    worst = max(worst, compare_grids(full[:, i0:i1, j0:j1].cpu().numpy(), ref[:, i0:i1, j0:j1], f"bench/{what} planes {i0}:{i1}"))
+                except AssertionError as exc:
+                    failures.append(str(exc))
         i0, i1 = 0, len(planes)
-        check = {"points": (i1 - i0) * (j1 - j0) * nz, "x_planes": planes, "max_rel_err": worst, "tol": 1e-6}
+        check = {"points": (i1 - i0) * (j1 - j0) * nz, "x_planes": planes, "max_rel_err": worst, "tol": 1e-6,
+                 "ok": not failures}
+        if failures:
+            check["failures"] = failures[:8]
+            selfcheck_failed = True
+            print("[bench] SELFCHECK FAILED: " + " | ".join(failures[:8]), file=sys.stderr)
 
     if rank == 0:
         ms = elapsed / max(args.steps, 1) * 1e3
@@ -356,19 +411,32 @@ def main():
         min_flops = slab_pts * per_point
         survey_flops = slab_pts * 310.0 * ((F_DIST_SURVEY + F_LJ if need_v else 0.0) + (F_DIST_SURVEY + F_EWALD if need_c else 0.0)
                                            - (F_DIST_SURVEY if (need_v and need_c) else 0.0))
-        tflops = min_flops / (kern_ms * 1e-3) / 1e12
-        # PMC-derived figures of the same command (separate rocprofv3 --pmc passes, scripts/pmc.sh -> profiles/pmc_summary.json)
-        traffic = valu_issue = lane_util = None
+        nominal_tflops = min_flops / (kern_ms * 1e-3) / 1e12
+        # Executed work, convention-free: FP64 VALU instructions of one launch by class (rocprofv3 PMC passes of this very command,
+        # scripts/pmc.sh -> profiles/pmc_summary.json) -> flops = (ADD + MUL + TRANS + 2 FMA) x 64 lanes x measured lane
+        # utilisation.  The instruction counts of a launch are a property of (library, workload), not of the box or the run, so they
+        # may be divided by the kernel time measured HERE; the record is only used when it was taken on this library (sha256 of
+        # the kernel sources).  Everything that comes from that file sits under "pmc" with its provenance.
         pmc_key = f"{args.mode}/{args.probe}/{args.n}/{world}"
-        prof = ROOT / "profiles" / "pmc_summary.json"
-        if prof.exists():
-            try:
-                rec = json.loads(prof.read_text()).get(pmc_key) or {}
-                traffic = rec.get("hbm_bytes_per_launch")
-                valu_issue = rec.get("valu_issue_util")
-                lane_util = rec.get("lane_util")
-            except Exception:
-                pass
+        pmc = load_pmc_record(pmc_key)
+        if (pmc is None or pmc.get("stale")) and world > 1:
+            # no profile of the N-rank run: the one-GPU record of the same workload, its per-launch totals scaled to this rank's
+            # share of the x-planes (every rank runs the same kernel on 1/N of the planes)
+            one = load_pmc_record(f"{args.mode}/{args.probe}/{args.n}/1")
+            if one and not one.get("stale"):
+                share = n_local / float(nx)
+                for k in ("hbm_bytes_per_launch", "fp64_flops_per_launch", "fp64_insts_per_launch", "gpu_cycles_per_launch"):
+                    if k in one:
+                        one[k] = one[k] * share
+                one["scaled_from"] = f"{args.mode}/{args.probe}/{args.n}/1 x {share:.4f} (this rank's share of the x-planes; per STEP, i.e. over all its chunk launches)"
+                one.pop("kernel_ms_in_profile", None)
+                pmc = one
+        traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
+        exec_flops = pmc.get("fp64_flops_per_launch") if pmc else None
+        exec_tflops = exec_flops / (kern_ms * 1e-3) / 1e12 if exec_flops else None
+        frac_issue = pmc.get("frac_issue") if pmc else None
+        eff_clock = (pmc["gpu_cycles_per_launch"] / (pmc["kernel_ms_in_profile"] * 1e-3) / 1e9
+                     if pmc and pmc.get("gpu_cycles_per_launch") and pmc.get("kernel_ms_in_profile") else None)
         transport = "RCCL" if args.backend == "nccl" else "gloo (rehearsal)"
         out = {
             "metric": "grid-points/sec", "value": value, "unit": "grid-points/s",
@@ -382,26 +450,37 @@ def main():
                                        else f"x-slab sharding over {world} GPU(s)" + (f", {transport} all-gather of slabs" if world > 1 else ""))},
             # neither HBM nor MFMA bounds this path (FP64 vector ALU does); `roofline` is the binding
             # one -- minimum-work flops / t against the FP64 vector peak -- and the HBM view sits alongside
-            "roofline": {"bound": "valu_fp64", "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tflops / FP64_VALU_PEAK_TFLOPS, "traffic": traffic,
+            "roofline": {"bound": "valu_fp64", "achieved": exec_tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (exec_tflops / FP64_VALU_PEAK_TFLOPS) if exec_tflops else None, "traffic": traffic,
+                         "frac_executed": (exec_tflops / FP64_VALU_PEAK_TFLOPS) if exec_tflops else None,
+                         "frac_issue": frac_issue,
+                         "frac_nominal": nominal_tflops / FP64_VALU_PEAK_TFLOPS,
                          "kernel": f"k_culled<{args.mode}>" if plan.can_cull and algo != _abi.ALGO_BRUTEFORCE else f"k_bruteforce<{args.mode}>",
-                         "kernel_ms": kern_ms, "launches_per_step": nlaunch, "algorithmic_flops": min_flops,
-                         "counted_work": dict(pw, flops_per_point=per_point, f_dist=F_DIST, f_lj=F_LJ, f_buckingham=F_BUCK, f_ewald=F_EWALD),
-                         "valu_issue_util": valu_issue, "lane_util": lane_util, "pmc_key": pmc_key,
-                         "frac_survey_convention": survey_flops / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                         "kernel_ms": kern_ms, "launches_per_step": nlaunch,
+                         "executed_fp64_flops_per_launch": exec_flops, "effective_clock_ghz_in_profile": eff_clock,
+                         "pmc": pmc,
+                         "nominal": {"achieved": nominal_tflops, "algorithmic_flops": min_flops,
+                                     "counted_work": dict(pw, flops_per_point=per_point, f_dist=F_DIST, f_lj=F_LJ, f_buckingham=F_BUCK, f_ewald=F_EWALD),
+                                     "frac_survey_convention": survey_flops / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                                     "note": "counted minimum work in SURVEY 8d's nominal flops (LJ 50, Buckingham 95, Ewald 140 incl. exp = 20, "
+                                             "erfc = 40; distance from an image list 8): a work RATE for comparing algorithms, not a hardware "
+                                             "fraction -- the kernel evaluates r^2-indexed tables and executes far fewer flops per pair"},
                          "pair_checks_per_s": slab_pts * float(w.natoms) / (kern_ms * 1e-3),
-                         "flops": "counted minimum work: sampled grid points x (in-cutoff images x 8 [distance from an image list] + images with a "
-                                  "VdW rule x 50 LJ | 95 Buckingham + in-cutoff images x 140 real-space Ewald), nominal convention of SURVEY 8d "
-                                  "(exp = 20, erfc = 40 flops); frac_survey_convention = round 1's 310 neighbours x (47 + 50 + 140) for continuity; "
-                                  "valu_issue_util / lane_util = PMC counters of the same command (profiles/pmc_summary.json); "
-                                  "peak = 256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz (FP64 MFMA has the same peak on MI355X; no MFMA is used)",
+                         "flops": "frac = frac_executed = executed FP64 flops of one launch (PMC: (ADD_F64 + MUL_F64 + TRANS_F64 + 2 FMA_F64) x 64 x "
+                                  "lane utilisation, instruction counts of THIS library on THIS workload from profiles/pmc_summary.json) / kernel "
+                                  "time measured in this run / peak; frac_issue = VALU issue utilisation x lane utilisation of the profiled "
+                                  "run (share of lane-issue slots doing work); frac_nominal = counted minimum work in nominal flops / time / peak "
+                                  "(round 2's headline; kept for continuity); peak = 256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz "
+                                  "(FP64 MFMA has the same peak on MI355X; no MFMA is used)",
                          "note": "the contract's bound enum is hbm|mfma; this path is an FP64 pairwise reduction bound by the vector ALU "
                                  "(>= 1e3 flop per compulsory HBM byte), see roofline_hbm for the byte view"},
             "roofline_hbm": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": alg_bytes,
                              "measured_GBps": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
+                             "traffic_source": (pmc or {}).get("source"),
                              "note": "algorithmic bytes (32 B/point/grid written once + 36 B/image) over the kernel time; ~1 % by construction; "
-                                     "measured_GBps = PMC traffic (WRITE_SIZE + 2 x FETCH_SIZE, profiles/pmc_summary.json) over the same time"},
+                                     "measured_GBps = PMC traffic of the profiled run (WRITE_SIZE + 2 x FETCH_SIZE, profiles/pmc_summary.json) "
+                                     "over this run's kernel time"},
             "selfcheck": check,
         }
         if multi:
@@ -416,6 +495,8 @@ def main():
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+    if selfcheck_failed:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

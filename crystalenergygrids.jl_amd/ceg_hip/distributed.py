@@ -23,8 +23,11 @@ in the CPU tests).
 from __future__ import annotations
 
 import contextlib
+import statistics
+import sys
+import time
 from dataclasses import dataclass
-from typing import Callable, List, Optional, Tuple
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -227,3 +230,63 @@ class PipelinedGather:
                 self._gather_chunk(j)
         if self.comm_stream is not None and self.exchange:
             cur.wait_stream(self.comm_stream)
+
+
+def autotune_exchange(labels: Sequence[str], setup: Callable[[str], None], step: Callable[[], None],
+                      sync: Callable[[], None], device: torch.device, timed_steps: int = 3, group=None,
+                      log: Callable[[str], None] = lambda m: print(m, file=sys.stderr)) -> Tuple[Optional[str], Dict[str, Optional[float]]]:
+    """Time every exchange configuration in ``labels`` on this node and return ``(best, {label: ms or None})``.
+
+    ``setup(label)`` builds the buffers / pipeline of a candidate, ``step()`` runs one full step with it, ``sync()`` drains the
+    device.  A candidate goes through three stages -- set-up, one untimed step, ``timed_steps`` timed steps (median, MAX over
+    the ranks) -- and after each stage the ranks agree (all-reduce MIN of an ok flag) whether to go on: a candidate that raises
+    on ANY rank is dropped on ALL of them (``None`` in the result), so no rank is left inside a collective the failed rank will
+    never join and every rank ends with the same choice.  ``best`` is ``None`` when nothing completed: the caller keeps its
+    default.  (A candidate that hangs instead of raising cannot be rescued from inside the process; the benchmark's default does
+    not autotune for that reason.)"""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def agree(ok: bool) -> bool:
+        if world == 1:
+            return ok
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return bool(t[0] > 0.5)
+
+    def timed() -> float:
+        ts = []
+        for _ in range(timed_steps):
+            sync()
+            if world > 1:
+                dist.barrier(group=group)
+            t0 = time.perf_counter()
+            step()
+            sync()
+            ts.append(time.perf_counter() - t0)
+        t = torch.tensor([statistics.median(ts)], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        return float(t[0]) * 1e3
+
+    results: Dict[str, Optional[float]] = {}
+    for label in labels:
+        ok, ms = True, None
+        for stage in ("setup", "first step", "timed steps"):
+            try:
+                if stage == "setup":
+                    setup(label)
+                elif stage == "first step":
+                    step()
+                    sync()
+                else:
+                    ms = timed()
+            except Exception as exc:          # noqa: BLE001 -- any failure disqualifies the candidate, nothing else
+                ok = False
+                log(f"[autotune] candidate '{label}' failed at '{stage}' on rank {rank}: {exc!r}")
+            ok = agree(ok)
+            if not ok:
+                break
+        results[label] = ms if ok else None
+    done = {k: v for k, v in results.items() if v is not None}
+    return (min(done, key=done.get) if done else None), results

@@ -528,9 +528,9 @@ bool build_ew2_table_uncached(double alpha, double r_exact2, double cutoff2, std
     auto B0 = [&](long double s) { const long double r = sqrtl(s); return which == 0 ? erfcl(a * r) / r : (long double)bkA * expl(-a * r); };
     auto Cf = [&](long double s) { return ka * expl(-a * a * s); };
     const int nf = which == 0 ? 2 : 1, stride = which == 0 ? CEG_EW2_STRIDE : CEG_BK2_STRIDE;
-    const int ND = which == 0 ? 7 : 6;                     // coefficients per polynomial: degree 6 (Ewald pair, 14 doubles) / degree 5
+    const int ND = which == 0 ? 7 : CEG_BK2_STRIDE;        // coefficients per polynomial: degree 6 (Ewald pair, 14 doubles) / degree 7
     const long double PI = 3.14159265358979323846264338327950288L;
-    long double node[7];
+    long double node[8];
     for (int k = 0; k < ND; ++k) node[k] = cosl(PI * (k + 0.5L) / (long double)ND);       // u in [-1, 1]
     tab.assign((size_t)ni * stride, 0.0);
     double worst = 0.0;
@@ -542,7 +542,7 @@ bool build_ew2_table_uncached(double alpha, double r_exact2, double cutoff2, std
         memcpy(&s_lo, &lo_bits, 8); memcpy(&s_mid, &mid_bits, 8); memcpy(&s_hi, &hi_bits, 8);
         const long double hh = 0.5L * ((long double)s_hi - (long double)s_lo);           // half width; s_mid is the exact centre
         for (int f = 0; f < nf; ++f) {
-            long double V[7][8];
+            long double V[8][9];
             for (int r = 0; r < ND; ++r) {
                 long double pw = 1.0L;
                 for (int c = 0; c < ND; ++c) { V[r][c] = pw; pw *= node[r]; }
@@ -561,7 +561,7 @@ bool build_ew2_table_uncached(double alpha, double r_exact2, double cutoff2, std
                 }
             }
             // P(u), u = (t - hh)/hh with t = s - s_lo  ->  coefficients in t (binomial expansion in long double)
-            long double cu[7], ct[7] = {0, 0, 0, 0, 0, 0, 0};
+            long double cu[8], ct[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             long double sc = 1.0L;
             for (int c = 0; c < ND; ++c) { cu[c] = V[c][ND] * sc; sc /= hh; }             // in (t - hh)
             for (int c = 0; c < ND; ++c) {                                                 // (t - hh)^c = sum_k C(c,k) t^k (-hh)^(c-k)
@@ -616,7 +616,7 @@ bool build_bk2_table(double A, double B, double C, double r_exact2, double cutof
     if (!(memo.valid && memo.A == A && memo.B == B && memo.C == C && memo.r_exact2 == r_exact2 && memo.cutoff2 == cutoff2)) {
         memo.tab.clear();
         double worst = 0.0;
-        memo.ok = build_ew2_table_uncached(B, r_exact2, cutoff2, memo.tab, &memo.base, &memo.ni, &worst, 1, A, C) && worst < 2e-12;
+        memo.ok = build_ew2_table_uncached(B, r_exact2, cutoff2, memo.tab, &memo.base, &memo.ni, &worst, 1, A, C) && worst < CEG_BK2_TOL;
         memo.A = A; memo.B = B; memo.C = C; memo.r_exact2 = r_exact2; memo.cutoff2 = cutoff2; memo.valid = true;
         if (std::getenv("CEG_HIP_TRACE"))
             fprintf(stderr, "[ceg_hip] r^2-indexed Buckingham table: %d intervals, worst error %.2e of the pair energy -> %s\n", memo.ni, worst,
@@ -739,7 +739,9 @@ extern "C" int ceg_plan_create(ceg_plan_t** plan, int32_t device,
         hc.r_exact2 = p->r_exact2;
         {   // |f_k(centre - image)| <= |row_k(invmat)| (reach of a kept image from the tile centre) for every image a 4x4x4 tile can
             // keep; if that plus the fractional half-extent of the tile stays below 1/2 on all three axes the kernel skips the test
-            const double hx = 1.5 * delta[0], hy = 1.5 * delta[1], hz = 1.5 * delta[2];
+            // (the tile's extent follows from size / dims, which is what grid_coord steps by -- NOT from the caller's `delta`, which
+            // only scales the derivative channels, grids.jl:126-133, and may be anything)
+            const double hx = 1.5 * size[0] / dims[0], hy = 1.5 * size[1] / dims[1], hz = 1.5 * size[2] / dims[2];
             const double reach = std::sqrt(cutoff2 * (1.0 + 1e-9) + 1e-9) + std::sqrt(hx * hx + hy * hy + hz * hz);
             bool all = true;
             for (int k = 0; k < 3; ++k) {

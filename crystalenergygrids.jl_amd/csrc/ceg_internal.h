@@ -41,6 +41,11 @@ struct Geom {
     int32_t _pad;
 };
 
+// A multi-probe plan holds the rule tables of up to CEG_MAX_PROBES probe atoms (one VdW grid each) of ONE framework: the K VdW
+// grids + the Coulomb grid of a setup_RASPA call (src/raspa.jl:497-520 builds them one after the other) come out of one pass
+// over one image list.
+constexpr int CEG_MAX_PROBES = 4;
+
 // Where results go.  Grid mode: 8 float channels per grid, written with
 // _set_gridpoint! semantics (src/grids.jl:118-135).  Raw mode (eval_points): the 8 FP64
 // numbers of compute_derivatives_* per point, before clamping/scaling.
@@ -54,6 +59,10 @@ struct Output {
     int32_t i_begin, i_end; // x-planes computed by this launch
     double  lambda_vdw, thr_vdw;
     double  lambda_coulomb, thr_coulomb;
+    // multi-probe launches (k_culled<..., NP > 1>): grid p of the launch is written to vdwm[p] with the rules of the plan's
+    // probe probe_idx[p]
+    float*  vdwm[CEG_MAX_PROBES];
+    int32_t probe_idx[CEG_MAX_PROBES];
 };
 
 // Arbitrary point list (eval_points) or null for grid mode.
@@ -124,7 +133,10 @@ struct PlanConst {
     double bk_nshift, bk_c1, bk_c2, bk_c3, bk_c4;      // scaled hot loop: -shift/C, -B/6, -B/48, B^2/3, -B/160
     double bk_s1, bk_s2, bk_s3;                        // exact path: 1/(6C), -1/(48C), 1/(480C)
     int32_t all_simple;        // grid mode: every image a tile can keep is provably the fractionally wrapped one (no per-candidate test)
-    int32_t _pad2;
+    int32_t nprobes;           // multi-probe plans: number of probes (0 = ordinary plan)
+    // multi-probe plans (all probes Lennard-Jones-only): per probe the rule table (exact path) and the per-kind fast records
+    RuleTable rtm[CEG_MAX_PROBES];
+    const FastVdw* fastm[CEG_MAX_PROBES];
 };
 
 // shared between the host table builder and the kernels
@@ -145,10 +157,16 @@ constexpr int CEG_EW2_LOGM = 5;
 constexpr int CEG_EW2_SHIFT = 20 - CEG_EW2_LOGM;               // bits of the high word below the interval key
 constexpr int CEG_EW2_STRIDE = 14;                             // doubles per interval record
 constexpr int CEG_EW2_NI_MAX = 176;                            // cutoff 12 A from r_exact 2 A: 165 intervals
-constexpr int CEG_BK2_STRIDE = 6;                              // one degree-5 polynomial per interval (48 B: 16 bank groups too)
-constexpr int CEG_BK2_LOGM = 6;                                // A exp(-B sqrt(s)) varies faster: 64 intervals per octave of s
+// Single Buckingham class: G0(s)/C = (A/C) exp(-B sqrt(s)) on the SAME intervals as the Ewald pair (one key and one t per
+// candidate serve both tables), one degree-7 polynomial per interval (64 B).  Round 2 used degree 5 on 64 intervals per octave
+// (3e-13 of the pair energy: up to 77 ULP in stored values where the attractive and repulsive sums of a channel cancel);
+// degree 7 on 32 per octave reaches 2e-15 (fit in long double, checked per plan against CEG_BK2_TOL) with 2/3 of the LDS
+// footprint and half the distinct records per wave.
+constexpr int CEG_BK2_STRIDE = 8;
+constexpr int CEG_BK2_LOGM = CEG_EW2_LOGM;
 constexpr int CEG_BK2_SHIFT = 20 - CEG_BK2_LOGM;
-constexpr int CEG_BK2_NI_MAX = 2 * CEG_EW2_NI_MAX;
+constexpr int CEG_BK2_NI_MAX = CEG_EW2_NI_MAX;
+constexpr double CEG_BK2_TOL = 2e-14;                          // of G0 + C/s^3, the pair energy the table value is added into
 
 // launchers (ceg_kernels.hip)
 hipError_t launch_bruteforce(int mode, const Geom& g, const AtomTable& atoms, const RuleTable& rt,
@@ -157,5 +175,9 @@ hipError_t launch_bruteforce(int mode, const Geom& g, const AtomTable& atoms, co
 // 2 r^2-indexed tables
 hipError_t launch_culled(int mode, const PlanConst* d_pc, const Geom& g, int vdwk, int ewk,
                          const Output& out, const Points& pts, hipStream_t stream);
+// multi-probe grid build: np (2..CEG_MAX_PROBES; with mode == MODE_FUSED at most CEG_MAX_PROBES_FUSED) Lennard-Jones probes of a
+// multi-probe plan in one pass, out.vdwm / out.probe_idx say which; mode MODE_VDW or MODE_FUSED (+ the Coulomb grid, EWK = 2)
+constexpr int CEG_MAX_PROBES_FUSED = 2;
+hipError_t launch_culled_multi(int mode, int np, const PlanConst* d_pc, const Geom& g, const Output& out, hipStream_t stream);
 
 }  // namespace ceg

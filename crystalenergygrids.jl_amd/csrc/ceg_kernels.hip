@@ -353,9 +353,19 @@ __global__ __launch_bounds__(256) void k_bruteforce(Geom g, AtomTable atoms, Rul
 #endif
 // pairs closer than this (A^2) take the literal min-image arithmetic in the culled kernel
 // waves per SIMD the register allocator plans for, per variant (measured, profiles/r01_variant_waves.txt)
-constexpr int culled_waves(int mode, int vdwk, int ewk)
+#ifndef CEG_WAVES_MULTI_FUSED
+#define CEG_WAVES_MULTI_FUSED 3      // two probes + Coulomb: 48 accumulator registers; 4 waves per SIMD would need <= 128 VGPRs in all
+#endif
+#ifndef CEG_WAVES_MULTI_VDW
+#define CEG_WAVES_MULTI_VDW 4
+#endif
+#ifndef CEG_NW_MULTI_FUSED
+#define CEG_NW_MULTI_FUSED 6         // 6 waves x 64 x 112 B + 19.7 KB of tables = 69 KB: two workgroups = 12 waves = 3 per SIMD on a CU
+#endif
+constexpr int culled_waves(int mode, int vdwk, int ewk, int np = 1)
 {
-    return (mode == 2 && vdwk >= 2 && ewk) ? CEG_WAVES_FUSED_BUCK
+    return np > 1 ? (mode == 2 ? CEG_WAVES_MULTI_FUSED : (np == 2 ? CEG_WAVES_MULTI_VDW : 3))
+           : (mode == 2 && vdwk >= 2 && ewk) ? CEG_WAVES_FUSED_BUCK
            : (mode == 2 && vdwk == 1 && ewk) ? CEG_WAVES_FUSED_LJ
            : (mode == 0 && vdwk == 1)      ? CEG_WAVES_VDW_LJ
            : (mode == 0 && vdwk >= 2)      ? CEG_WAVES_VDW_BUCK
@@ -367,7 +377,12 @@ constexpr int culled_waves(int mode, int vdwk, int ewk)
 #endif
 // waves (= tiles) per workgroup: the r^2-indexed Ewald tables take 18 KB of LDS, shared by 8 waves instead of 4 so that
 // two workgroups (16 waves, 4 per SIMD) still fit a CU's 160 KB
-constexpr int culled_nw(int mode, int vdwk, int ewk) { return ((mode != 0 && ewk == 2) || (mode != 1 && vdwk == 3)) ? CEG_NW_EW2 : CEG_WG / 64; }
+constexpr int culled_nw(int mode, int vdwk, int ewk, int np = 1)
+{
+    // multi-probe records are 48 + 32 np bytes; VdW-only: 4 waves x 64 x (112 .. 176) B, three or four workgroups per CU
+    return np > 1 ? (mode == 2 ? CEG_NW_MULTI_FUSED : CEG_WG / 64)
+                  : ((mode != 0 && ewk == 2) || (mode != 1 && vdwk == 3)) ? CEG_NW_EW2 : CEG_WG / 64;
+}
 [[maybe_unused]] constexpr double R_EXACT2 = CEG_R_EXACT2;
 static_assert(ERFCX_TAB_N == CEG_ERFCX_TAB_N, "table size mismatch");
 constexpr int META_SIMPLE = 1 << 24;      // image is the wrapped one for every point of the tile
@@ -393,13 +408,14 @@ struct __attribute__((aligned(16))) CandRec {
 // position, invmat*d, wrap, mat*f, neighbour search (periodic_distance2_literal) -- and evaluated
 // with the literal radial formulas.  Runs after the hot loop so that its registers do not
 // overlap the hot loop's.
-template <int MODE, bool FASTEW, bool LJSLOW, bool EWSCALED, bool BKSCALED, typename Rec>
+template <int MODE, bool FASTEW, bool LJSLOW, bool EWSCALED, bool BKSCALED, int NP, typename Rec>
 __device__ __forceinline__ void slow_pairs(const PlanConst* __restrict__ pc, unsigned long long cands, int lane,
                                            double px, double py, double pz,
                                            const Rec* s_rec,
                                            const unsigned long long* s_odd,
-                                           Accum& av, Accum& ac, double& smallest_d2)
+                                           Accum* avm, const int32_t* probe_idx, Accum& ac, double& smallest_d2)
 {
+    Accum& av = avm[0];
     const Geom& g = pc->g;
     while (cands != 0ull) {
         const int q = __builtin_ctzll(cands);
@@ -411,7 +427,22 @@ __device__ __forceinline__ void slow_pairs(const PlanConst* __restrict__ pc, uns
         double dx = px - O.x, dy = py - O.y, dz = pz - O.z;
         const double r2 = periodic_distance2_literal(g, dx, dy, dz);
         if (r2 >= g.cutoff2) continue;
-        if (MODE != MODE_COULOMB && (mt & META_HASVDW)) {
+        if constexpr (NP > 1) {
+            if (mt & META_HASVDW) {           // multi-probe plan: the rule run of the image's kind in every probe's table
+                const int kd = mt & META_KINDMASK;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const RuleTable& rtp = pc->rtm[probe_idx[p]];
+                    const int rb = rtp.offset[kd], re = rtp.offset[kd + 1];
+                    if (re == rb) continue;       // no rule for this probe: nothing is added (as in a single-probe launch, where the all-zero
+                                                  // record of the hot loop adds exact zeros)
+                    double v, p1, p2, p3;
+                    vdw_terms<true, true>(rtp.rules, rb, re, r2, v, p1, p2, p3);
+                    p1 *= -1.0 / 6.0; p2 *= 1.0 / 48.0; p3 *= -1.0 / 480.0;
+                    accum_add(avm[p], v, p1, p2, p3, dx, dy, dz);
+                }
+            }
+        } else if (MODE != MODE_COULOMB && (mt & META_HASVDW)) {
             const int kd = mt & META_KINDMASK;
             double v, p1, p2, p3;
             vdw_terms<LJSLOW, true>(pc->rt.rules, pc->rt.offset[kd], pc->rt.offset[kd + 1], r2, v, p1, p2, p3);
@@ -483,6 +514,23 @@ struct __attribute__((aligned(16))) CandRecS {
     int32_t _pad[2];
 };
 static_assert(sizeof(CandRecS) == 48, "candidate record layout");
+// multi-probe launches: the Lennard-Jones record (4 eps, sigma^2, sigma^6, shift) of the image's kind for each of the NP probes
+template <int NP>
+struct __attribute__((aligned(16))) CandRecM {
+    Quad xyzq;
+    Quad ljm[NP];
+    int32_t meta;
+    int32_t atom;
+    int32_t _pad[2];
+};
+static_assert(sizeof(CandRecM<2>) == 112 && sizeof(CandRecM<4>) == 176, "candidate record layout");
+// the per-candidate VdW record of probe p, whatever the record type (so that branches the variant never takes still compile)
+template <int NP> __device__ __forceinline__ Quad lj_record(const CandRecM<NP>& r, int p) { return r.ljm[p]; }
+__device__ __forceinline__ Quad lj_record(const CandRec& r, int) { return r.lj; }
+__device__ __forceinline__ Quad lj_record(const CandRecS&, int) { return Quad{0.0, 0.0, 0.0, 0.0}; }
+template <int NP> __device__ __forceinline__ void set_lj_record(CandRecM<NP>& r, int p, Quad q) { r.ljm[p] = q; }
+__device__ __forceinline__ void set_lj_record(CandRec& r, int, Quad q) { r.lj = q; }
+__device__ __forceinline__ void set_lj_record(CandRecS&, int, Quad) {}
 
 // Template flags of k_culled
 //   MODE    what is accumulated (VdW / Coulomb / both in one pass)
@@ -498,13 +546,19 @@ static_assert(sizeof(CandRecS) == 48, "candidate record layout");
 //           polynomial, no division); otherwise libm-style erfc/exp
 //   EWK     real-space Ewald term: 0 libm-style erfc / exp; 1 (alpha*cutoff <= ERFCX_XMAX) one table exp + erfcx table,
 //           no division; 2 B0(r^2), C(r^2) from r^2-indexed polynomial tables + the B_n recurrence, no sqrt / exp / erfc
-template <int MODE, bool POINTS, int VDWK, int EWK>
-__global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE, VDWK, EWK)) void k_culled(const PlanConst* __restrict__ pc, Output out, Points pts,
+//   NP      probes per launch (multi-probe plans: NP > 1 needs VDWK = 1, grid mode, EWK = 2): NP VdW accumulator sets, the
+//           candidate record carries the Lennard-Jones parameters of its kind for each probe; distance, 1/r^2, products and
+//           the Coulomb part are shared.  The per-pair arithmetic and the order of the sums are those of the NP = 1 kernel:
+//           a multi-probe launch is bit-identical to single-probe launches from the same plan.
+template <int MODE, bool POINTS, int VDWK, int EWK, int NP = 1>
+__global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK, NP), culled_waves(MODE, VDWK, EWK, NP)) void k_culled(const PlanConst* __restrict__ pc, Output out, Points pts,
                                                               int tiles_j, int tiles_k, int64_t ntiles)
 {
+    static_assert(NP >= 1 && NP <= CEG_MAX_PROBES && (NP == 1 || (VDWK == 1 && !POINTS && EWK == 2 && MODE != MODE_COULOMB)), "multi-probe variant");
+    constexpr bool MULTI = NP > 1;
     constexpr bool FASTEW = EWK != 0;
     constexpr bool EW2 = EWK == 2 && MODE != MODE_VDW;
-    constexpr int WG = 64 * culled_nw(MODE, VDWK, EWK);
+    constexpr int WG = 64 * culled_nw(MODE, VDWK, EWK, NP);
     constexpr bool BK2 = VDWK == 3 && MODE != MODE_COULOMB;       // one Buckingham class, G0(r^2) tabulated
     // One workgroup = CEG_WG/64 waves; each wave owns one tile and its own slice of the staging
     // arrays (waves never touch each other's slice, so no workgroup barrier inside the loops --
@@ -512,8 +566,8 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
     constexpr int NW = WG / 64;
     // one record per kept candidate: image position + charge, VdW parameters of its kind, flags, atom index.
     // A single array so that the hot loop walks ONE LDS address (immediate offsets reach the fields).
-    constexpr bool HAS_LJ = (VDWK == 1 || VDWK == 2) && MODE != MODE_COULOMB;      // per-candidate VdW parameters travel in the record
-    using Rec = std::conditional_t<HAS_LJ, CandRec, CandRecS>;
+    constexpr bool HAS_LJ = !MULTI && (VDWK == 1 || VDWK == 2) && MODE != MODE_COULOMB;      // per-candidate VdW parameters travel in the record
+    using Rec = std::conditional_t<MULTI, CandRecM<NP>, std::conditional_t<HAS_LJ, CandRec, CandRecS>>;
     __shared__ __attribute__((aligned(16))) Rec s_rec_all[NW][64];
     __shared__ int32_t s_rowstart_all[NW][64];
     __shared__ int32_t s_rowprefix_all[NW][66];
@@ -621,8 +675,10 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
     const int nrows = active ? (bx1 - bx0 + 1) * nry : 0;
     const float inv_nry = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(1.0f / (float)nry)));
 
-    Accum av, ac;
-    accum_zero(av);
+    Accum avm[NP], ac;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) accum_zero(avm[p]);
+    Accum& av = avm[0];
     accum_zero(ac);
     double smallest_d2 = __builtin_huge_val();
     // width of the "decide with the reference's arithmetic" band around a threshold
@@ -697,6 +753,9 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
             bool keep = false, interior = false;
             double4 P = make_double4(0, 0, 0, 0);
             double4 LJ = make_double4(0, 0, 0, 0);
+            double4 LJM[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) LJM[p] = make_double4(0, 0, 0, 0);
             int meta = 0, aidx = 0;
             if (t < total) {
                 int lo = 0, hi = 64;           // largest lo with prefix[lo] <= t
@@ -724,7 +783,15 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
                 int vclass = 0;
                 if (MODE != MODE_COULOMB && kd >= 0) {
                     hasvdw = (kw & META_HASVDW) != 0;
-                    if (FASTVDW && VDWK != 3 && hasvdw && keep) {
+                    if constexpr (MULTI) {
+                        if (hasvdw && keep) {
+#pragma unroll
+                            for (int p = 0; p < NP; ++p) {          // a kind without a rule for probe p has an all-zero record: exact zeros
+                                const FastVdw F = pc->fastm[out.probe_idx[p]][kd];
+                                LJM[p] = make_double4(F.p0, F.p1, F.p2, F.shift);
+                            }
+                        }
+                    } else if (FASTVDW && VDWK != 3 && hasvdw && keep) {
                         const FastVdw F = pc->fastvdw[kd];          // class + parameters of this kind
                         LJ = make_double4(F.p0, F.p1, F.p2, F.shift);
                         vclass = F.cls;
@@ -770,7 +837,10 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
                 const int first = !simple_c ? nreg : (withv ? (interior ? 0 : nvi) : (interior ? nv : nni));
                 const int slot = first + __builtin_amdgcn_mbcnt_hi((unsigned)(mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mine, 0));
                 s_rec[slot].xyzq = Quad{P.x, P.y, P.z, P.w};
-                if constexpr (HAS_LJ) s_rec[slot].lj = Quad{LJ.x, LJ.y, LJ.z, LJ.w};
+                if constexpr (MULTI) {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) set_lj_record(s_rec[slot], p, Quad{LJM[p].x, LJM[p].y, LJM[p].z, LJM[p].w});
+                } else if constexpr (HAS_LJ) s_rec[slot].lj = Quad{LJ.x, LJ.y, LJ.z, LJ.w};
                 s_rec[slot].meta = meta;
                 s_rec[slot].atom = aidx;
             }
@@ -822,27 +892,53 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
                 // interval of s = r2 in the r^2-indexed tables: key = exponent + leading mantissa bits, t = s - start of the interval
                 int key = 0;
                 double t = 0.0;
-                if (EW2) {
+                static_assert(CEG_BK2_SHIFT == CEG_EW2_SHIFT, "the Buckingham table shares the interval key of the Ewald tables");
+                if (EW2 || (BK2 && WITH_VDW)) {
                     key = (int)((unsigned)hi >> CEG_EW2_SHIFT);
                     t = r2 - __hiloint2double(hi & (int)(0xffffffffu << CEG_EW2_SHIFT), 0);
                 }
-                if constexpr (WITH_VDW) {
+                if constexpr (WITH_VDW && MULTI) {
+                    // the LJ branch below, once per probe: 1/r^2 and its powers are shared, the expressions are the same
+                    const double inv2 = inv * inv;
+                    const double y3 = inv2 * inv;
+                    const double inv4 = inv2 * inv2;
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        const Quad L = lj_record(s_rec[q], p);  // 4 eps, sigma^2, sigma^6, shift
+                        const double x6 = L.z * y3;
+                        const double w = L.x * x6;
+                        const double u = w * x6;
+                        const double v = (u - w) - L.w;
+                        const double p1 = __builtin_fma(u, 2.0, -w) * inv;                 // / -6
+                        const double p2 = fms_vsv(u, 3.5, w) * inv2;                       // / 48
+                        const double p3 = fms_vsv(u, 5.6, w) * inv4;                       // / -480
+                        Accum& a = avm[p];
+                        a.v += v;
+                        a.d1x = __builtin_fma(p1, dx, a.d1x);
+                        a.d1y = __builtin_fma(p1, dy, a.d1y);
+                        a.d1z = __builtin_fma(p1, dz, a.d1z);
+                        a.d2xy = __builtin_fma(p2, dxy, a.d2xy);
+                        a.d2xz = __builtin_fma(p2, dxz, a.d2xz);
+                        a.d2yz = __builtin_fma(p2, dyz, a.d2yz);
+                        a.d3 = __builtin_fma(p3, dxyz, a.d3);
+                    }
+                } else if constexpr (WITH_VDW) {
                     double v, p1, p2, p3;
                     if constexpr (VDWK == 3) {
                         // derivativesGrid, Buckingham branch (src/interactions.jl:447-457) with G0 = A exp(-B r) from the table,
                         // u = G0/r, x6 = C/r^6 and D = (1/r) d/dr:  D G0 = -B u,  D u = -(B G0 + u)/r^2
                         //   v = G0 - x6 - shift,  p1 = -B u + 6 x6/r^2,  p2 = B (B G0 + u)/r^2 - 48 x6/r^4,
                         //   p3 = -B (B^2 u + 3 (B G0 + u)/r^2)/r^2 + 480 x6/r^6
-                        const int keyb = (int)((unsigned)hi >> CEG_BK2_SHIFT);
-                        const double tb = r2 - __hiloint2double(hi & (int)(0xffffffffu << CEG_BK2_SHIFT), 0);
                         const double2* rec = reinterpret_cast<const double2*>(
-                            reinterpret_cast<const char*>(s_bk2) + mad_u24(keyb, bk2_stride, bk2_off));
-                        const double2 g01 = rec[0], g23 = rec[1], g45 = rec[2];
-                        double g0 = __builtin_fma(g45.y, tb, g45.x);
-                        g0 = __builtin_fma(g0, tb, g23.y);
-                        g0 = __builtin_fma(g0, tb, g23.x);
-                        g0 = __builtin_fma(g0, tb, g01.y);
-                        g0 = __builtin_fma(g0, tb, g01.x);
+                            reinterpret_cast<const char*>(s_bk2) + mad_u24(key, bk2_stride, bk2_off));
+                        const double2 g01 = rec[0], g23 = rec[1], g45 = rec[2], g67 = rec[3];
+                        double g0 = __builtin_fma(g67.y, t, g67.x);      // degree 7 on the Ewald tables' intervals (ceg_internal.h)
+                        g0 = __builtin_fma(g0, t, g45.y);
+                        g0 = __builtin_fma(g0, t, g45.x);
+                        g0 = __builtin_fma(g0, t, g23.y);
+                        g0 = __builtin_fma(g0, t, g23.x);
+                        g0 = __builtin_fma(g0, t, g01.y);
+                        g0 = __builtin_fma(g0, t, g01.x);
                         // The table holds G' = G0/C and the channels are accumulated as v/C, p1/(6C), p2/(-48C), p3/(480C): the
                         // dispersion parts are then bare powers of 1/r^2 and every constant sits in ONE fma per channel
                         // (factors applied once per tile).  With u = G'/r, w = B G' + u:
@@ -860,7 +956,7 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
                       if (VDWK == 2 && (__builtin_amdgcn_readfirstlane(s_rec[q].meta) & META_BUCK)) {
                         // derivativesGrid, Buckingham branch (src/interactions.jl:447-457); a hard
                         // sphere summed with it is 0 here (its radius lies inside the exact path)
-                        const Quad L = s_rec[q].lj;            // A, B, C, shift
+                        const Quad L = lj_record(s_rec[q], 0);  // A, B, C, shift
                         const double Br = L.y * rr;
                         const double xe = L.x * exp_neg_tab(s_exp2, -Br);
                         const double inv2 = inv * inv;
@@ -876,7 +972,7 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
                         // derivativesGrid, LJ branch (src/interactions.jl:434-441), with 1/r2 shared.  In terms of
                         // w = 4 eps x6 and u = 4 eps x6^2 (x6 = sigma^6/r^6, sigma^6 formed once per kind on the host):
                         //   v = u - w - shift,  p1 = -6 (2u - w)/r^2,  p2 = 48 (3.5u - w)/r^4,  p3 = -480 (5.6u - w)/r^8
-                        const Quad L = s_rec[q].lj;            // 4 eps, sigma^2, sigma^6, shift
+                        const Quad L = lj_record(s_rec[q], 0);  // 4 eps, sigma^2, sigma^6, shift
                         const double inv2 = inv * inv;
                         const double x6 = L.z * (inv2 * inv);
                         const double w = L.x * x6;
@@ -993,14 +1089,18 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
 #endif
             if (slow != 0ull) {
                 __builtin_amdgcn_wave_barrier();
-                slow_pairs<MODE, FASTEW, VDWK == 1, EW2, VDWK == 3 && MODE != MODE_COULOMB>(pc, slow, lane, px, py, pz, s_rec, s_odd, av, ac, smallest_d2);
+                slow_pairs<MODE, FASTEW, VDWK == 1, EW2, VDWK == 3 && MODE != MODE_COULOMB, NP>(pc, slow, lane, px, py, pz, s_rec, s_odd, avm, out.probe_idx, ac, smallest_d2);
             }
         }
     }
     if (VDWK == 1 && MODE != MODE_COULOMB) {      // constant factors of the LJ derivative channels, deferred out of the hot loop
-        av.d1x *= -6.0; av.d1y *= -6.0; av.d1z *= -6.0;
-        av.d2xy *= 48.0; av.d2xz *= 48.0; av.d2yz *= 48.0;
-        av.d3 *= -480.0;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            Accum& a = avm[p];
+            a.d1x *= -6.0; a.d1y *= -6.0; a.d1z *= -6.0;
+            a.d2xy *= 48.0; a.d2xz *= 48.0; a.d2yz *= 48.0;
+            a.d3 *= -480.0;
+        }
     }
     if (VDWK == 3 && MODE != MODE_COULOMB) {      // constant factors of the single Buckingham class
         const double C = pc->bk_C;
@@ -1026,6 +1126,39 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK), culled_waves(MODE,
     const int64_t nz = g.dims[2] + 1, ny = g.dims[1] + 1;
     constexpr int NSEG = 8 * 16 * NW;                 // 16-byte segments per grid in this workgroup
     if (MODE != MODE_VDW) ac.v = (smallest_d2 < 1.0) ? __builtin_huge_val() : ac.v;      // src/probes.jl:116
+    if constexpr (MULTI) {
+        // one grid per pass through the wave's record slice: the NP VdW grids, then the Coulomb grid
+        constexpr int NGRID = NP + (MODE == MODE_FUSED ? 1 : 0);
+        float* sm = reinterpret_cast<float*>(s_rec_all[wave]);
+#pragma unroll
+        for (int gi = 0; gi < NGRID; ++gi) {
+            if (gi == 0) __builtin_amdgcn_wave_barrier(); else __syncthreads();      // readers of the previous contents are done
+            float r[8];
+            if (gi < NP) gridpoint8(r, g.delta, out.lambda_vdw, out.thr_vdw, avm[gi < NP ? gi : 0]);
+            else gridpoint8(r, g.delta, out.lambda_coulomb, out.thr_coulomb, ac);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) sm[c * 64 + lane] = r[c];
+            __syncthreads();
+            float* base = gi < NP ? out.vdwm[gi < NP ? gi : 0] : out.coulomb;
+            for (int seg = threadIdx.x; seg < NSEG; seg += WG) {
+                const int w = seg % NW;
+                const int row = seg / NW;                     // (channel, li, lj)
+                const int c = row >> 4, li = (row >> 2) & 3, lj = row & 3;
+                const int oi = s_org[w][0];
+                if (oi < 0) continue;
+                const int gi_ = oi + li, gj = s_org[w][1] + lj, gk = s_org[w][2];
+                if (gi_ >= out.i_end || gj > g.dims[1] || gk > g.dims[2]) continue;
+                const int64_t idx = (int64_t)gk + nz * ((int64_t)gj + ny * (int64_t)(gi_ - out.i_origin)) + (int64_t)c * out.channel_stride;
+                const int so = c * 64 + li * 16 + lj * 4;
+                const int nvalid = (g.dims[2] + 1 - gk) < 4 ? (g.dims[2] + 1 - gk) : 4;
+                const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(s_rec_all[w]) + so);
+                float* dst = base + idx;
+                if (nvalid == 4) store_float4_unaligned(dst, v);
+                else { dst[0] = v.x; if (nvalid > 1) dst[1] = v.y; if (nvalid > 2) dst[2] = v.z; }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int pass = 0; pass < (TWO_PASS ? 2 : 1); ++pass) {
         const bool do_v = MODE != MODE_COULOMB && (!TWO_PASS || pass == 0);
@@ -1138,6 +1271,36 @@ static hipError_t launch_cull_t(int mode, const PlanConst* pc, int vdwk, int ewk
     case MODE_VDW: return launch_cull_flags<MODE_VDW, POINTS>(vdwk, ewk, stream, pc, out, pts, tj, tk, ntiles);
     case MODE_COULOMB: return launch_cull_flags<MODE_COULOMB, POINTS>(vdwk, ewk, stream, pc, out, pts, tj, tk, ntiles);
     default: return launch_cull_flags<MODE_FUSED, POINTS>(vdwk, ewk, stream, pc, out, pts, tj, tk, ntiles);
+    }
+}
+
+template <int MODE, int NP>
+static hipError_t launch_multi_t(const PlanConst* pc, const Output& out, int tj, int tk, int64_t ntiles, hipStream_t stream)
+{
+    const int nw = culled_nw(MODE, 1, 2, NP);
+    const int64_t nblocks = (ntiles + nw - 1) / nw;
+    if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_culled<MODE, false, 1, 2, NP>), dim3((unsigned)nblocks), dim3(64 * nw), 0, stream, pc, out, Points{nullptr, 0}, tj, tk, ntiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_culled_multi(int mode, int np, const PlanConst* d_pc, const Geom& g, const Output& out, hipStream_t stream)
+{
+    const int ni = out.i_end - out.i_begin;
+    const int ti = (ni + 3) / 4, tj = (g.dims[1] + 1 + 3) / 4, tk = (g.dims[2] + 1 + 3) / 4;
+    const int64_t ntiles = (int64_t)ti * tj * tk;
+    if (ntiles <= 0) return hipSuccess;
+    if (mode == MODE_FUSED) {
+        static_assert(CEG_MAX_PROBES_FUSED == 2, "fused multi-probe variants");
+        if (np == 2) return launch_multi_t<MODE_FUSED, 2>(d_pc, out, tj, tk, ntiles, stream);
+        return hipErrorInvalidValue;
+    }
+    if (mode != MODE_VDW) return hipErrorInvalidValue;
+    switch (np) {
+    case 2: return launch_multi_t<MODE_VDW, 2>(d_pc, out, tj, tk, ntiles, stream);
+    case 3: return launch_multi_t<MODE_VDW, 3>(d_pc, out, tj, tk, ntiles, stream);
+    case 4: return launch_multi_t<MODE_VDW, 4>(d_pc, out, tj, tk, ntiles, stream);
+    default: return hipErrorInvalidValue;
     }
 }
 

@@ -74,24 +74,21 @@ __device__ __forceinline__ double min_nonan(double a, double b)
     return r;
 }
 
-// sqrt(a) and 1/sqrt(a) for a normal positive a: v_rsq_f64 seed + one coupled Goldschmidt step
-// (measured on MI355X: pair terms accurate to 1.3e-13 with one step, 3e-14 with two --
-// tests/test_gpu_parity.py::test_fast_math_accuracy_single_pair; define CEG_RSQ_TWO_ITER for two).
+// sqrt(a) and 1/sqrt(a) for a normal positive a: v_rsq_f64 seed y (4.6e-8 relative, scripts/probes/seed_accuracy.hip) + ONE
+// third-order step: with e = 1 - a y^2, 1/sqrt(a) = y (1 - e)^(-1/2) = y (1 + e/2 + 3 e^2/8 + O(e^3)), O(e^3) ~ 3e-22.
+// Five instructions for 1/sqrt alone (the sqrt is one more product, dropped when unused) -- what the coupled Goldschmidt step of
+// round 2 cost, whose second-order remainder (3/8) e^2 = 3e-15 reached the stored Float32 values where the repulsive and
+// dispersive sums of a derivative channel cancel (profiles/r02_parity_report.txt: 77 ULP); now <= 3 roundings.
 __device__ __forceinline__ void fast_sqrt_rsqrt(double a, double& s, double& rs)
 {
     const double y = __builtin_amdgcn_rsq(a);
-    double g = a * y;          // ~ sqrt(a)
-    double h = 0.5 * y;        // ~ 1/(2 sqrt(a))
-    double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    h = __builtin_fma(h, r, h);
-#ifdef CEG_RSQ_TWO_ITER
-    r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    h = __builtin_fma(h, r, h);
-#endif
-    s = g;
-    rs = h + h;
+    const double t = a * y;
+    const double e = __builtin_fma(-t, y, 1.0);
+    double p;
+    asm("v_fma_f64 %0, %1, %2, 0.5" : "=v"(p) : "v"(e), "s"(0.375));      // 1/2 + 3 e / 8 (0.375 in a scalar pair: no inline constant)
+    const double q = y * e;
+    rs = __builtin_fma(q, p, y);
+    s = a * rs;
 }
 
 // 1/a for a normal a: hardware seed (4.6e-8 relative, measured: scripts/probes/seed_accuracy.hip) + CEG_RCP_ITERS Newton steps

@@ -626,10 +626,31 @@ struct ceg_mc {
     unsigned long long *h_flag = nullptr, *dm_flag = nullptr;
     unsigned* d_done = nullptr;
     unsigned long long seq = 0;
+    // set when a state-changing call failed after it had started to change the host mirror (counts, slot lists, cell lists) or the
+    // device state: host and device may then disagree, so every later call fails until ceg_mc_set_guests rebuilds both
+    bool poisoned = false;
 };
 
 namespace {
 int rebuild_cells(ceg_mc* h);
+
+int poison(ceg_mc* h, int rc)
+{
+    h->poisoned = true;
+    return rc;
+}
+
+int refuse_poisoned()
+{
+    return merr(CEG_ERR_HIP, "the handle is inconsistent after an earlier failure of accept / insert / remove: call ceg_mc_set_guests");
+}
+
+// test hook: CEG_HIP_MC_INJECT_FAILURE=accept|insert|remove|set_guests makes the next such call fail after its host-side bookkeeping
+bool injected_failure(const char* what)
+{
+    const char* e = std::getenv("CEG_HIP_MC_INJECT_FAILURE");
+    return e && std::strcmp(e, what) == 0;
+}
 }
 
 extern "C" int ceg_mc_create(ceg_mc_t** handle, int32_t device, ceg_interp_t* const* vdw_grids, ceg_interp_t* coulomb_grid,
@@ -940,11 +961,13 @@ extern "C" int ceg_mc_set_guests(ceg_mc_t* h, const double* positions, const int
     }
     Guard guard(h->device);
     if (!guard.ok) return merr(CEG_ERR_HIP, "hipSetDevice failed");
-    if (hipStreamSynchronize(h->stream) != hipSuccess) return merr(CEG_ERR_HIP, "stream synchronisation failed");
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return poison(h, merr(CEG_ERR_HIP, "stream synchronisation failed"));
+    h->poisoned = true;                                    // until this call has rebuilt host and device state completely
     h->v.natoms = 0; h->v.nmol = 0;                        // nothing worth copying when the arrays grow
+    h->h_mol.clear();
     if (int rc = ensure_capacity(h, std::max<int64_t>(natoms, 1), std::max<int64_t>(nmol, 1))) return rc;
-    bool ok = true;
-    if (natoms > 0) ok = hipMemcpy(h->d_atoms, host.data(), sizeof(double4) * (size_t)natoms, hipMemcpyHostToDevice) == hipSuccess;
+    bool ok = !injected_failure("set_guests");
+    if (ok && natoms > 0) ok = hipMemcpy(h->d_atoms, host.data(), sizeof(double4) * (size_t)natoms, hipMemcpyHostToDevice) == hipSuccess;
     if (ok && nmol > 0) ok = hipMemcpy(h->d_molidx, idx.data(), sizeof(int2) * (size_t)nmol, hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) return merr(CEG_ERR_HIP, "could not upload the guest atoms");
     h->h_mol.assign(idx.begin(), idx.begin() + nmol);
@@ -968,12 +991,14 @@ extern "C" int ceg_mc_set_guests(ceg_mc_t* h, const double* positions, const int
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
             return merr(CEG_ERR_HIP, "structure-factor kernels failed");
     }
+    h->poisoned = false;
     return CEG_OK;
 }
 
 extern "C" int ceg_mc_trial(ceg_mc_t* h, int32_t molecule, const double* trial, int64_t n, double* out)
 {
     if (!h || n < 0 || !out || (n > 0 && !trial)) return merr(CEG_ERR_INVALID, "bad argument");
+    if (h->poisoned) return refuse_poisoned();
     if (molecule < 0 || molecule >= h->v.nmol) return merr(CEG_ERR_INVALID, "no such molecule");
     return run_trial(h, false, molecule, McMolecule{}, h->h_mol[molecule].y, trial, n, out);
 }
@@ -981,6 +1006,7 @@ extern "C" int ceg_mc_trial(ceg_mc_t* h, int32_t molecule, const double* trial, 
 extern "C" int ceg_mc_trial_insert(ceg_mc_t* h, const int32_t* kinds, int32_t m, const double* trial, int64_t n, double* out)
 {
     if (!h || n < 0 || (n > 0 && (!trial || !out))) return merr(CEG_ERR_INVALID, "bad argument");
+    if (h->poisoned) return refuse_poisoned();
     McMolecule nm{};
     if (int rc = check_molecule(h, kinds, m, &nm)) return rc;
     return run_trial(h, true, -1, nm, m, trial, n, out);
@@ -989,6 +1015,7 @@ extern "C" int ceg_mc_trial_insert(ceg_mc_t* h, const int32_t* kinds, int32_t m,
 extern "C" int ceg_mc_accept(ceg_mc_t* h, int32_t molecule, const double* positions)
 {
     if (!h || !positions) return merr(CEG_ERR_INVALID, "bad argument");
+    if (h->poisoned) return refuse_poisoned();
     if (molecule < 0 || molecule >= h->v.nmol) return merr(CEG_ERR_INVALID, "no such molecule");
     const int m = h->h_mol[molecule].y;
     McPositions np{};
@@ -1009,15 +1036,18 @@ extern "C" int ceg_mc_accept(ceg_mc_t* h, int32_t molecule, const double* positi
         }
         rebuild = !cm.finish(ops);
     }
-    hipLaunchKernelGGL(k_mc_accept, dim3(1), dim3(MC_THREADS), tables_bytes(h, m), h->stream, h->v, molecule, np, ops, h->stride);
-    if (hipGetLastError() != hipSuccess) return merr(CEG_ERR_HIP, "accept kernel launch failed");
-    if (rebuild) return rebuild_cells(h);
+    // (from here on the cell mirror already describes the accepted state: any failure leaves host and device out of step)
+    if (!injected_failure("accept"))
+        hipLaunchKernelGGL(k_mc_accept, dim3(1), dim3(MC_THREADS), tables_bytes(h, m), h->stream, h->v, molecule, np, ops, h->stride);
+    if (injected_failure("accept") || hipGetLastError() != hipSuccess) return poison(h, merr(CEG_ERR_HIP, "accept kernel launch failed"));
+    if (rebuild) { if (int rc = rebuild_cells(h)) return poison(h, rc); }
     return CEG_OK;                      // asynchronous: the next call on this handle is ordered behind it
 }
 
 extern "C" int ceg_mc_insert(ceg_mc_t* h, const int32_t* kinds, int32_t m, const double* positions, int32_t* molecule_out)
 {
     if (!h || !positions) return merr(CEG_ERR_INVALID, "bad argument");
+    if (h->poisoned) return refuse_poisoned();
     McMolecule nm{};
     if (int rc = check_molecule(h, kinds, m, &nm)) return rc;
     if (tables_bytes(h, m) > 64 * 1024) return merr(CEG_ERR_UNSUPPORTED, "k-space tables of the molecule do not fit in LDS");
@@ -1025,13 +1055,14 @@ extern "C" int ceg_mc_insert(ceg_mc_t* h, const int32_t* kinds, int32_t m, const
     if (!guard.ok) return merr(CEG_ERR_HIP, "hipSetDevice failed");
     if (h->free_runs.empty()) h->free_runs.assign(MC_MAX_ATOMS + 1, {});
     int32_t first;
-    if (!h->free_runs[m].empty()) {            // reuse the slots of a removed molecule of the same size
+    // capacity first (it may fail and has changed nothing yet), the host mirror afterwards
+    const bool reuse = !h->free_runs[m].empty();  // the slots of a removed molecule of the same size
+    if (int rc = ensure_capacity(h, (int64_t)h->v.natoms + (reuse ? 0 : m), (int64_t)h->v.nmol + 1)) return poison(h, rc);
+    if (reuse) {
         first = h->free_runs[m].back();
         h->free_runs[m].pop_back();
-        if (int rc = ensure_capacity(h, h->v.natoms, (int64_t)h->v.nmol + 1)) return rc;
     } else {
         first = h->v.natoms;
-        if (int rc = ensure_capacity(h, (int64_t)h->v.natoms + m, (int64_t)h->v.nmol + 1)) return rc;
         h->v.natoms += m;
     }
     const int32_t molecule = h->v.nmol;
@@ -1047,16 +1078,18 @@ extern "C" int ceg_mc_insert(ceg_mc_t* h, const int32_t* kinds, int32_t m, const
         for (int a = 0; a < m; ++a) cm.put_in(first + a, cm.bin_of(positions + 3 * a));
         rebuild = !cm.finish(ops);
     }
-    hipLaunchKernelGGL(k_mc_insert, dim3(1), dim3(MC_THREADS), tables_bytes(h, m), h->stream, h->v, molecule, first, nm, np, ops, h->stride);
-    if (hipGetLastError() != hipSuccess) return merr(CEG_ERR_HIP, "insert kernel launch failed");
+    if (!injected_failure("insert"))
+        hipLaunchKernelGGL(k_mc_insert, dim3(1), dim3(MC_THREADS), tables_bytes(h, m), h->stream, h->v, molecule, first, nm, np, ops, h->stride);
+    if (injected_failure("insert") || hipGetLastError() != hipSuccess) return poison(h, merr(CEG_ERR_HIP, "insert kernel launch failed"));
     if (molecule_out) *molecule_out = molecule;
-    if (rebuild) return rebuild_cells(h);
+    if (rebuild) { if (int rc = rebuild_cells(h)) return poison(h, rc); }
     return CEG_OK;
 }
 
 extern "C" int ceg_mc_remove(ceg_mc_t* h, int32_t molecule, int32_t* moved_out)
 {
     if (!h) return merr(CEG_ERR_INVALID, "bad argument");
+    if (h->poisoned) return refuse_poisoned();
     if (molecule < 0 || molecule >= h->v.nmol) return merr(CEG_ERR_INVALID, "no such molecule");
     Guard guard(h->device);
     if (!guard.ok) return merr(CEG_ERR_HIP, "hipSetDevice failed");
@@ -1071,9 +1104,10 @@ extern "C" int ceg_mc_remove(ceg_mc_t* h, int32_t molecule, int32_t* moved_out)
             for (int a = 0; a < h->h_mol[last].y; ++a) cm.refresh(h->h_mol[last].x + a);
         rebuild = !cm.finish(ops);
     }
-    hipLaunchKernelGGL(k_mc_remove, dim3(1), dim3(MC_THREADS), 0, h->stream, h->v, molecule, last, ops);
-    if (hipGetLastError() != hipSuccess) return merr(CEG_ERR_HIP, "remove kernel launch failed");
-    if (rebuild) { if (int rc = rebuild_cells(h)) return rc; }
+    if (!injected_failure("remove"))
+        hipLaunchKernelGGL(k_mc_remove, dim3(1), dim3(MC_THREADS), 0, h->stream, h->v, molecule, last, ops);
+    if (injected_failure("remove") || hipGetLastError() != hipSuccess) return poison(h, merr(CEG_ERR_HIP, "remove kernel launch failed"));
+    if (rebuild) { if (int rc = rebuild_cells(h)) return poison(h, rc); }
     if (h->free_runs.empty()) h->free_runs.assign(MC_MAX_ATOMS + 1, {});
     h->free_runs[h->h_mol[molecule].y].push_back(h->h_mol[molecule].x);
     if (last != molecule) h->h_mol[molecule] = h->h_mol[last];
@@ -1095,6 +1129,7 @@ extern "C" int ceg_mc_neighbour_cells(ceg_mc_t* h, int32_t nb[3], int32_t* capac
 extern "C" int ceg_mc_get_state(ceg_mc_t* h, double* positions, double* sf_total_re, double* sf_total_im)
 {
     if (!h) return merr(CEG_ERR_INVALID, "bad argument");
+    if (h->poisoned) return refuse_poisoned();
     Guard guard(h->device);
     if (!guard.ok) return merr(CEG_ERR_HIP, "hipSetDevice failed");
     if (hipStreamSynchronize(h->stream) != hipSuccess) return merr(CEG_ERR_HIP, "stream synchronisation failed");

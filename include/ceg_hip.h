@@ -370,6 +370,13 @@ CEG_API int ceg_pairs_neighbour_cells(ceg_pairs_t* handle, int32_t nb[3]);
  *               coulomb_grid NULL when the framework carries no charges.  The handles must outlive this object.
  *  kind_charge  [nkinds] e;  mat, invmat: MC cell (= supercell), column-major;  rules / rule_offset / coulombic as ceg_pairs_create
  *  kvec_ijk, kfactors, sf_re, sf_im, nk, ks, ewald_invmat as ceg_recip_create (nk = 0: no Ewald summation)
+ *
+ * Threading: a handle is NOT thread-safe -- one Markov chain, one caller at a time (the reference's update_mc! is not either);
+ * different handles may be driven from different threads.
+ * Errors: accept / insert / remove keep a host mirror (molecule table, free atom slots, neighbour-cell lists) in step with the
+ * device state.  If one of them fails after it has started to change either side (kernel launch failure, allocation failure
+ * while growing the arrays or rebuilding the cells) the handle is marked inconsistent: every later call except
+ * ceg_mc_set_guests and ceg_mc_destroy returns CEG_ERR_HIP, and ceg_mc_set_guests rebuilds both sides from scratch.
  */
 typedef struct ceg_mc ceg_mc_t;
 

@@ -1,20 +1,33 @@
 """Grid comparison used by the parity tests, smoke() and bench.py's self-check (test
 infrastructure).  Tolerance: north_star's 1e-6 relative on every stored value, NaN / Inf /
 sentinel (|x| >= 1.9e7 file units, i.e. the 2e7 clamp of grids.jl:120-125) patterns must be
-IDENTICAL.  A tiny absolute floor (1e-9 x the channel's median magnitude) covers the rare
-point where positive and negative pair terms cancel to ~1e-9 of their size, so that the FP64
-summation order becomes visible."""
+IDENTICAL.  A tiny absolute floor (FLOOR x the channel's median magnitude; 1e-11 since round 3,
+1e-9 before) covers the rare point where positive and negative pair terms cancel to ~1e-10 of
+their size, so that the FP64 summation order becomes visible.  Channel 0 (the energy north_star's
+tolerance is quoted on) can be checked with NO floor: see `floor0`."""
 from __future__ import annotations
 
 import numpy as np
 
+import os
+
 RTOL = 1e-6
 SENTINEL = 1.9e7
+FLOOR = float(os.environ.get("CEG_COMPARE_FLOOR", "1e-11"))
 
 
-def compare_grids(got: np.ndarray, ref: np.ndarray, what: str = "grid", rtol: float = RTOL, sentinel: float = SENTINEL):
+def compare_grids(got: np.ndarray, ref: np.ndarray, what: str = "grid", rtol: float = RTOL, sentinel: float = SENTINEL,
+                  floor: float = None, floor0: float = None):
     """got/ref: float arrays with the channel as FIRST axis.  Returns the max relative error over
-    regular points; raises AssertionError with a diagnostic otherwise."""
+    regular points; raises AssertionError with a diagnostic otherwise.  `floor` (default FLOOR) is the
+    absolute allowance as a fraction of the channel's median magnitude, `floor0` the one for channel 0 (default: the
+    same; the fixture-grid tests pass 0.0 -- every stored energy within rtol of the oracle's, no allowance at all.
+    Synthetic systems with +q / -q atoms at equal distances from a grid point cannot: the oracle's wrap arithmetic
+    leaves 1e-17 of a term there where the image-list arithmetic gives an exact 0)."""
+    if floor is None:
+        floor = FLOOR
+    if floor0 is None:
+        floor0 = floor
     assert got.shape == ref.shape, f"{what}: shape {got.shape} vs {ref.shape}"
     nan_g, nan_r = np.isnan(got), np.isnan(ref)
     assert np.array_equal(nan_g, nan_r), f"{what}: NaN pattern differs at {int((nan_g != nan_r).sum())} values"
@@ -32,7 +45,7 @@ def compare_grids(got: np.ndarray, ref: np.ndarray, what: str = "grid", rtol: fl
         assert np.all(np.isfinite(g)), f"{what}: channel {c} has non-finite values where the oracle is finite"
         scale = float(np.median(np.abs(r)))
         diff = np.abs(g - r)
-        tol = rtol * np.abs(r) + 1e-9 * scale
+        tol = rtol * np.abs(r) + (floor0 if c == 0 else floor) * scale
         bad = diff > tol
         if bad.any():
             q = int(np.argmax(diff - tol))

@@ -113,3 +113,68 @@ def test_cyclic_plan_shapes():
     assert cyclic_plan(218, 8, 0) is None            # falls back to contiguous slabs
     q = cyclic_plan(64, 8, 3, nchunks=4)             # only 2 chunks keep m a multiple of the tile edge
     assert q.nchunks == 2 and q.m == 4
+
+
+def _autotune_worker(rank, world, port, outdir):
+    for p in (str(ROOT / "crystalenergygrids.jl_amd"), str(ROOT)):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import json
+        import time
+        from ceg_hip.distributed import PipelinedGather, autotune_exchange, cyclic_plan
+        nx, ny, nz = 32, 3, 5
+        state = {}
+
+        def setup(label):
+            nch, mode = int(label.split()[0]), label.split(", ")[1]
+            if label == "4 chunks, inplace" and rank == 1:
+                raise RuntimeError("injected: this candidate fails on rank 1 only")
+            if label == "2 chunks, staged":
+                raise RuntimeError("injected: this candidate fails everywhere")
+            cyc = cyclic_plan(nx, world, rank, nchunks=nch, align=1)
+            loc = torch.zeros((cyc.nchunks, 8, cyc.m, ny, nz))
+            full = torch.full((8, nx, ny, nz), float("nan"))
+            state.update(cyc=cyc, loc=loc, full=full, pipe=PipelinedGather(cyc, [full], [loc], mode=mode), label=label)
+
+        def step():
+            def launch(j, ib, ie, blocks):
+                if state["label"] == "2 chunks, inplace":
+                    raise RuntimeError("injected: the first step fails (on every rank, before its first collective)")
+                if state["label"].startswith("8"):
+                    time.sleep(0.01)                      # the 8-chunk candidates are the slow ones
+                blocks[0].copy_(torch.arange(ib, ie, dtype=torch.float32)[None, :, None, None].expand(8, ie - ib, ny, nz))
+            state["pipe"].run(launch)
+
+        labels = [f"{n} chunks, {m}" for n in (8, 4, 2) for m in ("staged", "inplace")]
+        best, res = autotune_exchange(labels, setup, step, lambda: None, torch.device("cpu"), log=lambda m: None)
+        # whatever was chosen must produce the right grid on this rank
+        setup(best)
+        step()
+        ok = bool(torch.equal(state["full"], torch.arange(nx, dtype=torch.float32)[None, :, None, None].expand(8, nx, ny, nz)))
+        with open(os.path.join(outdir, f"autotune{rank}.json"), "w") as fh:
+            json.dump({"best": best, "results": res, "grid_ok": ok}, fh)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_autotune_survives_failing_candidates(tmp_path):
+    """bench.py --gather auto: a candidate that raises -- during set-up on one rank only or on all ranks, or inside its first
+    step -- is dropped on EVERY rank, the ranks end with the same choice and that choice works.  (A rank
+    that dies INSIDE a step while its peers already wait in a collective cannot be rescued in-process: the default does not
+    autotune.)"""
+    import json
+    world = 2
+    mp.spawn(_autotune_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    out = [json.loads((tmp_path / f"autotune{r}.json").read_text()) for r in range(world)]
+    assert out[0]["best"] == out[1]["best"] == "4 chunks, staged"
+    for o in out:
+        assert o["grid_ok"]
+        r = o["results"]
+        assert r["4 chunks, inplace"] is None and r["2 chunks, staged"] is None and r["2 chunks, inplace"] is None
+        assert r["8 chunks, staged"] > r["4 chunks, staged"] > 0 and r["8 chunks, inplace"] is not None
+    assert out[0]["results"] == out[1]["results"]            # max over ranks: identical numbers everywhere

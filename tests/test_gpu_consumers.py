@@ -307,6 +307,39 @@ def test_mc_insertions_and_removals(hip_lib, tmp_path):
         ceg.setdir_RASPA(Path(__file__).parent / "golden" / "raspa")
 
 
+def test_mc_handle_refuses_work_after_a_failed_update(hip_lib, tmp_path, monkeypatch):
+    """accept / insert / remove change the host mirror before the launch is known to have succeeded; when one of them fails
+    after that point (injected: CEG_HIP_MC_INJECT_FAILURE) the handle must refuse every later call -- instead of answering from
+    host and device state that no longer agree -- until ceg_mc_set_guests (refresh) rebuilds both."""
+    from ceg_hip.energy import DeviceMonteCarlo
+    try:
+        M, mc = _mc_setup(tmp_path)
+        M.baseline_energy(mc)
+        dev = DeviceMonteCarlo(mc)
+        ref = dev.trial((1, 0), np.empty((0, 3, 3)))[0].copy()
+        pos0, sf0 = dev.state()
+        for what, call in (("accept", lambda: dev.accept((1, 0), mc.positions[1][0] + 0.1)),
+                           ("insert", lambda: dev.insert(0, np.array([[3.0, 4.0, 5.0]]))),
+                           ("remove", lambda: dev.remove((1, 1)))):
+            monkeypatch.setenv("CEG_HIP_MC_INJECT_FAILURE", what)
+            with pytest.raises(_abi.CegError) as ei:
+                call()
+            assert ei.value.code == -3, what                       # CEG_ERR_HIP
+            monkeypatch.delenv("CEG_HIP_MC_INJECT_FAILURE")
+            for later in (lambda: dev.trial((1, 0), np.empty((0, 3, 3))), lambda: dev.accept((1, 0), mc.positions[1][0]),
+                          lambda: dev.trial_insert(0, np.zeros((1, 1, 3))), lambda: dev.state()):
+                with pytest.raises(_abi.CegError) as ei:
+                    later()
+                assert ei.value.code == -3 and "ceg_mc_set_guests" in str(ei.value), what
+            dev.refresh()                                          # the host-side mc was never touched: same state as before
+            np.testing.assert_allclose(dev.trial((1, 0), np.empty((0, 3, 3)))[0], ref, rtol=1e-12, atol=1e-9)
+            pos, sf = dev.state()
+            assert np.array_equal(pos, pos0) and np.abs(sf - sf0).max() <= 1e-12 * np.abs(sf0).max()
+        dev.close()
+    finally:
+        ceg.setdir_RASPA(Path(__file__).parent / "golden" / "raspa")
+
+
 # ------------------------------------------------------------------ neighbour cells of the device-resident MC state
 class _RawMc:
     """ceg_mc_* through the C ABI on explicit tables: no framework grids, no Ewald summation -- the guest-guest term alone."""
