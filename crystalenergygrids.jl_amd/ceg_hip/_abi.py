@@ -86,6 +86,16 @@ PROTOTYPES = {
         C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double,
         C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
         C.c_int32, C.c_void_p]),
+    "ceg_plan_create_multi": (C.c_int, [
+        C.POINTER(C.c_void_p), C.c_int32,
+        c_double_p, c_int64_p, c_double_p, C.c_int64,
+        c_double_p, c_double_p, C.c_int32, C.c_double, C.c_double,
+        C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_double,
+        c_int32_p, c_double_p, c_double_p, c_double_p]),
+    "ceg_plan_num_probes": (C.c_int, [C.c_void_p]),
+    "ceg_plan_build_multi": (C.c_int, [
+        C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double,
+        C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "ceg_plan_eval_points": (C.c_int, [
         C.c_void_p, C.c_int32, C.c_int32, c_double_p, C.c_int64, c_double_p]),
     "ceg_interp_create": (C.c_int, [

@@ -111,3 +111,75 @@ class GridPlan:
         w = {"vdw": 0, "coulomb": 1}[which]
         _abi.check(self._lib, self._lib.ceg_plan_eval_points(self._h, w, algo, _abi.dptr(pts), len(pts), _abi.dptr(out)))
         return out
+
+
+class MultiGridPlan:
+    """The K VdW probes (one grid each) + optionally the charges of ONE framework made resident on one GPU
+    (``ceg_plan_create_multi``): what ``setup_RASPA`` needs for a molecule -- one ``create_grid_vdw`` per distinct
+    guest atom and one ``create_grid_coulomb`` (raspa.jl:497-520) -- from one lattice-image list in one pass.
+
+    ``probes``: ProbeSystems of the same framework (same positions / kinds / cutoff), one per probe atom, every one
+    Lennard-Jones-only against the kinds present (``_abi.CegError`` with code -5 otherwise: build that probe alone)."""
+    MAX_PROBES = 4
+
+    def __init__(self, cset: GridCoordinatesSetup, probes, coulomb: Optional[ProbeSystem] = None, alpha: float = 0.0,
+                 device: int = 0):
+        probes = list(probes)
+        if not 1 <= len(probes) <= self.MAX_PROBES:
+            raise ValueError(f"1..{self.MAX_PROBES} probes per multi-probe plan")
+        ref = probes[0]
+        for other in probes[1:] + ([coulomb] if coulomb is not None else []):
+            if other.positions.shape != ref.positions.shape or not np.array_equal(other.positions, ref.positions):
+                raise ValueError("all probes of a multi-probe plan must share the same framework")
+        for other in probes[1:]:
+            if not np.array_equal(other.atomkinds, ref.atomkinds) or other.cutoff2 != ref.cutoff2:
+                raise ValueError("all probes of a multi-probe plan must share atom kinds and cutoff")
+        self._lib = _abi.load_library()
+        self.cset, self.device = cset, device
+        self.nprobes = len(probes)
+        self.has_coulomb = coulomb is not None
+        pos = np.ascontiguousarray(ref.positions, dtype=np.float64)
+        mat, invmat = _matT(ref.mat), _matT(ref.invmat)
+        ortho, safemin2 = ref.periodic_setup()
+        dims, size, shift, delta = _grid_args(cset)
+        kinds = np.ascontiguousarray(ref.atomkinds, dtype=np.int64)
+        tables = []
+        for pr in probes:
+            pr.forcefield.check_vdw_grid(pr.probe, np.unique(pr.atomkinds))
+            tables.append(pr.forcefield.rule_table(pr.probe))
+        rules_pp = (C.c_void_p * self.nprobes)(*[t[0].ctypes.data for t in tables])
+        offs_pp = (C.c_void_p * self.nprobes)(*[t[1].ctypes.data for t in tables])
+        q = np.ascontiguousarray(coulomb.charges, dtype=np.float64) if coulomb is not None else None
+        handle = C.c_void_p()
+        rc = self._lib.ceg_plan_create_multi(C.byref(handle), device, _abi.dptr(pos), _abi.i64ptr(kinds), _abi.dptr(q) if q is not None else None,
+                                             len(pos), _abi.dptr(mat), _abi.dptr(invmat), int(ortho), safemin2, ref.cutoff2,
+                                             self.nprobes, rules_pp, offs_pp, ref.forcefield.nkinds, float(alpha),
+                                             _abi.i32ptr(dims), _abi.dptr(size), _abi.dptr(shift), _abi.dptr(delta))
+        _abi.check(self._lib, rc)
+        self._h = handle
+        self.npoints = cset.npoints
+        self.plane = self.npoints[1] * self.npoints[2]
+
+    @property
+    def num_images(self) -> int:
+        return int(self._lib.ceg_plan_num_images(self._h))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.ceg_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def build(self, d_vdw, d_coulomb: int, channel_stride: int, i_begin: int, i_end: int, i_origin: int = 0, stream: int = 0) -> None:
+        """``d_vdw``: device pointer per probe (0 / None = skip that grid), ``d_coulomb``: device pointer or 0.  Asynchronous."""
+        d_vdw = list(d_vdw) + [0] * (self.nprobes - len(d_vdw))
+        ptrs = (C.c_void_p * self.nprobes)(*[int(x) if x else None for x in d_vdw])
+        lv, tv = vdw_scaling()
+        lc, tc = coulomb_scaling()
+        _abi.check(self._lib, self._lib.ceg_plan_build_multi(self._h, lv, tv, lc, tc, i_begin, i_end, ptrs, int(d_coulomb) if d_coulomb else None,
+                                                             channel_stride, i_origin, stream))

@@ -75,6 +75,7 @@ struct ceg_plan {
     std::vector<int32_t> h_kind;           // 0-based, -1 if none
     std::vector<DevRule> h_rules;
     std::vector<int32_t> h_offset;
+    std::vector<int32_t> h_offset_union;   // multi-probe plans: offsets of a table with one entry per kind that has a rule with ANY probe
     int32_t nkinds = 0;
     // device
     double4* d_atoms = nullptr;
@@ -100,6 +101,19 @@ struct ceg_plan {
     bool fast_ewald = false;     // alpha*cutoff within the erfcx polynomial's domain
     bool ew2 = false;            // r^2-indexed Ewald tables built (hot-loop variant EWK = 2)
     double* d_ew2 = nullptr;
+    // multi-probe plans (ceg_plan_create_multi): the rule tables of every probe; d_pc holds probe 0 in its single-probe slots and
+    // all of them in rtm / fastm, d_pc_probe[p] is the same block with probe p in the single-probe slots (launches of one probe)
+    struct ProbeTab {
+        std::vector<DevRule> rules;
+        std::vector<int32_t> offset;
+        std::vector<FastVdw> fast;
+        DevRule* d_rules = nullptr;
+        int32_t* d_offset = nullptr;
+        FastVdw* d_fast = nullptr;
+        PlanConst* d_pc = nullptr;
+    };
+    int nprobes = 0;             // 0: ordinary plan
+    std::vector<ProbeTab> probes;
 };
 
 namespace {
@@ -335,6 +349,9 @@ int build_images(ceg_plan* p)
         nb[a] = std::max(1, (int)std::floor((hi[a] - lo[a]) / target[a]));
         bin[a] = (hi[a] - lo[a]) / nb[a];
     }
+    // "the kind has a VdW rule": with the plan's probe, or with any probe of a multi-probe plan
+    const std::vector<int32_t>& off = p->nprobes > 0 ? p->h_offset_union : p->h_offset;
+    auto kind_has_rule = [&](int32_t k) { return k >= 0 && k + 1 < (int32_t)off.size() && off[k + 1] > off[k]; };
     struct Img { double x, y, z, q; int32_t kind; int32_t bin; int32_t atom; };
     std::vector<Img> imgs;
     imgs.reserve((size_t)p->natoms * 8);
@@ -345,9 +362,7 @@ int build_images(ceg_plan* p)
             // a VdW-only plan (create_grid_vdw: one probe atom against the framework): atoms whose kind has no rule for the probe
             // contribute exact zeros (an empty rule run, src/interactions.jl:599-610) -- they need not be staged at all
             // (Si / Al against Ar or Na in the fixture force field: a third of the framework)
-            const int32_t k = p->h_kind[a];
-            const bool hasvdw = k >= 0 && k + 1 < (int32_t)p->h_offset.size() && p->h_offset[k + 1] > p->h_offset[k];
-            if (!hasvdw) continue;
+            if (!kind_has_rule(p->h_kind[a])) continue;
         }
         const double pa[3] = {p->h_pos[3 * a], p->h_pos[3 * a + 1], p->h_pos[3 * a + 2]};
         double fmin[3] = {1e300, 1e300, 1e300}, fmax[3] = {-1e300, -1e300, -1e300};
@@ -390,8 +405,7 @@ int build_images(ceg_plan* p)
                     im.kind = -1;
                     if (p->has_rules) {
                         const int32_t k = p->h_kind[a];
-                        const bool hasvdw = k >= 0 && k + 1 < (int32_t)p->h_offset.size() && p->h_offset[k + 1] > p->h_offset[k];
-                        im.kind = k < 0 ? -1 : (k | (hasvdw ? (1 << 25) : 0));
+                        im.kind = k < 0 ? -1 : (k | (kind_has_rule(k) ? (1 << 25) : 0));
                     }
                     im.bin = (b[0] * nb[1] + b[1]) * nb[2] + b[2];
                     im.atom = (int32_t)a;
@@ -640,19 +654,30 @@ int check_common(const double* pos, int64_t natoms, const double* mat, const dou
 
 }  // namespace
 
-extern "C" int ceg_plan_create(ceg_plan_t** plan, int32_t device,
-                               const double* pos, const int64_t* atomkind, const double* charge,
-                               int64_t natoms,
-                               const double mat[9], const double invmat[9],
-                               int32_t ortho, double safemin2, double cutoff2,
-                               const ceg_rule_t* rules, const int32_t* rule_offset, int32_t nkinds,
-                               double alpha,
-                               const int32_t dims[3], const double size[3], const double shift[3],
-                               const double delta[3])
+// nprobes == 0: the ordinary plan of ceg_plan_create (rules / rule_offset may be NULL: Coulomb only);
+// nprobes >= 1: a multi-probe plan, mrules / moffset [nprobes], every probe Lennard-Jones-only for the kinds present
+static int create_impl(ceg_plan_t** plan, int32_t device,
+                       const double* pos, const int64_t* atomkind, const double* charge,
+                       int64_t natoms,
+                       const double mat[9], const double invmat[9],
+                       int32_t ortho, double safemin2, double cutoff2,
+                       const ceg_rule_t* rules, const int32_t* rule_offset, int32_t nkinds,
+                       int32_t nprobes, const ceg_rule_t* const* mrules, const int32_t* const* moffset,
+                       double alpha,
+                       const int32_t dims[3], const double size[3], const double shift[3],
+                       const double delta[3])
 {
     if (!plan) return fail(CEG_ERR_INVALID, "plan is NULL");
     *plan = nullptr;
     if (int rc = check_common(pos, natoms, mat, invmat, dims, size, shift, delta)) return rc;
+    if (nprobes < 0 || nprobes > CEG_MAX_PROBES) return fail(CEG_ERR_INVALID, "nprobes = %d outside 1..%d", nprobes, CEG_MAX_PROBES);
+    if (nprobes > 0) {
+        if (!mrules || !moffset || !atomkind || nkinds <= 0) return fail(CEG_ERR_INVALID, "rule tables / atomkind missing");
+        for (int q = 0; q < nprobes; ++q)
+            if (!mrules[q] || !moffset[q]) return fail(CEG_ERR_INVALID, "rule table of probe %d is NULL", q);
+        rules = mrules[0];
+        rule_offset = moffset[0];
+    }
     const bool trace = std::getenv("CEG_HIP_TRACE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     auto stamp = [&](const char* what) {
@@ -701,6 +726,29 @@ extern "C" int ceg_plan_create(ceg_plan_t** plan, int32_t device,
         if (int rc = convert_rules(p, rules, rule_offset, nkinds)) {
             delete p;
             return rc;
+        }
+        if (nprobes > 0) {
+            // every probe through the same classification; the plan keeps probe 0 in its single-probe fields and the union of the
+            // probes' "kind has a rule" sets in h_offset (what build_images turns into the per-image flag)
+            p->nprobes = nprobes;
+            p->probes.resize(nprobes);
+            std::vector<int32_t> any(nkinds, 0);
+            for (int q = 0; q < nprobes; ++q) {
+                if (q > 0)
+                    if (int rc = convert_rules(p, mrules[q], moffset[q], nkinds)) { delete p; return rc; }
+                if (p->vdwk != 1 || p->r_exact2 != CEG_R_EXACT2) {
+                    delete p;
+                    return fail(CEG_ERR_UNSUPPORTED, "multi-probe plans take Lennard-Jones-only probes (probe %d has another rule class "
+                                                     "against a framework kind that is present): build that grid with its own plan", q);
+                }
+                ceg_plan::ProbeTab& t = p->probes[q];
+                t.rules = p->h_rules; t.offset = p->h_offset; t.fast = p->h_fast;
+                for (int32_t k = 0; k < nkinds; ++k) any[k] |= (t.offset[k + 1] > t.offset[k]) ? 1 : 0;
+            }
+            p->h_rules = p->probes[0].rules; p->h_fast = p->probes[0].fast;
+            p->h_offset_union.assign(nkinds + 1, 0);
+            for (int32_t k = 0; k < nkinds; ++k) p->h_offset_union[k + 1] = p->h_offset_union[k] + any[k];
+            p->h_offset = p->probes[0].offset;
         }
     }
     // culling needs: finite cutoff, every perpendicular width >= 2*cutoff (two images of one atom
@@ -800,7 +848,30 @@ extern "C" int ceg_plan_create(ceg_plan_t** plan, int32_t device,
                 if (!rc) p->vdwk = 3;
             }
         }
+        if (!rc && p->nprobes > 0) {
+            if (p->has_charge && !p->ew2)
+                rc = fail(CEG_ERR_UNSUPPORTED, "multi-probe plans with charges need the r^2-indexed Ewald tables (alpha * cutoff <= 5)");
+            hc.nprobes = p->nprobes;
+            for (int q = 0; q < p->nprobes && !rc; ++q) {
+                ceg_plan::ProbeTab& t = p->probes[q];
+                rc = upload(&t.d_rules, t.rules.data(), t.rules.size());
+                if (!rc) rc = upload(&t.d_offset, t.offset.data(), t.offset.size());
+                if (!rc) rc = upload(&t.d_fast, t.fast.data(), t.fast.size());
+                hc.rtm[q] = RuleTable{t.d_rules, t.d_offset, p->nkinds};
+                hc.fastm[q] = t.d_fast;
+            }
+            for (int q = 0; q < p->nprobes && !rc; ++q) {        // the block with probe q in the single-probe slots
+                PlanConst hq = hc;
+                hq.rt = hc.rtm[q];
+                hq.fastvdw = hc.fastm[q];
+                rc = upload(&p->probes[q].d_pc, &hq, 1);
+            }
+            hc.rt = hc.rtm[0];
+            hc.fastvdw = hc.fastm[0];
+        }
         if (!rc) rc = upload(&p->d_pc, &hc, 1);
+    } else if (!rc && p->nprobes > 0) {
+        rc = fail(CEG_ERR_UNSUPPORTED, "multi-probe plans need every perpendicular cell width >= 2*cutoff (what a ProbeSystem guarantees)");
     }
     stamp("function tables, constants");
     if (rc) {
@@ -811,6 +882,33 @@ extern "C" int ceg_plan_create(ceg_plan_t** plan, int32_t device,
     return CEG_OK;
 }
 
+extern "C" int ceg_plan_create(ceg_plan_t** plan, int32_t device,
+                               const double* pos, const int64_t* atomkind, const double* charge,
+                               int64_t natoms,
+                               const double mat[9], const double invmat[9],
+                               int32_t ortho, double safemin2, double cutoff2,
+                               const ceg_rule_t* rules, const int32_t* rule_offset, int32_t nkinds,
+                               double alpha,
+                               const int32_t dims[3], const double size[3], const double shift[3],
+                               const double delta[3])
+{
+    return create_impl(plan, device, pos, atomkind, charge, natoms, mat, invmat, ortho, safemin2, cutoff2, rules, rule_offset, nkinds, 0,
+                       nullptr, nullptr, alpha, dims, size, shift, delta);
+}
+
+extern "C" int ceg_plan_create_multi(ceg_plan_t** plan, int32_t device, const double* pos, const int64_t* atomkind, const double* charge,
+                                     int64_t natoms, const double mat[9], const double invmat[9], int32_t ortho, double safemin2,
+                                     double cutoff2, int32_t nprobes, const ceg_rule_t* const* rules,
+                                     const int32_t* const* rule_offset, int32_t nkinds, double alpha, const int32_t dims[3],
+                                     const double size[3], const double shift[3], const double delta[3])
+{
+    if (nprobes < 1) return fail(CEG_ERR_INVALID, "nprobes = %d < 1", nprobes);
+    return create_impl(plan, device, pos, atomkind, charge, natoms, mat, invmat, ortho, safemin2, cutoff2, nullptr, nullptr, nkinds, nprobes,
+                       rules, rule_offset, alpha, dims, size, shift, delta);
+}
+
+extern "C" int ceg_plan_num_probes(const ceg_plan_t* p) { return p ? p->nprobes : 0; }
+
 extern "C" int ceg_plan_destroy(ceg_plan_t* p)
 {
     if (!p) return CEG_OK;
@@ -820,6 +918,8 @@ extern "C" int ceg_plan_destroy(ceg_plan_t* p)
                       (void*)p->d_imgkind, (void*)p->d_imgatom, (void*)p->d_binstart, (void*)p->d_pc, (void*)p->d_erfcx,
                       (void*)p->d_exp2, (void*)p->d_fast, (void*)p->d_ew2, (void*)p->d_bk2})
         cached_free(ptr);
+    for (auto& t : p->probes)
+        for (void* ptr : {(void*)t.d_rules, (void*)t.d_offset, (void*)t.d_fast, (void*)t.d_pc}) cached_free(ptr);
     delete p;
     return CEG_OK;
 }
@@ -916,6 +1016,71 @@ extern "C" int ceg_plan_build_fused(ceg_plan_t* plan, double lambda_vdw, double 
 {
     return build_common(plan, MODE_FUSED, lambda_vdw, threshold_vdw, lambda_coulomb, threshold_coulomb, i_begin,
                         i_end, d_out_vdw, d_out_coulomb, channel_stride, i_origin, algo, stream);
+}
+
+// K VdW grids + the Coulomb grid of one framework from one image list (the grids setup_RASPA asks for one after the other,
+// src/raspa.jl:497-520).  The requested set is cut into launches of the multi-probe kernels: with the Coulomb grid the first two
+// probes ride in the fused launch (48 accumulator registers: 3 waves per SIMD), the others in VdW launches of up to four probes.
+// Whatever the cut, every grid is bit-identical to the one a launch of that grid alone produces (same per-pair arithmetic, same
+// order of the sums; ceg_kernels.hip).
+extern "C" int ceg_plan_build_multi(ceg_plan_t* p, double lambda_vdw, double threshold_vdw, double lambda_coulomb, double threshold_coulomb,
+                                    int32_t i_begin, int32_t i_end, float* const* d_out_vdw, float* d_out_coulomb,
+                                    int64_t channel_stride, int32_t i_origin, void* stream)
+{
+    if (!p) return fail(CEG_ERR_INVALID, "plan is NULL");
+    if (p->nprobes < 1) return fail(CEG_ERR_INVALID, "not a multi-probe plan (ceg_plan_create_multi)");
+    if (i_begin < 0 || i_end > p->g.dims[0] + 1 || i_begin > i_end)
+        return fail(CEG_ERR_INVALID, "bad x-plane range [%d,%d) for dims[0]+1 = %d", i_begin, i_end, p->g.dims[0] + 1);
+    if (i_origin > i_begin) return fail(CEG_ERR_INVALID, "i_origin %d > i_begin %d", i_origin, i_begin);
+    const int64_t plane = (int64_t)(p->g.dims[1] + 1) * (p->g.dims[2] + 1);
+    if (channel_stride < (int64_t)(i_end - i_origin) * plane) return fail(CEG_ERR_INVALID, "channel_stride %lld too small", (long long)channel_stride);
+    if (d_out_coulomb && !p->has_charge) return fail(CEG_ERR_INVALID, "plan was created without charges");
+    std::vector<int> req;
+    for (int q = 0; q < p->nprobes; ++q)
+        if (d_out_vdw && d_out_vdw[q]) req.push_back(q);
+    if (req.empty() && !d_out_coulomb) return CEG_OK;
+    Output base{};
+    base.channel_stride = channel_stride;
+    base.i_origin = i_origin;
+    base.i_begin = i_begin;
+    base.i_end = i_end;
+    base.lambda_vdw = lambda_vdw;
+    base.thr_vdw = threshold_vdw;
+    base.lambda_coulomb = lambda_coulomb;
+    base.thr_coulomb = threshold_coulomb;
+    DeviceGuard guard(p->device);
+    if (!guard.ok) return fail(CEG_ERR_HIP, "hipSetDevice(%d) failed", p->device);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipSuccess;
+    auto single = [&](int mode, int q) {          // one probe (q >= 0) and / or the Coulomb grid: the single-probe kernels
+        Output o = base;
+        o.vdw = q >= 0 ? d_out_vdw[q] : nullptr;
+        o.coulomb = mode != MODE_VDW ? d_out_coulomb : nullptr;
+        return launch_culled(mode, q >= 0 ? p->probes[q].d_pc : p->d_pc, p->g, 1, 2, o, Points{nullptr, 0}, st);
+    };
+    auto multi = [&](int mode, const int* idx, int np) {
+        Output o = base;
+        for (int t = 0; t < np; ++t) { o.vdwm[t] = d_out_vdw[idx[t]]; o.probe_idx[t] = idx[t]; }
+        o.coulomb = mode == MODE_FUSED ? d_out_coulomb : nullptr;
+        return launch_culled_multi(mode, np, p->d_pc, p->g, o, st);
+    };
+    size_t at = 0;
+    if (d_out_coulomb) {
+        int fused_np = CEG_MAX_PROBES_FUSED;          // probes that share the Coulomb launch (CEG_HIP_MULTI_FUSED_NP = 0 | 1 | 2: measurement aid)
+        if (const char* env = std::getenv("CEG_HIP_MULTI_FUSED_NP")) fused_np = std::max(0, std::min(CEG_MAX_PROBES_FUSED, atoi(env)));
+        fused_np = std::min<int>(fused_np, (int)req.size());
+        if (fused_np >= 2) e = multi(MODE_FUSED, &req[0], 2);
+        else if (fused_np == 1) e = single(MODE_FUSED, req[0]);
+        else e = single(MODE_COULOMB, -1);
+        at = (size_t)std::min(fused_np, 2);
+    }
+    while (e == hipSuccess && at < req.size()) {
+        const int n = (int)std::min<size_t>(CEG_MAX_PROBES, req.size() - at);
+        e = n == 1 ? single(MODE_VDW, req[at]) : multi(MODE_VDW, &req[at], n);
+        at += (size_t)n;
+    }
+    if (e != hipSuccess) return fail(CEG_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    return CEG_OK;
 }
 
 extern "C" int ceg_plan_eval_points(ceg_plan_t* p, int32_t which, int32_t algo, const double* points,

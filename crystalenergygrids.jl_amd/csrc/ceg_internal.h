@@ -43,8 +43,7 @@ struct Geom {
 
 // A multi-probe plan holds the rule tables of up to CEG_MAX_PROBES probe atoms (one VdW grid each) of ONE framework: the K VdW
 // grids + the Coulomb grid of a setup_RASPA call (src/raspa.jl:497-520 builds them one after the other) come out of one pass
-// over one image list.
-constexpr int CEG_MAX_PROBES = 4;
+// over one image list.  (CEG_MAX_PROBES = 4: include/ceg_hip.h)
 
 // Where results go.  Grid mode: 8 float channels per grid, written with
 // _set_gridpoint! semantics (src/grids.jl:118-135).  Raw mode (eval_points): the 8 FP64

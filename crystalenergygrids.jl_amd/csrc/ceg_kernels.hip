@@ -162,6 +162,22 @@ __device__ __forceinline__ void ewald_terms_poly(double alpha, double charge, do
     p3 = charge * (-er2a2 * (15.0 + 10.0 * r2a2 + 4.0 * (r2a2 * r2a2)) - 15.0 * erfar) / (r5 * r2);
 }
 
+// Out-of-line forms for the exact path of the multi-probe kernels: with three accumulator sets live (48 registers) the inlined
+// literal formulas -- IEEE divisions, sqrt, the exp and erfcx polynomials -- pushed the kernel over 128 VGPRs and the exact path
+// spilled ~90 registers per pair; as calls their temporaries live in the callee's scratch registers.  Same arithmetic.
+__device__ __attribute__((noinline)) double4 ewald_terms_poly_call(double alpha, double charge, double r2)
+{
+    double v, p1, p2, p3;
+    ewald_terms_poly(alpha, charge, r2, v, p1, p2, p3);
+    return make_double4(v, p1, p2, p3);
+}
+__device__ __attribute__((noinline)) double4 lj_terms_call(const DevRule* __restrict__ rules, int rb, int re, double r2)
+{
+    double v, p1, p2, p3;
+    vdw_terms<true, true>(rules, rb, re, r2, v, p1, p2, p3);
+    return make_double4(v, p1, p2, p3);
+}
+
 // ------------------------------------------------------------------ result store
 // Base.clamp semantics: NaN passes through.
 __device__ __forceinline__ double clamp_julia(double x, double lo, double hi)
@@ -354,13 +370,13 @@ __global__ __launch_bounds__(256) void k_bruteforce(Geom g, AtomTable atoms, Rul
 // pairs closer than this (A^2) take the literal min-image arithmetic in the culled kernel
 // waves per SIMD the register allocator plans for, per variant (measured, profiles/r01_variant_waves.txt)
 #ifndef CEG_WAVES_MULTI_FUSED
-#define CEG_WAVES_MULTI_FUSED 3      // two probes + Coulomb: 48 accumulator registers; 4 waves per SIMD would need <= 128 VGPRs in all
+#define CEG_WAVES_MULTI_FUSED 4
 #endif
 #ifndef CEG_WAVES_MULTI_VDW
 #define CEG_WAVES_MULTI_VDW 4
 #endif
 #ifndef CEG_NW_MULTI_FUSED
-#define CEG_NW_MULTI_FUSED 6         // 6 waves x 64 x 112 B + 19.7 KB of tables = 69 KB: two workgroups = 12 waves = 3 per SIMD on a CU
+#define CEG_NW_MULTI_FUSED 8         // 8 waves x 64 x 96 B + 19.7 KB of tables + 8 KB = 77 KB: two workgroups per CU
 #endif
 constexpr int culled_waves(int mode, int vdwk, int ewk, int np = 1)
 {
@@ -408,7 +424,7 @@ struct __attribute__((aligned(16))) CandRec {
 // position, invmat*d, wrap, mat*f, neighbour search (periodic_distance2_literal) -- and evaluated
 // with the literal radial formulas.  Runs after the hot loop so that its registers do not
 // overlap the hot loop's.
-template <int MODE, bool FASTEW, bool LJSLOW, bool EWSCALED, bool BKSCALED, int NP, typename Rec>
+template <int MODE, bool FASTEW, bool LJSLOW, bool EWSCALED, bool BKSCALED, int NP, bool DOV = true, bool DOC = true, typename Rec>
 __device__ __forceinline__ void slow_pairs(const PlanConst* __restrict__ pc, unsigned long long cands, int lane,
                                            double px, double py, double pz,
                                            const Rec* s_rec,
@@ -428,7 +444,7 @@ __device__ __forceinline__ void slow_pairs(const PlanConst* __restrict__ pc, uns
         const double r2 = periodic_distance2_literal(g, dx, dy, dz);
         if (r2 >= g.cutoff2) continue;
         if constexpr (NP > 1) {
-            if (mt & META_HASVDW) {           // multi-probe plan: the rule run of the image's kind in every probe's table
+            if (DOV && (mt & META_HASVDW)) {  // multi-probe plan: the rule run of the image's kind in every probe's table
                 const int kd = mt & META_KINDMASK;
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
@@ -436,10 +452,8 @@ __device__ __forceinline__ void slow_pairs(const PlanConst* __restrict__ pc, uns
                     const int rb = rtp.offset[kd], re = rtp.offset[kd + 1];
                     if (re == rb) continue;       // no rule for this probe: nothing is added (as in a single-probe launch, where the all-zero
                                                   // record of the hot loop adds exact zeros)
-                    double v, p1, p2, p3;
-                    vdw_terms<true, true>(rtp.rules, rb, re, r2, v, p1, p2, p3);
-                    p1 *= -1.0 / 6.0; p2 *= 1.0 / 48.0; p3 *= -1.0 / 480.0;
-                    accum_add(avm[p], v, p1, p2, p3, dx, dy, dz);
+                    const double4 T = lj_terms_call(rtp.rules, rb, re, r2);
+                    accum_add(avm[p], T.x, T.y * (-1.0 / 6.0), T.z * (1.0 / 48.0), T.w * (-1.0 / 480.0), dx, dy, dz);
                 }
             }
         } else if (MODE != MODE_COULOMB && (mt & META_HASVDW)) {
@@ -455,10 +469,13 @@ __device__ __forceinline__ void slow_pairs(const PlanConst* __restrict__ pc, uns
             }
             accum_add(av, v, p1, p2, p3, dx, dy, dz);
         }
-        if (MODE != MODE_VDW) {
+        if (MODE != MODE_VDW && DOC) {
             smallest_d2 = fmin(smallest_d2, r2);
             double v, p1, p2, p3;
-            if (FASTEW)
+            if constexpr (NP > 1) {
+                const double4 T = ewald_terms_poly_call(g.alpha, O.w, r2);
+                v = T.x; p1 = T.y; p2 = T.z; p3 = T.w;
+            } else if (FASTEW)
                 ewald_terms_poly(g.alpha, O.w, r2, v, p1, p2, p3);
             else
                 ewald_terms(g.alpha, O.w, r2, v, p1, p2, p3);
@@ -515,20 +532,22 @@ struct __attribute__((aligned(16))) CandRecS {
 };
 static_assert(sizeof(CandRecS) == 48, "candidate record layout");
 // multi-probe launches: the Lennard-Jones record (4 eps, sigma^2, sigma^6, shift) of the image's kind for each of the NP probes
+// (three doubles per probe -- 4 eps, sigma^6, shift; sigma^2 is not used by the hot loop -- so that the two-probe record is 96 B:
+// 8 waves x 64 x 96 B + the Ewald tables stay under half a CU's LDS)
 template <int NP>
 struct __attribute__((aligned(16))) CandRecM {
     Quad xyzq;
-    Quad ljm[NP];
+    double ljm[3 * NP + (NP & 1)];
     int32_t meta;
     int32_t atom;
     int32_t _pad[2];
 };
-static_assert(sizeof(CandRecM<2>) == 112 && sizeof(CandRecM<4>) == 176, "candidate record layout");
+static_assert(sizeof(CandRecM<2>) == 96 && sizeof(CandRecM<3>) == 128 && sizeof(CandRecM<4>) == 144, "candidate record layout");
 // the per-candidate VdW record of probe p, whatever the record type (so that branches the variant never takes still compile)
-template <int NP> __device__ __forceinline__ Quad lj_record(const CandRecM<NP>& r, int p) { return r.ljm[p]; }
+template <int NP> __device__ __forceinline__ Quad lj_record(const CandRecM<NP>& r, int p) { return Quad{r.ljm[3 * p], 0.0, r.ljm[3 * p + 1], r.ljm[3 * p + 2]}; }
 __device__ __forceinline__ Quad lj_record(const CandRec& r, int) { return r.lj; }
 __device__ __forceinline__ Quad lj_record(const CandRecS&, int) { return Quad{0.0, 0.0, 0.0, 0.0}; }
-template <int NP> __device__ __forceinline__ void set_lj_record(CandRecM<NP>& r, int p, Quad q) { r.ljm[p] = q; }
+template <int NP> __device__ __forceinline__ void set_lj_record(CandRecM<NP>& r, int p, Quad q) { r.ljm[3 * p] = q.x; r.ljm[3 * p + 1] = q.z; r.ljm[3 * p + 2] = q.w; }
 __device__ __forceinline__ void set_lj_record(CandRec& r, int, Quad q) { r.lj = q; }
 __device__ __forceinline__ void set_lj_record(CandRecS&, int, Quad) {}
 
@@ -1089,7 +1108,13 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK, NP), culled_waves(M
 #endif
             if (slow != 0ull) {
                 __builtin_amdgcn_wave_barrier();
-                slow_pairs<MODE, FASTEW, VDWK == 1, EW2, VDWK == 3 && MODE != MODE_COULOMB, NP>(pc, slow, lane, px, py, pz, s_rec, s_odd, avm, out.probe_idx, ac, smallest_d2);
+                if constexpr (MULTI && MODE == MODE_FUSED) {
+                    // two passes (the literal distance is redone): the registers of the Lennard-Jones and of the Ewald evaluation are
+                    // not needed at the same time beside the three accumulator sets
+                    slow_pairs<MODE, FASTEW, true, EW2, false, NP, true, false>(pc, slow, lane, px, py, pz, s_rec, s_odd, avm, out.probe_idx, ac, smallest_d2);
+                    slow_pairs<MODE, FASTEW, true, EW2, false, NP, false, true>(pc, slow, lane, px, py, pz, s_rec, s_odd, avm, out.probe_idx, ac, smallest_d2);
+                } else
+                    slow_pairs<MODE, FASTEW, VDWK == 1, EW2, VDWK == 3 && MODE != MODE_COULOMB, NP>(pc, slow, lane, px, py, pz, s_rec, s_odd, avm, out.probe_idx, ac, smallest_d2);
             }
         }
     }

@@ -239,6 +239,42 @@ CEG_API int ceg_plan_build_fused(ceg_plan_t* plan,
                          int32_t algo, void* stream);
 
 /*
+ * Multi-probe plans: ALL the grids of one setup from one pass.  setup_RASPA (src/raspa.jl:497-520) asks for one
+ * create_grid_vdw per distinct guest atom plus one create_grid_coulomb, all on the same framework, cutoff and grid geometry;
+ * here the K probes' rule tables go into ONE plan (one lattice-image list, one set of bins and function tables) and
+ * ceg_plan_build_multi computes the requested grids together: per candidate image one staging, one distance, one 1/r^2, K
+ * Lennard-Jones evaluations with K accumulator sets, one real-space Ewald evaluation.
+ *
+ *   nprobes       1 .. 4 (CEG_MAX_PROBES)
+ *   rules[q], rule_offset[q]   the flattened column ff.interactions[:, probe_q] as for ceg_plan_create (same nkinds for all).
+ *                 Every probe must be Lennard-Jones-only against the framework kinds that are present (at most one LJ rule per
+ *                 kind; NoInteraction / CoulombEwaldDirect count as none) -- CEG_ERR_UNSUPPORTED otherwise: a Buckingham or
+ *                 hard-sphere probe (a cation) gets its own ceg_plan_create plan.  charge may be NULL (VdW grids only).
+ *   d_out_vdw     [nprobes] device pointers, NULL entries are skipped; d_out_coulomb may be NULL.  Layout, channel_stride,
+ *                 i_begin / i_end / i_origin, lambda / threshold and the asynchronous stream semantics as ceg_plan_build_*.
+ *
+ * Every grid is bit-identical to the one the same call produces when it is asked for that grid alone (identical per-pair
+ * arithmetic and summation order, whatever the grouping into launches); against a single-probe plan of ceg_plan_create the
+ * values agree to the last bits of the FP64 sums (a VdW-only single-probe plan lists fewer images, which reorders the sums).
+ * The ordinary ceg_plan_build_vdw / _coulomb / _fused calls work on a multi-probe plan too and use probe 0.
+ */
+#define CEG_MAX_PROBES 4
+CEG_API int ceg_plan_create_multi(ceg_plan_t** plan, int32_t device,
+                          const double* pos, const int64_t* atomkind, const double* charge, int64_t natoms,
+                          const double mat[9], const double invmat[9],
+                          int32_t ortho, double safemin2, double cutoff2,
+                          int32_t nprobes, const ceg_rule_t* const* rules, const int32_t* const* rule_offset, int32_t nkinds,
+                          double alpha,
+                          const int32_t dims[3], const double size[3], const double shift[3], const double delta[3]);
+CEG_API int ceg_plan_num_probes(const ceg_plan_t* plan);    /* 0 for an ordinary plan */
+CEG_API int ceg_plan_build_multi(ceg_plan_t* plan,
+                         double lambda_vdw, double threshold_vdw,
+                         double lambda_coulomb, double threshold_coulomb,
+                         int32_t i_begin, int32_t i_end,
+                         float* const* d_out_vdw, float* d_out_coulomb,
+                         int64_t channel_stride, int32_t i_origin, void* stream);
+
+/*
  * Raw FP64 results of compute_derivatives_vdw / compute_derivatives_ewald
  * (src/probes.jl:71-117) at arbitrary cartesian points, before
  * _set_gridpoint!: out[8*p + 0..7] = value, d1x, d1y, d1z, d2xy, d2xz, d2yz, d3.

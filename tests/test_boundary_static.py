@@ -58,6 +58,8 @@ def _compatible(header_cls: str, other: str) -> bool:
         return header_cls.endswith("*") and not header_cls.endswith("**")
     if header_cls == "void*":                     # untyped byte buffers of the header (file header / trailer, masks)
         return other in ("char*", "u8*")
+    if other == "handle**":                       # an array of untyped pointers where the header has an array of typed ones
+        return header_cls.endswith("**")          # (rule tables / output grids of the multi-probe calls)
     return False
 
 

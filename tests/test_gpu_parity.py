@@ -1093,3 +1093,85 @@ def test_grid_file_never_visible_when_the_build_fails(hip_lib, tmp_path):
     assert call(bad, good) != 0
     assert good.read_bytes() == reference_bytes
     assert sorted(p.name for p in tmp_path.iterdir()) == ["good.grid"]
+
+
+# ------------------------------------------------------------------ multi-probe plans (all grids of a setup in one pass)
+def _probe_set(fwname, atoms, spacing=None, dims=None, tile=None):
+    ws = [W.fixture_workload(fwname, a, spacing or 0.0, dims=dims, tile=tile) for a in atoms]
+    return ws[0], [w.probe_vdw for w in ws]
+
+
+@pytest.mark.parametrize("fwname,atoms,spacing", [
+    ("CHA_1.4_3b4eeb96", ("C_co2", "O_co2"), 0.45),                       # CO2 in CHA: the reference's own test molecule (2 VdW + Coulomb)
+    ("CHA_1.4_3b4eeb96_Na_11812", ("Ar", "C_co2", "O_co2", "N_n2"), 0.7),  # four probes; Na cations in the framework: a second LJ kind
+    ("CIT-7", ("O_co2", "Ar", "C_co2"), 0.4),                             # triclinic 2x3x3 supercell, three probes
+])
+def test_multi_probe_build(hip_lib, oracle, fwname, atoms, spacing):
+    """ceg_plan_create_multi / ceg_plan_build_multi: the K VdW grids + the Coulomb grid of one framework from one image list in one
+    call (raspa.jl:497-520 asks for them one by one).  (1) every grid within the suite's tolerance of the oracle; (2) every grid
+    BIT-identical to the one the same plan produces when asked for that grid alone, and to any other grouping of the request into
+    launches (fused pair + VdW rest, VdW only, one by one); (3) slabs with i_origin, skipped outputs."""
+    import torch
+    from ceg_hip.plan import MultiGridPlan
+    w, probes = _probe_set(fwname, atoms, spacing)
+    cset = w.cset
+    nx, ny, nz = cset.npoints
+    dev = torch.device("cuda", 0)
+    K = len(probes)
+    plan = MultiGridPlan(cset, probes, w.probe_coulomb, w.alpha)
+    cs = nx * ny * nz
+
+    def build(which, coulomb, env=None):
+        outs = [torch.full((8, nx, ny, nz), float("nan"), dtype=torch.float32, device=dev) if q in which else None for q in range(K)]
+        oc = torch.full((8, nx, ny, nz), float("nan"), dtype=torch.float32, device=dev) if coulomb else None
+        if env is not None:
+            os.environ["CEG_HIP_MULTI_FUSED_NP"] = env
+        try:
+            plan.build([o.data_ptr() if o is not None else 0 for o in outs], oc.data_ptr() if oc is not None else 0, cs, 0, nx)
+        finally:
+            os.environ.pop("CEG_HIP_MULTI_FUSED_NP", None)
+        torch.cuda.synchronize()
+        return [o.cpu().numpy() if o is not None else None for o in outs], (oc.cpu().numpy() if oc is not None else None)
+
+    allv, allc = build(range(K), True)
+    lam, thr = G.vdw_scaling()
+    for q, pr in enumerate(probes):
+        compare_grids(allv[q], oracle.grid_vdw(pr, cset, lam, thr)[0], f"multi/{fwname}/{atoms[q]}", floor0=0.0)
+    lam, thr = G.coulomb_scaling()
+    compare_grids(allc, oracle.grid_coulomb(w.probe_coulomb, w.alpha, cset, lam, thr)[0], f"multi/{fwname}/coulomb", floor0=0.0)
+    # one grid at a time, and other groupings of the same request: bit-identical
+    for q in range(K):
+        one, _ = build([q], False)
+        assert np.array_equal(one[q].view(np.int32), allv[q].view(np.int32)), (atoms[q], "alone")
+    _, conly = build([], True)
+    assert np.array_equal(conly.view(np.int32), allc.view(np.int32))
+    for env in ("0", "1"):
+        v2, c2 = build(range(K), True, env)
+        assert np.array_equal(c2.view(np.int32), allc.view(np.int32)), env
+        for q in range(K):
+            assert np.array_equal(v2[q].view(np.int32), allv[q].view(np.int32)), (atoms[q], env)
+    vonly, _ = build(range(K), False)
+    for q in range(K):
+        assert np.array_equal(vonly[q].view(np.int32), allv[q].view(np.int32)), (atoms[q], "vdw only")
+    # a slab with an origin, the last probe skipped
+    b, e = nx // 3, nx - 2
+    m = e - b
+    outs = [torch.full((8, m, ny, nz), float("nan"), dtype=torch.float32, device=dev) for _ in range(K - 1)]
+    oc = torch.full((8, m, ny, nz), float("nan"), dtype=torch.float32, device=dev)
+    plan.build([o.data_ptr() for o in outs], oc.data_ptr(), m * ny * nz, b, e, b)
+    torch.cuda.synchronize()
+    for q in range(K - 1):
+        assert np.array_equal(outs[q].cpu().numpy().view(np.int32), allv[q][:, b:e].view(np.int32))
+    assert np.array_equal(oc.cpu().numpy().view(np.int32), allc[:, b:e].view(np.int32))
+    # against the ordinary single-probe plans: same values up to the order of the FP64 sums
+    for q, pr in enumerate(probes[:2]):
+        compare_grids(G.build_vdw_array(pr, cset), allv[q], f"multi vs single plan/{atoms[q]}", floor0=0.0)
+    plan.close()
+
+
+def test_multi_probe_plan_rejects_non_lj_probes(hip_lib):
+    from ceg_hip.plan import MultiGridPlan
+    w, probes = _probe_set("CHA_1.4_3b4eeb96", ("Ar", "Na"), 0.7)
+    with pytest.raises(_abi.CegError) as ei:
+        MultiGridPlan(w.cset, probes, w.probe_coulomb, w.alpha)
+    assert ei.value.code == -5 and "Lennard-Jones" in str(ei.value)
