@@ -93,6 +93,11 @@ PROTOTYPES = {
         C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_double,
         c_int32_p, c_double_p, c_double_p, c_double_p]),
     "ceg_plan_num_probes": (C.c_int, [C.c_void_p]),
+    "ceg_grids_multi": (C.c_int, [
+        c_double_p, c_int64_p, c_double_p, C.c_int64, c_double_p, c_double_p, C.c_int32, C.c_double, C.c_double,
+        C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_double,
+        c_int32_p, c_double_p, c_double_p, c_double_p,
+        C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_void_p), c_float_p, C.c_int32]),
     "ceg_plan_build_multi": (C.c_int, [
         C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double,
         C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),

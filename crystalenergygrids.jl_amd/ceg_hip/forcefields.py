@@ -165,6 +165,17 @@ class ForceField:
                     return True
         return False
 
+    def lj_only_probe(self, atom: str, framework) -> bool:
+        """True when the probe ``atom`` meets every framework kind that is present with at most one Lennard-Jones rule
+        (NoInteraction / CoulombEwaldDirect count as none): the condition of the multi-probe grid pass (``ceg_plan_create_multi``)."""
+        i = self.sdict[get_atom_name(atom)]
+        kinds = {self.sdict[get_atom_name(s)] for s in framework.atomic_symbol}
+        for k in kinds:
+            real = [r for r in rules_of(self.interactions[k - 1][i - 1]) if r.kind not in (FF.NoInteraction, FF.CoulombEwaldDirect)]
+            if len(real) > 1 or (real and real[0].kind != FF.LennardJones):
+                return False
+        return True
+
     def rule_table(self, probe: int):
         """Flatten column ``probe`` (1-based) into the C-ABI table:
         ``rules`` structured array + ``rule_offset`` (nkinds+1 int32), i.e. what

@@ -9,6 +9,7 @@ path has no CPU fallback: without the HIP library these functions raise.
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 import os
 import struct
@@ -224,6 +225,64 @@ def create_grid_coulomb(file, framework, forcefield: ForceField, spacing: float,
     probe_coulomb = ProbeSystem.build(framework, forcefield)
     return build_coulomb_array(probe_coulomb, ewald.alpha, cset, ngpus, file=file, num_unitcell=num_unitcell,
                                ewald_precision=ewald.precision)
+
+
+def build_multi_arrays(probes, coulomb_probe: Optional[ProbeSystem], alpha: float, cset: GridCoordinatesSetup, ngpus: int = 1):
+    """All the grids of one setup from one pass over one lattice-image list (``ceg_grids_multi``): the VdW grid of every probe
+    in ``probes`` (ProbeSystems of the same framework, Lennard-Jones-only: 1..4 of them) and, with ``coulomb_probe``, the
+    Coulomb grid.  -> (list of float32[8, nx, ny, nz], float32[8, nx, ny, nz] or None)."""
+    lib = _abi.load_library()
+    probes = list(probes)
+    ref = probes[0]
+    tables = []
+    for pr in probes:
+        pr.forcefield.check_vdw_grid(pr.probe, np.unique(pr.atomkinds))
+        tables.append(pr.forcefield.rule_table(pr.probe))
+    K = len(probes)
+    rules_pp = (C.c_void_p * K)(*[t[0].ctypes.data for t in tables])
+    offs_pp = (C.c_void_p * K)(*[t[1].ctypes.data for t in tables])
+    ortho, safemin2 = ref.periodic_setup()
+    lv, tv = vdw_scaling()
+    lc, tc = coulomb_scaling()
+    dims, size, shift, delta = _grid_args(cset)
+    nx, ny, nz = cset.npoints
+    vgrids = [np.empty((8, nx, ny, nz), dtype=np.float32) for _ in range(K)]
+    cgrid = np.empty((8, nx, ny, nz), dtype=np.float32) if coulomb_probe is not None else None
+    pos = np.ascontiguousarray(ref.positions, dtype=np.float64)
+    kinds = np.ascontiguousarray(ref.atomkinds, dtype=np.int64)
+    q = np.ascontiguousarray(coulomb_probe.charges, dtype=np.float64) if coulomb_probe is not None else None
+    mat, invmat = _matT(ref.mat), _matT(ref.invmat)
+    out_pp = (C.c_void_p * K)(*[g.ctypes.data for g in vgrids])
+    rc = lib.ceg_grids_multi(_abi.dptr(pos), _abi.i64ptr(kinds), _abi.dptr(q) if q is not None else None, len(kinds),
+                             _abi.dptr(mat), _abi.dptr(invmat), int(ortho), safemin2, ref.cutoff2,
+                             K, rules_pp, offs_pp, ref.forcefield.nkinds, float(alpha),
+                             _abi.i32ptr(dims), _abi.dptr(size), _abi.dptr(shift), _abi.dptr(delta),
+                             lv, tv, lc, tc, out_pp, _abi.fptr(cgrid) if cgrid is not None else None, ngpus)
+    _abi.check(lib, rc)
+    return vgrids, cgrid
+
+
+def create_grids_multi(vdw_files, coulomb_file, framework, forcefield: ForceField, spacing: float, atoms,
+                       _ewald: Optional[EwaldFramework] = None, ngpus: int = 1):
+    """``create_grid_vdw`` (grids.jl:137-157) for every atom of ``atoms`` and -- with ``coulomb_file`` -- ``create_grid_coulomb``
+    (grids.jl:159-185) of one framework in ONE pass: the files are byte-identical in format to the ones the two functions write
+    (same header / payload / trailer writer), the payloads come from ``ceg_grids_multi``.  This is the call pattern of
+    setup_RASPA (raspa.jl:497-520) collapsed into one call.  Atoms whose rules are not Lennard-Jones-only cannot share the
+    pass (the library says so): the caller builds those with ``create_grid_vdw``."""
+    atoms = list(atoms)
+    assert len(vdw_files) == len(atoms) and 1 <= len(atoms) <= 4
+    cset, num_unitcell = _setup_grid_common(framework, spacing, forcefield.cutoff)
+    probes = [ProbeSystem.build(framework, forcefield, a) for a in atoms]
+    pc, alpha, prec = None, 0.0, None
+    if coulomb_file is not None:
+        ewald = _ewald if isinstance(_ewald, EwaldFramework) else initialize_ewald(framework, num_unitcell)
+        pc, alpha, prec = ProbeSystem.build(framework, forcefield), ewald.alpha, ewald.precision
+    vgrids, cgrid = build_multi_arrays(probes, pc, alpha, cset, ngpus)
+    for f, g in zip(vdw_files, vgrids):
+        write_grid_file(f, cset, num_unitcell, g)
+    if coulomb_file is not None:
+        write_grid_file(coulomb_file, cset, num_unitcell, cgrid, ewald_precision=prec)
+    return vgrids, cgrid
 
 
 def parse_grid(file, iscoulomb: bool, mat=None) -> EnergyGrid:

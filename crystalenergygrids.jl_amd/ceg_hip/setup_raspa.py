@@ -11,8 +11,9 @@ import numpy as np
 
 from .ewald import EwaldFramework, initialize_ewald
 from .forcefields import ForceField
-from .grids import (BlockFile, CrystalEnergySetup, EnergyGrid, create_grid_coulomb, create_grid_vdw,
+from .grids import (BlockFile, CrystalEnergySetup, EnergyGrid, create_grid_coulomb, create_grid_vdw, create_grids_multi,
                     parse_blockfile, parse_blockfile_gpu, parse_grid)
+from . import _abi
 from .coordinates import GridCoordinatesSetup
 from .raspa import (RASPASystem, _ff, _ffname, _ffpal, getdir_RASPA, load_framework_RASPA,
                     load_molecule_RASPA)
@@ -99,9 +100,10 @@ def retrieve_or_create_grid(grid_path, syst_framework, forcefield: ForceField, g
 
 def setup_RASPA(framework, pff, molecule, ffname_molecule: Optional[str] = None, *, gridstep: float = 0.15,
                 supercell=None, blockfile=None, new: bool = False, cutoff: float = 12.0,
-                ngpus: int = 1) -> CrystalEnergySetup:
+                ngpus: int = 1, multi: bool = True) -> CrystalEnergySetup:
     """raspa.jl:472-531.  ``molecule`` may be a molecule name (with ``ffname_molecule``),
-    a RASPASystem, or the name of a single atom of the framework force field."""
+    a RASPASystem, or the name of a single atom of the framework force field.  ``multi=False`` builds missing grids
+    one by one like the reference does."""
     syst_framework = load_framework_RASPA(framework, pff)
     if isinstance(molecule, RASPASystem):
         syst_mol = molecule
@@ -126,15 +128,39 @@ def setup_RASPA(framework, pff, molecule, ffname_molecule: Optional[str] = None,
     coulomb_grid_path, vdws = grid_locations(framework, pff, forcefield, rev_atomdict, gridstep, supercell)
 
     needcoulomb = any(q != 0 for q in syst_mol.atomic_charge)
+    ewald = initialize_ewald(syst_framework, supercell) if needcoulomb else EwaldFramework.empty(mat)
+    # The reference builds the missing grids one after the other (raspa.jl:497-520: one retrieve_or_create_grid for the
+    # Coulomb grid, one per distinct atom of the molecule).  Here every grid that has to be CREATED is collected first and
+    # built by one multi-probe call -- one lattice-image list, one pass over the framework (grids.create_grids_multi) --;
+    # retrieve_or_create_grid then finds the files and only parses them.  Atoms the multi-probe pass cannot take (rules that
+    # are not Lennard-Jones-only, e.g. a Buckingham cation) and anything the library refuses fall through to the one-by-one path.
+    if multi and not isinstance(framework, np.ndarray) and not math.isinf(cutoff) and cutoff == 12.0:
+        missing = [i for i, atom in enumerate(rev_atomdict)
+                   if vdws[i] and forcefield.needsvdwgrid(atom) and forcefield.lj_only_probe(atom, syst_framework)
+                   and (new or not os.path.isfile(vdws[i]))]
+        want_c = bool(needcoulomb and coulomb_grid_path and (new or not os.path.isfile(coulomb_grid_path)))
+        for lo in range(0, len(missing), 4):
+            part = missing[lo:lo + 4]
+            with_c = want_c and lo == 0
+            if len(part) + int(with_c) < 2:
+                continue                                          # a single grid: the ordinary path does it
+            for pth in [vdws[i] for i in part] + ([coulomb_grid_path] if with_c else []):
+                os.makedirs(os.path.dirname(pth), exist_ok=True)
+            try:
+                create_grids_multi([vdws[i] for i in part], coulomb_grid_path if with_c else None, syst_framework, forcefield,
+                                   gridstep, [rev_atomdict[i] for i in part], ewald if with_c else None, ngpus)
+            except _abi.CegError as exc:
+                if exc.code != -5:                                # CEG_ERR_UNSUPPORTED: one by one instead
+                    raise
+        new = False if missing or want_c else new                 # whatever was asked anew has just been written
     if needcoulomb:
-        ewald = initialize_ewald(syst_framework, supercell)
         if isinstance(framework, np.ndarray):
             coulomb = EnergyGrid.trivial(True)
         else:
             coulomb = retrieve_or_create_grid(coulomb_grid_path, syst_framework, forcefield, gridstep, ewald,
                                               mat, new, cutoff, ngpus)
     else:
-        coulomb, ewald = EnergyGrid.trivial(True), EwaldFramework.empty(mat)
+        coulomb = EnergyGrid.trivial(True)
 
     grids: List[EnergyGrid] = [None] * len(atomdict)  # type: ignore[list-item]
     for atom, i in atomdict.items():

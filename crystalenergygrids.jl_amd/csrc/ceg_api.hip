@@ -1462,6 +1462,137 @@ int oneshot(int mode, const double* pos, const int64_t* atomkind, const double* 
     return CEG_OK;
 }
 
+// One device's share of a multi-probe one-shot build (ceg_grids_multi): like device_pipeline, with NG = (requested VdW grids) +
+// (Coulomb grid) outputs per chunk -- one multi-probe plan, one ceg_plan_build_multi per chunk, NG x 8 channel segments copied
+// D2H into a slot of the pinned ring and moved into the callers' arrays by the host threads while the next chunks are computed.
+int multi_device_pipeline(int d, int b, int e, int nx, int64_t plane, const double* pos, const int64_t* atomkind,
+                          const double* charge, int64_t natoms, const double* mat, const double* invmat, int32_t ortho,
+                          double safemin2, double cutoff2, int32_t nprobes, const ceg_rule_t* const* rules,
+                          const int32_t* const* rule_offset, int32_t nkinds, double alpha, const int32_t* dims, const double* size,
+                          const double* shift, const double* delta, double lambda_vdw, double threshold_vdw, double lambda_coulomb,
+                          double threshold_coulomb, float* const* grids_vdw, float* grid_coulomb, int copy_threads, std::string* err)
+{
+    auto bad = [&](int code, const char* what) {
+        *err = std::string(what) + " (device " + std::to_string(d) + "): " + hipGetErrorString(hipGetLastError());
+        return code;
+    };
+    const int64_t npts = plane * nx;
+    const int64_t slab_pts = (int64_t)(e - b) * plane;
+    if (slab_pts <= 0) return CEG_OK;
+    const bool trace = std::getenv("CEG_HIP_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto stamp = [&](const char* what) {
+        if (trace)
+            fprintf(stderr, "[ceg multi one-shot dev %d] %-28s %8.3f ms\n", d, what,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    };
+    // outputs of this call: host array + (device slab assigned below)
+    std::vector<float*> host;               // NG host arrays, VdW grids in probe order, then the Coulomb grid
+    std::vector<int> probe_of;              // probe index, -1 for the Coulomb grid
+    for (int q = 0; q < nprobes; ++q)
+        if (grids_vdw && grids_vdw[q]) { host.push_back(grids_vdw[q]); probe_of.push_back(q); }
+    if (grid_coulomb) { host.push_back(grid_coulomb); probe_of.push_back(-1); }
+    const int NG = (int)host.size();
+    if (NG == 0) return CEG_OK;
+    if (hipSetDevice(d) != hipSuccess) return bad(CEG_ERR_HIP, "hipSetDevice failed");
+    ceg_plan* plan = nullptr;
+    int rc = ceg_plan_create_multi(&plan, d, pos, atomkind, grid_coulomb ? charge : nullptr, natoms, mat, invmat, ortho, safemin2, cutoff2,
+                                   nprobes, rules, rule_offset, nkinds, alpha, dims, size, shift, delta);
+    if (rc) { *err = g_err; return rc; }
+    stamp("plan created");
+    // chunk = a multiple of 4 planes (the kernel's tile edge) of about 32 MB over the NG x 8 channels
+    int cx = (int)std::max<int64_t>(4, ((32ll << 20) / (plane * 8 * NG * (int64_t)sizeof(float))) / 4 * 4);
+    cx = std::min(cx, (e - b + 3) / 4 * 4);
+    const int nchunks = (e - b + cx - 1) / cx;
+    const int R = std::min(3, nchunks);
+    const size_t grid_slot = (size_t)8 * cx * plane;           // floats of one grid in a ring slot
+    const size_t slot_floats = grid_slot * NG;
+    float* d_all = nullptr;                                     // NG slabs of 8 * slab_pts floats
+    float* h_ring = nullptr;
+    hipStream_t s_comp = nullptr, s_copy = nullptr;
+    std::vector<hipEvent_t> ev_comp(nchunks, nullptr), ev_copy(nchunks, nullptr);
+    std::thread drain;
+    std::atomic<int> drained{0}, enqueued{0};
+    std::atomic<int> drain_rc{CEG_OK};
+    bool ok = streams_acquire(d, &s_comp, &s_copy) &&
+              (d_all = static_cast<float*>(device_acquire(d, sizeof(float) * 8 * slab_pts * NG))) != nullptr;
+    for (int j = 0; j < nchunks && ok; ++j)
+        ok = hipEventCreateWithFlags(&ev_comp[j], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&ev_copy[j], hipEventDisableTiming) == hipSuccess;
+    if (ok) {
+        h_ring = static_cast<float*>(pinned_acquire(sizeof(float) * slot_floats * R));
+        ok = h_ring != nullptr;
+    }
+    if (!ok) rc = bad(CEG_ERR_HIP, "allocation of streams / buffers failed");
+    std::vector<float*> d_vdw(nprobes, nullptr);
+    float* d_coulomb = nullptr;
+    for (int gidx = 0; gidx < NG && !rc; ++gidx) {
+        float* slab = d_all + (size_t)gidx * 8 * slab_pts;
+        if (probe_of[gidx] >= 0) d_vdw[probe_of[gidx]] = slab; else d_coulomb = slab;
+    }
+    stamp("streams, buffers, pinned ring");
+    for (int j = 0; j < nchunks && !rc; ++j) {
+        const int cb = b + j * cx, ce = std::min(e, cb + cx);
+        rc = ceg_plan_build_multi(plan, lambda_vdw, threshold_vdw, lambda_coulomb, threshold_coulomb, cb, ce, d_vdw.data(), d_coulomb,
+                                  slab_pts, b, s_comp);
+        if (rc) { *err = g_err; break; }
+        if (hipEventRecord(ev_comp[j], s_comp) != hipSuccess) rc = bad(CEG_ERR_HIP, "hipEventRecord failed");
+    }
+    stamp("kernels enqueued");
+    if (!rc) {
+        drain = std::thread([&]() {
+            (void)hipSetDevice(d);
+            for (int j = 0; j < nchunks; ++j) {
+                while (j >= enqueued.load()) std::this_thread::yield();
+                if (drain_rc.load() != CEG_OK) { drained.store(j + 1); continue; }
+                if (hipEventSynchronize(ev_copy[j]) != hipSuccess) { drain_rc.store(CEG_ERR_HIP); drained.store(j + 1); continue; }
+                const int cb = b + j * cx, ce = std::min(e, cb + cx);
+                const size_t cpts = (size_t)(ce - cb) * plane;
+                const float* slot = h_ring + (size_t)(j % R) * slot_floats;
+                std::vector<Segment> segs;
+                for (int gidx = 0; gidx < NG; ++gidx)
+                    for (int c = 0; c < 8; ++c)
+                        segs.push_back({host[gidx] + (size_t)c * npts + (size_t)cb * plane, slot + (size_t)gidx * grid_slot + (size_t)c * cpts, cpts, 0});
+                (void)parallel_copy(segs, copy_threads);
+                drained.store(j + 1);
+            }
+        });
+        for (int j = 0; j < nchunks && !rc; ++j) {
+            while (j - drained.load() >= R) std::this_thread::yield();        // ring slot still being emptied
+            const int cb = b + j * cx, ce = std::min(e, cb + cx);
+            const size_t cpts = (size_t)(ce - cb) * plane;
+            float* slot = h_ring + (size_t)(j % R) * slot_floats;
+            if (hipStreamWaitEvent(s_copy, ev_comp[j], 0) != hipSuccess) rc = bad(CEG_ERR_HIP, "hipStreamWaitEvent failed");
+            for (int gidx = 0; gidx < NG && !rc; ++gidx)
+                for (int c = 0; c < 8 && !rc; ++c)
+                    if (hipMemcpyAsync(slot + (size_t)gidx * grid_slot + (size_t)c * cpts,
+                                       d_all + (size_t)gidx * 8 * slab_pts + (size_t)c * slab_pts + (size_t)(cb - b) * plane, sizeof(float) * cpts,
+                                       hipMemcpyDeviceToHost, s_copy) != hipSuccess)
+                        rc = bad(CEG_ERR_HIP, "hipMemcpyAsync D2H failed");
+            if (!rc && hipEventRecord(ev_copy[j], s_copy) != hipSuccess) rc = bad(CEG_ERR_HIP, "hipEventRecord failed");
+            if (rc) drain_rc.store(rc);
+            enqueued.store(j + 1);
+        }
+        if (rc) enqueued.store(nchunks);       // let the drain thread run to its end
+        stamp("copies enqueued");
+        drain.join();
+        stamp("drained into caller arrays");
+        if (!rc && drain_rc.load() != CEG_OK) rc = bad(CEG_ERR_HIP, "kernel execution or D2H copy failed");
+    }
+    (void)hipStreamSynchronize(s_comp);
+    (void)hipStreamSynchronize(s_copy);
+    for (int j = 0; j < nchunks; ++j) {
+        if (ev_comp[j]) (void)hipEventDestroy(ev_comp[j]);
+        if (ev_copy[j]) (void)hipEventDestroy(ev_copy[j]);
+    }
+    if (h_ring) pinned_release(h_ring);
+    if (d_all) device_release(d_all);
+    if (s_comp) streams_release(s_comp);
+    ceg_plan_destroy(plan);
+    stamp("cleaned up");
+    return rc;
+}
+
 // One slab of the device-resident one-shot build: slab 0 is built straight into the assembled grid on the target device; the other
 // slabs are built on their own devices and travel to the target chunk by chunk with hipMemcpyPeerAsync (xGMI between the GPUs of a
 // node) while the later chunks are still being computed.
@@ -1581,6 +1712,50 @@ extern "C" int ceg_grid_coulomb_device(const double* pos, const double* charge, 
     if (!charge) return fail(CEG_ERR_INVALID, "charge is NULL");
     return oneshot_resident(MODE_COULOMB, pos, nullptr, charge, natoms, mat, invmat, ortho, safemin2, cutoff2, nullptr, nullptr, 0, alpha, dims,
                             size, shift, delta, lambda, threshold, d_grid, target_device, ngpus);
+}
+
+extern "C" int ceg_grids_multi(const double* pos, const int64_t* atomkind, const double* charge, int64_t natoms, const double mat[9],
+                               const double invmat[9], int32_t ortho, double safemin2, double cutoff2, int32_t nprobes,
+                               const ceg_rule_t* const* rules, const int32_t* const* rule_offset, int32_t nkinds, double alpha,
+                               const int32_t dims[3], const double size[3], const double shift[3], const double delta[3],
+                               double lambda_vdw, double threshold_vdw, double lambda_coulomb, double threshold_coulomb,
+                               float* const* grids_vdw, float* grid_coulomb, int32_t ngpus)
+{
+    if (nprobes < 1 || nprobes > CEG_MAX_PROBES) return fail(CEG_ERR_INVALID, "nprobes = %d outside 1..%d", nprobes, CEG_MAX_PROBES);
+    if (!rules || !rule_offset || !atomkind || nkinds <= 0) return fail(CEG_ERR_INVALID, "rule tables / atomkind missing");
+    if (grid_coulomb && !charge) return fail(CEG_ERR_INVALID, "charge is NULL");
+    if (int rc = check_common(pos, natoms, mat, invmat, dims, size, shift, delta)) return rc;
+    const int ndev = ceg_device_count();
+    if (ndev <= 0) return fail(CEG_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    const bool oversubscribe = std::getenv("CEG_HIP_OVERSUBSCRIBE") != nullptr;
+    if (ngpus < 1 || (ngpus > ndev && !oversubscribe)) return fail(CEG_ERR_NO_DEVICE, "ngpus = %d but %d HIP devices are present", ngpus, ndev);
+    const int nx = dims[0] + 1;
+    const int64_t plane = (int64_t)(dims[1] + 1) * (dims[2] + 1);
+    ngpus = std::min(ngpus, nx);
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    int copy_threads = 8;
+    if (const char* env = std::getenv("CEG_HIP_COPY_THREADS")) copy_threads = std::max(1, atoi(env));
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw > 0) copy_threads = std::min<int>(copy_threads, (int)hw);
+    copy_threads = std::max(1, copy_threads / ngpus);
+    std::vector<int> rcs(ngpus, CEG_OK);
+    std::vector<std::string> errs(ngpus);
+    auto run = [&](int d) {
+        int b, e;
+        slab(nx, ngpus, d, &b, &e);
+        rcs[d] = multi_device_pipeline(d % ndev, b, e, nx, plane, pos, atomkind, charge, natoms, mat, invmat, ortho, safemin2, cutoff2, nprobes,
+                                       rules, rule_offset, nkinds, alpha, dims, size, shift, delta, lambda_vdw, threshold_vdw, lambda_coulomb,
+                                       threshold_coulomb, grids_vdw, grid_coulomb, copy_threads, &errs[d]);
+    };
+    std::vector<std::thread> workers;
+    for (int d = 1; d < ngpus; ++d) workers.emplace_back(run, d);
+    run(0);
+    for (auto& w : workers) w.join();
+    if (prev >= 0) (void)hipSetDevice(prev);
+    for (int d = 0; d < ngpus; ++d)
+        if (rcs[d]) return fail(rcs[d], "%s", errs[d].c_str());
+    return CEG_OK;
 }
 
 extern "C" int ceg_release_cached_buffers(void)

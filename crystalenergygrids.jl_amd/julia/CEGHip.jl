@@ -166,6 +166,122 @@ function create_grid_coulomb(file, framework::AbstractSystem{3}, forcefield::For
     grid
 end
 
+# ------------------------------------------------------------------ all the grids of a setup in one pass
+# setup_RASPA (src/raspa.jl:497-520) calls retrieve_or_create_grid once for the Coulomb grid and once per distinct atom of the
+# molecule; each call that has to CREATE its grid runs a full pass over the framework.  ceg_grids_multi (include/ceg_hip.h)
+# builds the VdW grids of up to 4 Lennard-Jones probes and the Coulomb grid from one lattice-image list in one pass.
+
+"True when `atom` meets every kind present in `probe` with at most one Lennard-Jones rule (what ceg_grids_multi accepts)."
+function lj_only(ff::ForceField, probe::Int, kinds)
+    for k in unique(kinds)
+        real = [r for r in _rules(ff.interactions[k, probe]) if r.kind !== FF.NoInteraction && r.kind !== FF.CoulombEwaldDirect]
+        (length(real) > 1 || (length(real) == 1 && real[1].kind !== FF.LennardJones)) && return false
+    end
+    true
+end
+
+"GPU replacement of K + 1 loop nests (src/grids.jl:144-150 per probe, :171-177): fills `vgrids[k]` for `probes[k]` and, if given, `cgrid`."
+function fill_grids_multi!(vgrids::Vector{Array{Cfloat,4}}, cgrid::Union{Nothing,Array{Cfloat,4}}, probes::Vector{<:ProbeSystem},
+                           probe_coulomb::Union{Nothing,ProbeSystem}, ewald::Union{Nothing,EwaldFramework}, cset::GridCoordinatesSetup)
+    ref = probes[1]
+    ff = ref.forcefield
+    tables = map(probes) do p
+        check_rules(ff, p.probe, p.atomkinds)
+        rule_table(ff, p.probe)
+    end
+    _, ortho, safemin = CEG.prepare_periodic_distance_computations(ref.mat)
+    cutoff2 = NoUnits(ff.cutoff^2/u"Å^2")
+    dims, size, shift, Δ = _geometry(cset)
+    pos = _flatpos(ref)
+    kinds = Int64.(ref.atomkinds)
+    mat = Vector{Float64}(vec(ref.mat)); invmat = Vector{Float64}(vec(ref.invmat))
+    λv = inv(GRID_TO_KELVIN); thrv = GRID_TO_KELVIN*1e7                                    # src/grids.jl:141-143,148
+    λc = ustrip(u"K*Å/e_au^2", COULOMBIC_CONVERSION_FACTOR)/GRID_TO_KELVIN; thrc = inv(λc)*1e7   # :169-170
+    α = ewald isa Nothing ? 0.0 : NoUnits(ewald.α*u"Å")
+    charges = probe_coulomb isa Nothing ? Float64[] : probe_coulomb.charges
+    rules = [t[1] for t in tables]; offsets = [t[2] for t in tables]
+    GC.@preserve vgrids cgrid pos kinds charges mat invmat rules offsets dims size shift Δ begin
+        rules_pp = Ptr{Cvoid}[pointer(r) for r in rules]
+        offs_pp = Ptr{Cvoid}[pointer(o) for o in offsets]
+        out_pp = Ptr{Cvoid}[pointer(g) for g in vgrids]
+        GC.@preserve rules_pp offs_pp out_pp _check(ccall((:ceg_grids_multi, LIB[]), Cint,
+            (Ptr{Float64}, Ptr{Int64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Int32, Float64, Float64,
+             Int32, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Int32, Float64,
+             Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+             Float64, Float64, Float64, Float64, Ptr{Ptr{Cvoid}}, Ptr{Cfloat}, Int32),
+            pos, kinds, (probe_coulomb isa Nothing ? C_NULL : pointer(charges)), length(kinds), mat, invmat, ortho, safemin^2, cutoff2,
+            length(probes), rules_pp, offs_pp, length(offsets[1])-1, α,
+            dims, size, shift, Δ,
+            λv, thrv, λc, thrc, out_pp, (cgrid isa Nothing ? C_NULL : pointer(cgrid)), ngpus()))
+    end
+    vgrids, cgrid
+end
+
+"""
+    create_grids_multi(vdw_files, coulomb_file, framework, forcefield, spacing, atoms, _ewald=nothing)
+
+`create_grid_vdw` (src/grids.jl:137-157) for every atom of `atoms` (1 to 4, Lennard-Jones-only against the framework) and, unless
+`coulomb_file === nothing`, `create_grid_coulomb` (:159-185) in one GPU pass; the files are written by the reference's own lines.
+"""
+function create_grids_multi(vdw_files, coulomb_file, framework::AbstractSystem{3}, forcefield::ForceField, spacing::TÅ, atoms::Vector{Symbol}, _ewald=nothing)
+    cset, num_unitcell = CEG._setup_grid_common(framework, spacing, forcefield.cutoff)
+    newgrid() = Array{Cfloat,4}(undef, cset.dims[3]+1, cset.dims[2]+1, cset.dims[1]+1, 8)
+    probes = [ProbeSystem(framework, forcefield, atom) for atom in atoms]
+    vgrids = [newgrid() for _ in atoms]
+    if coulomb_file === nothing
+        fill_grids_multi!(vgrids, nothing, probes, nothing, nothing, cset)
+    else
+        ewald = _ewald isa EwaldFramework ? _ewald : CEG.initialize_ewald(framework, num_unitcell)
+        cgrid = newgrid()
+        fill_grids_multi!(vgrids, cgrid, probes, ProbeSystem(framework, forcefield), ewald, cset)
+        open(coulomb_file, "w") do f
+            CEG._create_grid_common(f, cset, num_unitcell)
+            write(f, ewald.precision)
+            write(f, cgrid)
+            write(f, NoUnits.(cset.cell.mat./u"Å"))
+        end
+    end
+    for (file, grid) in zip(vdw_files, vgrids)
+        open(file, "w") do f
+            CEG._create_grid_common(f, cset, num_unitcell)
+            write(f, grid)
+            write(f, NoUnits.(cset.cell.mat./u"Å"))
+        end
+    end
+    nothing
+end
+
+"""
+    prebuild_grids!(framework, pff, syst_mol; gridstep=0.15u"Å", supercell=nothing, new=false, cutoff=12.0u"Å")
+
+Call with the arguments of `setup_RASPA` (src/raspa.jl:472-531) right before it: every grid that `setup_RASPA` would have to
+create -- same paths (`grid_locations`, :403-419), same conditions (`retrieve_or_create_grid`, :420-439) -- is created here by
+`create_grids_multi`, four probes at a time; `setup_RASPA` then only retrieves.  Atoms that are not Lennard-Jones-only
+(a Buckingham cation) are left to `create_grid_vdw`.
+"""
+function prebuild_grids!(framework, pff, syst_mol; gridstep=0.15u"Å", supercell=nothing, new=false, cutoff=12.0u"Å")
+    (framework isa AbstractMatrix || isinf(cutoff) || cutoff != 12.0u"Å") && return nothing
+    syst_framework = CEG.load_framework_RASPA(framework, pff)
+    supercell = supercell isa Nothing ? CEG.find_supercell(syst_framework, cutoff) : supercell
+    forcefield = CEG._ff(pff; cutoff)
+    atoms = unique(syst_mol[:,:atomic_symbol])
+    coulomb_grid_path, vdws = CEG.grid_locations(framework, pff, forcefield, atoms, gridstep, supercell)
+    needcoulomb = any(!iszero(syst_mol[i,:atomic_charge])::Bool for i in 1:length(syst_mol))
+    kinds = ProbeSystem(syst_framework, forcefield).atomkinds
+    todo = [i for (i, atom) in enumerate(atoms) if CEG.needsvdwgrid(forcefield, atom) && (new || !isfile(vdws[i])) &&
+            lj_only(forcefield, forcefield.sdict[CEG.get_atom_name(atom)], kinds)]
+    want_c = needcoulomb && (new || !isfile(coulomb_grid_path))
+    for lo in 1:4:max(length(todo), 1)
+        part = todo[lo:min(lo+3, length(todo))]
+        with_c = want_c && lo == 1
+        length(part) + with_c < 2 && continue
+        foreach(p -> mkpath(dirname(p)), vdws[part]); with_c && mkpath(dirname(coulomb_grid_path))
+        create_grids_multi(vdws[part], with_c ? coulomb_grid_path : nothing, syst_framework, forcefield, gridstep, atoms[part],
+                           with_c ? CEG.initialize_ewald(syst_framework, supercell) : nothing)
+    end
+    nothing
+end
+
 "Override the package's two grid builders with the GPU versions (method overwrite)."
 function install!()
     @eval CEG begin

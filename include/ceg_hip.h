@@ -267,6 +267,15 @@ CEG_API int ceg_plan_create_multi(ceg_plan_t** plan, int32_t device,
                           double alpha,
                           const int32_t dims[3], const double size[3], const double shift[3], const double delta[3]);
 CEG_API int ceg_plan_num_probes(const ceg_plan_t* plan);    /* 0 for an ordinary plan */
+/* One-shot form (what the Julia binding calls once per setup_RASPA): host arrays out, grids_vdw [nprobes] (NULL entries skipped),
+ * grid_coulomb may be NULL; the x-slabs are spread over `ngpus` devices and every device pipelines compute / D2H / host copy as
+ * ceg_grid_vdw does.  A probe that is not Lennard-Jones-only -> CEG_ERR_UNSUPPORTED and nothing is written. */
+CEG_API int ceg_grids_multi(const double* pos, const int64_t* atomkind, const double* charge, int64_t natoms,
+                    const double mat[9], const double invmat[9], int32_t ortho, double safemin2, double cutoff2,
+                    int32_t nprobes, const ceg_rule_t* const* rules, const int32_t* const* rule_offset, int32_t nkinds, double alpha,
+                    const int32_t dims[3], const double size[3], const double shift[3], const double delta[3],
+                    double lambda_vdw, double threshold_vdw, double lambda_coulomb, double threshold_coulomb,
+                    float* const* grids_vdw, float* grid_coulomb, int32_t ngpus);
 CEG_API int ceg_plan_build_multi(ceg_plan_t* plan,
                          double lambda_vdw, double threshold_vdw,
                          double lambda_coulomb, double threshold_coulomb,

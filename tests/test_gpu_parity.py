@@ -1175,3 +1175,43 @@ def test_multi_probe_plan_rejects_non_lj_probes(hip_lib):
     with pytest.raises(_abi.CegError) as ei:
         MultiGridPlan(w.cset, probes, w.probe_coulomb, w.alpha)
     assert ei.value.code == -5 and "Lennard-Jones" in str(ei.value)
+
+
+def test_setup_raspa_builds_missing_grids_in_one_pass(hip_lib, oracle, tmp_path):
+    """setup_RASPA for CO2 in CIT-7 (raspa.jl:472-531): the three grids it needs -- C_co2, O_co2, Coulomb -- are created by ONE
+    multi-probe call (grids.create_grids_multi) instead of three builds; the files have the reference's format (parse_grid reads
+    them), hold the oracle's values, and the resulting CrystalEnergySetup gives the same energy_point as the one-by-one path.
+    Na (Buckingham + hard sphere) cannot share the pass and still gets its grid through create_grid_vdw."""
+    import shutil
+    golden = Path(__file__).parent / "golden" / "raspa"
+    try:
+        setups = {}
+        for multi in (True, False):
+            raspa = tmp_path / f"raspa_{int(multi)}"
+            raspa.mkdir()
+            for sub in ("forcefield", "molecules", "structures"):
+                os.symlink(golden / sub, raspa / sub)
+            ceg.setdir_RASPA(raspa)
+            setups[multi] = ceg.setup_RASPA("CIT-7", "BoulfelfelSholl2021", "CO2", "TraPPE", gridstep=0.4, multi=multi)
+            files = sorted(p.name for p in (raspa / "grids").rglob("*.grid"))
+            assert len(files) == 3 and any("C_co2" in f for f in files) and any("O_co2" in f for f in files) and any("Ewald" in f for f in files), files
+        a, b = setups[True], setups[False]
+        for ga, gb in zip(a.grids + [a.coulomb], b.grids + [b.coulomb]):
+            assert ga.grid.shape == gb.grid.shape and ga.num_unitcell == gb.num_unitcell == (2, 3, 3)
+            compare_grids(np.ascontiguousarray(ga.grid), np.ascontiguousarray(gb.grid), "setup_RASPA multi vs one-by-one", sentinel=1.9e7 * ceg.GRID_TO_KELVIN, floor0=0.0)
+        # against the oracle
+        w = W.fixture_workload("CIT-7", "C_co2", 0.4)
+        lam, thr = G.vdw_scaling()
+        ref, _ = oracle.grid_vdw(w.probe_vdw, w.cset, lam, thr)
+        idx = a.atomsidx[1] if a.molecule.atomic_symbol[1].startswith("C") else a.atomsidx[0]
+        got = a.grids[idx].grid
+        compare_grids(np.ascontiguousarray(got), (ref.astype(np.float64) * ceg.GRID_TO_KELVIN).astype(np.float32), "setup_RASPA multi / C_co2 vs oracle",
+                      sentinel=1.9e7 * ceg.GRID_TO_KELVIN)
+        pos = np.array([[3.1, 4.2, 5.3], [3.1, 4.2, 6.46], [3.1, 4.2, 4.14]])
+        ea, eb = ceg.energy_point(a, pos), ceg.energy_point(b, pos)
+        assert ea[0] == pytest.approx(eb[0], rel=1e-6) and ea[1] == pytest.approx(eb[1], rel=1e-6)
+        # a cation: not Lennard-Jones-only -> one by one, same API
+        na = ceg.setup_RASPA("CIT-7", "BoulfelfelSholl2021", "Na", gridstep=0.6)
+        assert na.grids[0].grid.shape[0] == 8 and np.isfinite(ceg.energy_point(na, np.array([[3.1, 4.2, 5.3]]))[0])
+    finally:
+        ceg.setdir_RASPA(golden)
