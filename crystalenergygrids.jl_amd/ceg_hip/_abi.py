@@ -21,6 +21,13 @@ PKG_DIR = Path(__file__).resolve().parent.parent          # crystalenergygrids.j
 REPO_DIR = PKG_DIR.parent
 LIB_PATH = PKG_DIR / "csrc" / "libceg_hip.so"
 
+class GridHeader(C.Structure):
+    """``ceg_grid_header_t``"""
+    _fields_ = [("spacing", C.c_double), ("dims", C.c_int32 * 3), ("has_mat", C.c_int32),
+                ("size", C.c_double * 3), ("shift", C.c_double * 3), ("delta", C.c_double * 3), ("unitcell", C.c_double * 3),
+                ("num_unitcell", C.c_int32 * 3), ("_pad", C.c_int32), ("ewald_precision", C.c_double), ("mat", C.c_double * 9)]
+
+
 c_double_p = C.POINTER(C.c_double)
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -74,6 +81,7 @@ PROTOTYPES = {
         C.c_void_p, c_int32_p, C.c_int32, C.c_double,
         c_int32_p, c_double_p, c_double_p, c_double_p]),
     "ceg_plan_destroy": (C.c_int, [C.c_void_p]),
+    "ceg_image_cache_stats": (C.c_int, [c_int64_p, c_int64_p, c_int64_p]),
     "ceg_plan_can_cull": (C.c_int, [C.c_void_p]),
     "ceg_plan_num_images": (C.c_int64, [C.c_void_p]),
     "ceg_plan_build_vdw": (C.c_int, [
@@ -106,6 +114,8 @@ PROTOTYPES = {
     "ceg_interp_create": (C.c_int, [
         C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_int32,
         c_int32_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int32]),
+    "ceg_interp_create_from_file": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_char_p, C.c_int32, C.c_double, c_double_p, c_double_p, C.c_void_p]),
+    "ceg_interp_set_higherorder": (C.c_int, [C.c_void_p, C.c_int32]),
     "ceg_interp_destroy": (C.c_int, [C.c_void_p]),
     "ceg_interp_points": (C.c_int, [C.c_void_p, c_double_p, C.c_int64, c_double_p]),
     "ceg_interp_points_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

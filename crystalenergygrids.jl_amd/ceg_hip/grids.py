@@ -367,7 +367,21 @@ def interpolate_grid(g: EnergyGrid, point) -> float:
     _, nx, ny, nz = g.grid.shape
     p0, p1, r = interpolation_stencil(g.csetup, (nx, ny, nz), point)
     if not g.higherorder:
-        raise NotImplementedError("raw-value grids are not produced by this package")
+        # "no derivatives" (grids.jl:259-269).  The reference indexes this branch g.grid[x, y, z, 1] although its array is
+        # [z, y, x, channel]: the first array index (along z) receives the x cell index and the third (along x) the z cell index.
+        # Kept as written; an index beyond its axis is Julia's BoundsError, IndexError here.  parse_grid never produces such a
+        # grid (grids.jl:92), so only hand-made EnergyGrids get here.
+        (x0, y0, z0), (x1, y1, z1) = p0, p1
+        rx, ry, rz = r
+        mrx, mry, mrz = 1 - rx, 1 - ry, 1 - rz
+
+        def at(a, b, c):          # g.grid[a, b, c, 1] of the Julia array = self.grid[0, c-1, b-1, a-1] of this channel-first copy
+            if not (1 <= a <= nz and 1 <= b <= ny and 1 <= c <= nx):
+                raise IndexError(f"BoundsError: attempt to access {nz}x{ny}x{nx}x8 grid at index [{a}, {b}, {c}, 1]")
+            return float(g.grid[0, c - 1, b - 1, a - 1])
+        return (at(x0, y0, z0) * mrx * mry * mrz + at(x1, y0, z0) * rx * mry * mrz + at(x0, y1, z0) * mrx * ry * mrz +
+                at(x0, y0, z1) * mrx * mry * rz + at(x1, y1, z0) * rx * ry * mrz + at(x1, y0, z1) * rx * mry * rz +
+                at(x0, y1, z1) * mrx * ry * rz + at(x1, y1, z1) * rx * ry * rz)
     X = gather_corners(g.grid, p0, p1)
     return interpolate_from_corners(X, r, g.ewald_precision == math.inf)
 

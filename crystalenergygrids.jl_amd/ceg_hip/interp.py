@@ -41,6 +41,33 @@ class GridInterpolator:
                                          1 if g.ewald_precision == math.inf else 0)
         _abi.check(self._lib, rc)
         self._h = h
+        if not g.higherorder:
+            _abi.check(self._lib, self._lib.ceg_interp_set_higherorder(self._h, 0))
+
+    @classmethod
+    def from_file(cls, path, iscoulomb: bool, mat=None, device: int = 0, with_header: bool = False):
+        """A cached ``.grid`` file straight onto the device (``ceg_interp_create_from_file``): what ``parse_grid`` (grids.jl:61-94)
+        + ``GridInterpolator(g)`` do, without the host array -- payload streamed file -> pinned ring -> device, scaled by
+        GRID_TO_KELVIN there.  ``mat``: the unit-cell matrix as for ``parse_grid``; None = the one stored in the file."""
+        import os
+        from .constants import GRID_TO_KELVIN
+        from .coordinates import CellMatrix
+        self = cls.__new__(cls)
+        self._lib = _abi.load_library()
+        m = i = None
+        if mat is not None:
+            cm = mat if isinstance(mat, CellMatrix) else CellMatrix.from_mat(mat)
+            m, i = _matT(cm.mat), _matT(cm.invmat)
+        self._keep = (m, i)
+        h = C.c_void_p()
+        hdr = _abi.GridHeader()
+        rc = self._lib.ceg_interp_create_from_file(C.byref(h), device, os.fsencode(str(path)), 1 if iscoulomb else 0, GRID_TO_KELVIN,
+                                                   _abi.dptr(m) if m is not None else None, _abi.dptr(i) if i is not None else None,
+                                                   C.cast(C.byref(hdr), C.c_void_p))
+        _abi.check(self._lib, rc)
+        self._h = h
+        self.header = hdr
+        return (self, hdr) if with_header else self
 
     def __call__(self, points) -> np.ndarray:
         """interpolate_grid(g, p) for every row p of ``points`` (Å) -> K, float64[n]."""

@@ -15,7 +15,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <unordered_map>
 #include <string>
@@ -82,10 +84,11 @@ struct ceg_plan {
     int32_t* d_kind = nullptr;
     DevRule* d_rules = nullptr;
     int32_t* d_offset = nullptr;
-    double4* d_images = nullptr;
+    double4* d_images = nullptr;    // (views into `images`, which owns them)
     int32_t* d_imgkind = nullptr;
     int32_t* d_imgatom = nullptr;
     int32_t* d_binstart = nullptr;
+    std::shared_ptr<void> images;          // owner of the lattice-image list + bins on the device (an ImageSet, shared between plans: image cache)
     ImageBins ib{};
     bool images_built = false;
     PlanConst* d_pc = nullptr;   // device copy of {g, ib, rt, tables}
@@ -323,6 +326,65 @@ int upload(T** dst, const T* src, size_t n)
     return CEG_OK;
 }
 
+// ---- image cache.  The lattice-image list of a plan depends on the framework (positions, cell), the cutoff, the grid's
+// bounding box and, per atom, on what travels with an image: its kind + "has a VdW rule" flag, its charge, and whether atoms
+// without a rule are left out (VdW-only plans).  setup_RASPA builds several grids of ONE framework one after the other
+// (src/raspa.jl:497-520) and every one-shot call used to enumerate, sort and upload the same images again (1.0-1.4 ms of host time
+// for the 11 664-atom workload: as long as a whole rank's compute at N = 8).  Finished lists are kept on the device, keyed by a
+// 128-bit hash of everything they depend on, and shared by reference between plans; the cache holds the last few (CEG_HIP_IMAGE_CACHE
+// = number of entries, 0 switches it off).
+struct ImageSet {
+    int device = 0;
+    uint64_t key[2] = {0, 0};
+    double4* d_images = nullptr;
+    int32_t* d_imgkind = nullptr;
+    int32_t* d_imgatom = nullptr;
+    int32_t* d_binstart = nullptr;
+    ImageBins ib{};                 // geometry of the bins + the pointers above (ib.atoms is per plan)
+    size_t bytes = 0;
+    ~ImageSet()
+    {
+        DeviceGuard guard(device);
+        (void)hipDeviceSynchronize();          // no kernel still reads the arrays
+        for (void* ptr : {(void*)d_images, (void*)d_imgkind, (void*)d_imgatom, (void*)d_binstart}) cached_free(ptr);
+    }
+};
+std::mutex g_image_mutex;
+// (heap-allocated and never destroyed: a static destructor would run ~ImageSet -- HIP calls -- after the runtime may be gone at exit)
+std::vector<std::shared_ptr<ImageSet>>& g_image_cache = *new std::vector<std::shared_ptr<ImageSet>>();       // most recently used last
+std::atomic<long> g_image_hits{0}, g_image_misses{0};
+
+struct Hash128 {
+    uint64_t a = 0x243F6A8885A308D3ull, b = 0x13198A2E03707344ull;
+    void word(uint64_t w)
+    {
+        a = (a ^ w) * 0x9E3779B97F4A7C15ull; a ^= a >> 29;
+        b = (b + w) * 0xC2B2AE3D27D4EB4Full; b ^= b >> 31; b += a;
+    }
+    void bytes(const void* ptr, size_t n)
+    {
+        const unsigned char* c = static_cast<const unsigned char*>(ptr);
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, c + i, 8); word(w); }
+        uint64_t w = 0;
+        if (i < n) memcpy(&w, c + i, n - i);
+        word(w ^ ((uint64_t)n << 56));
+    }
+    template <class T> void pod(const T& v) { bytes(&v, sizeof v); }
+};
+
+int image_cache_capacity()
+{
+    if (const char* e = std::getenv("CEG_HIP_IMAGE_CACHE")) return std::max(0, atoi(e));
+    return 6;
+}
+
+void image_cache_release()
+{
+    std::lock_guard<std::mutex> lock(g_image_mutex);
+    g_image_cache.clear();
+}
+
 // Expand the atoms into every lattice image that can be within the cutoff of a grid point
 // (grid bounding box grown by the cutoff), bin them on a cartesian lattice and upload.
 #ifndef CEG_BIN_Z
@@ -352,6 +414,45 @@ int build_images(ceg_plan* p)
     // "the kind has a VdW rule": with the plan's probe, or with any probe of a multi-probe plan
     const std::vector<int32_t>& off = p->nprobes > 0 ? p->h_offset_union : p->h_offset;
     auto kind_has_rule = [&](int32_t k) { return k >= 0 && k + 1 < (int32_t)off.size() && off[k + 1] > off[k]; };
+    // ---- cache look-up: everything the list below is a function of
+    Hash128 hk;
+    std::shared_ptr<ImageSet> hit;
+    const int cap = image_cache_capacity();
+    if (cap > 0) {
+        hk.pod(p->device); hk.pod(p->natoms);
+        hk.bytes(g.mat, sizeof g.mat); hk.bytes(g.invmat, sizeof g.invmat);
+        hk.bytes(lo, sizeof lo); hk.bytes(hi, sizeof hi); hk.bytes(target, sizeof target);
+        hk.bytes(p->h_pos.data(), p->h_pos.size() * sizeof(double));
+        const int32_t mode = (p->has_rules ? 1 : 0) | (p->has_charge ? 2 : 0);
+        hk.pod(mode);
+        if (p->has_charge) hk.bytes(p->h_charge.data(), p->h_charge.size() * sizeof(double));
+        if (p->has_rules)
+            for (int64_t a = 0; a < p->natoms; ++a) {
+                const int32_t k = p->h_kind[a];
+                hk.pod((int32_t)(k < 0 ? -1 : (k | (kind_has_rule(k) ? (1 << 25) : 0))));
+            }
+        std::lock_guard<std::mutex> lock(g_image_mutex);
+        for (size_t t = 0; t < g_image_cache.size(); ++t) {
+            const std::shared_ptr<ImageSet> c = g_image_cache[t];
+            if (c->device == p->device && c->key[0] == hk.a && c->key[1] == hk.b) {
+                hit = c;
+                std::rotate(g_image_cache.begin() + t, g_image_cache.begin() + t + 1, g_image_cache.end());      // most recently used last
+                break;
+            }
+        }
+    }
+    if (hit) {
+        g_image_hits.fetch_add(1);
+        p->images = hit;
+        const ImageSet& c = *hit;
+        p->d_images = c.d_images; p->d_imgkind = c.d_imgkind; p->d_imgatom = c.d_imgatom; p->d_binstart = c.d_binstart;
+        p->ib = c.ib;
+        p->ib.kind = p->has_rules ? p->d_imgkind : nullptr;
+        p->ib.atoms = p->d_atoms;
+        p->images_built = true;
+        return CEG_OK;
+    }
+    g_image_misses.fetch_add(1);
     struct Img { double x, y, z, q; int32_t kind; int32_t bin; int32_t atom; };
     std::vector<Img> imgs;
     imgs.reserve((size_t)p->natoms * 8);
@@ -427,10 +528,16 @@ int build_images(ceg_plan* p)
         kind[s] = im.kind;
         atom[s] = im.atom;
     }
-    if (int rc = upload(&p->d_images, xyzq.data(), xyzq.size())) return rc;
-    if (int rc = upload(&p->d_imgkind, kind.data(), kind.size())) return rc;
-    if (int rc = upload(&p->d_imgatom, atom.data(), atom.size())) return rc;
-    if (int rc = upload(&p->d_binstart, start.data(), start.size())) return rc;
+    auto set = std::make_shared<ImageSet>();
+    set->device = p->device;
+    set->key[0] = hk.a; set->key[1] = hk.b;
+    if (int rc = upload(&set->d_images, xyzq.data(), xyzq.size())) return rc;
+    if (int rc = upload(&set->d_imgkind, kind.data(), kind.size())) return rc;
+    if (int rc = upload(&set->d_imgatom, atom.data(), atom.size())) return rc;
+    if (int rc = upload(&set->d_binstart, start.data(), start.size())) return rc;
+    set->bytes = xyzq.size() * sizeof(double4) + (kind.size() + atom.size() + start.size()) * sizeof(int32_t);
+    p->images = set;
+    p->d_images = set->d_images; p->d_imgkind = set->d_imgkind; p->d_imgatom = set->d_imgatom; p->d_binstart = set->d_binstart;
     ImageBins& ib = p->ib;
     ib.xyzq = p->d_images;
     ib.kind = p->has_rules ? p->d_imgkind : nullptr;
@@ -445,6 +552,12 @@ int build_images(ceg_plan* p)
     }
     ib.nimages = (int32_t)imgs.size();
     p->images_built = true;
+    set->ib = ib;
+    if (cap > 0) {
+        std::lock_guard<std::mutex> lock(g_image_mutex);
+        g_image_cache.push_back(set);
+        while ((int)g_image_cache.size() > cap) g_image_cache.erase(g_image_cache.begin());     // (freed when the last plan lets go)
+    }
     return CEG_OK;
 }
 
@@ -777,7 +890,7 @@ static int create_impl(ceg_plan_t** plan, int32_t device,
     }
     stamp("atom / rule tables uploaded");
     if (!rc && p->can_cull) rc = build_images(p);
-    stamp("images built + uploaded");
+    stamp(p->images && p->images.use_count() > 1 && g_image_hits.load() > 0 ? "images (cache / built)" : "images built + uploaded");
     if (!rc && p->can_cull) {
         PlanConst hc{};
         hc.g = p->g;
@@ -914,13 +1027,22 @@ extern "C" int ceg_plan_destroy(ceg_plan_t* p)
     if (!p) return CEG_OK;
     DeviceGuard guard(p->device);
     (void)hipDeviceSynchronize();          // what hipFree would do: no kernel of this plan is still running
-    for (void* ptr : {(void*)p->d_atoms, (void*)p->d_kind, (void*)p->d_rules, (void*)p->d_offset, (void*)p->d_images,
-                      (void*)p->d_imgkind, (void*)p->d_imgatom, (void*)p->d_binstart, (void*)p->d_pc, (void*)p->d_erfcx,
+    p->images.reset();                     // the image arrays belong to the (possibly cached, possibly shared) ImageSet
+    for (void* ptr : {(void*)p->d_atoms, (void*)p->d_kind, (void*)p->d_rules, (void*)p->d_offset, (void*)p->d_pc, (void*)p->d_erfcx,
                       (void*)p->d_exp2, (void*)p->d_fast, (void*)p->d_ew2, (void*)p->d_bk2})
         cached_free(ptr);
     for (auto& t : p->probes)
         for (void* ptr : {(void*)t.d_rules, (void*)t.d_offset, (void*)t.d_fast, (void*)t.d_pc}) cached_free(ptr);
     delete p;
+    return CEG_OK;
+}
+
+extern "C" int ceg_image_cache_stats(int64_t* hits, int64_t* misses, int64_t* entries)
+{
+    std::lock_guard<std::mutex> lock(g_image_mutex);
+    if (hits) *hits = g_image_hits.load();
+    if (misses) *misses = g_image_misses.load();
+    if (entries) *entries = (int64_t)g_image_cache.size();
     return CEG_OK;
 }
 
@@ -1758,6 +1880,119 @@ extern "C" int ceg_grids_multi(const double* pos, const int64_t* atomkind, const
     return CEG_OK;
 }
 
+// ------------------------------------------------------------------ cached .grid file -> interpolation handle
+// The reference's common case is not "create" but "Retrieved ... grid" (src/raspa.jl:426-438 -> parse_grid, src/grids.jl:61-94):
+// the file is read into a host array, multiplied by GRID_TO_KELVIN, and only then would a GPU consumer upload it and make its
+// node-major copy.  Here the payload goes file -> pinned ring (parallel pread) -> device while the next chunk is being read,
+// is scaled on the device exactly like grids.jl:78 (Float32(Float64(x) * scale)) and handed to ceg_interp_create in place.
+extern "C" int ceg_interp_create(ceg_interp_t** handle, int32_t device, const float* grid, int32_t grid_on_device, const int32_t dims[3],
+                                 const double size[3], const double shift[3], const double mat[9], const double invmat[9], int32_t is_vdw);
+extern "C" int ceg_scale_grid_device(float* d_grid, int64_t nfloats, double scale, int32_t device, void* stream);
+
+extern "C" int ceg_interp_create_from_file(ceg_interp_t** handle, int32_t device, const char* path, int32_t iscoulomb, double scale,
+                                           const double* mat, const double* invmat, ceg_grid_header_t* header_out)
+{
+    if (!handle || !path) return fail(CEG_ERR_INVALID, "NULL argument");
+    *handle = nullptr;
+    if ((mat == nullptr) != (invmat == nullptr)) return fail(CEG_ERR_INVALID, "mat and invmat go together");
+    const int ndev = ceg_device_count();
+    if (ndev <= 0) return fail(CEG_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(CEG_ERR_NO_DEVICE, "device %d not present (%d devices)", device, ndev);
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(CEG_ERR_INVALID, "cannot open %s", path);
+    struct Closer { int fd; ~Closer() { close(fd); } } closer{fd};
+    // header (src/grids.jl:62-75, written by :108-116): f64 spacing, 3 x i32 dims, 3 x f64 size, shift, delta, unitcell lengths,
+    // 3 x i32 num_unitcell [, f64 Ewald precision]
+    unsigned char hb[136];
+    const size_t hbytes = iscoulomb ? 136 : 128;
+    if (pread(fd, hb, hbytes, 0) != (ssize_t)hbytes) return fail(CEG_ERR_INVALID, "%s: truncated header", path);
+    ceg_grid_header_t H{};
+    size_t o = 0;
+    auto rd = [&](void* dst, size_t n) { memcpy(dst, hb + o, n); o += n; };
+    rd(&H.spacing, 8); rd(H.dims, 12); rd(H.size, 24); rd(H.shift, 24); rd(H.delta, 24); rd(H.unitcell, 24); rd(H.num_unitcell, 12);
+    H.ewald_precision = std::numeric_limits<double>::infinity();          // EnergyGrid(..., Inf, ...) for a VdW grid (grids.jl:92)
+    if (iscoulomb) rd(&H.ewald_precision, 8);
+    for (int a = 0; a < 3; ++a)
+        if (H.dims[a] < 1 || H.dims[a] > (1 << 20) || !(H.size[a] > 0.0)) return fail(CEG_ERR_INVALID, "%s: not a .grid header (dims / size)", path);
+    const int64_t nodes = (int64_t)(H.dims[0] + 1) * (H.dims[1] + 1) * (H.dims[2] + 1);
+    const int64_t nfl = 8 * nodes;
+    const int64_t payload = nfl * (int64_t)sizeof(float);
+    const off_t fsize = lseek(fd, 0, SEEK_END);
+    if (fsize < (off_t)(hbytes + payload)) return fail(CEG_ERR_INVALID, "%s: file shorter than its header says", path);
+    H.has_mat = 0;
+    if (fsize >= (off_t)(hbytes + payload + 72) && pread(fd, H.mat, 72, (off_t)(hbytes + payload)) == 72) H.has_mat = 1;   // :154 / :182
+    double M[9], I[9];
+    if (mat) { memcpy(M, mat, sizeof M); memcpy(I, invmat, sizeof I); }
+    else {
+        if (!H.has_mat) return fail(CEG_ERR_INVALID, "%s carries no cell matrix: pass mat / invmat (parse_grid's `mat` argument, grids.jl:80-90)", path);
+        memcpy(M, H.mat, sizeof M);
+        const double* m = M;                         // column-major: m[i + 3 j]
+        const double c00 = m[4] * m[8] - m[7] * m[5], c01 = m[7] * m[2] - m[1] * m[8], c02 = m[1] * m[5] - m[4] * m[2];
+        const double det = m[0] * c00 + m[3] * c01 + m[6] * c02;
+        if (!(std::fabs(det) > 0.0)) return fail(CEG_ERR_INVALID, "%s: singular cell matrix", path);
+        const double id = 1.0 / det;
+        I[0] = c00 * id; I[1] = c01 * id; I[2] = c02 * id;
+        I[3] = (m[6] * m[5] - m[3] * m[8]) * id; I[4] = (m[0] * m[8] - m[6] * m[2]) * id; I[5] = (m[3] * m[2] - m[0] * m[5]) * id;
+        I[6] = (m[3] * m[7] - m[6] * m[4]) * id; I[7] = (m[6] * m[1] - m[0] * m[7]) * id; I[8] = (m[0] * m[4] - m[3] * m[1]) * id;
+    }
+    if (header_out) *header_out = H;
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(CEG_ERR_HIP, "hipSetDevice(%d) failed", device);
+    float* d_raw = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_raw, (size_t)payload));
+    hipStream_t s_comp = nullptr, s_copy = nullptr;
+    if (!streams_acquire(device, &s_comp, &s_copy)) { (void)hipFree(d_raw); return fail(CEG_ERR_HIP, "stream creation failed"); }
+    const size_t slot = 32ull << 20;
+    const int nchunks = (int)((payload + (int64_t)slot - 1) / (int64_t)slot);
+    const int R = std::min(3, nchunks);
+    char* ring = static_cast<char*>(pinned_acquire(slot * R));
+    std::vector<hipEvent_t> ev(R, nullptr);
+    int rc = ring ? CEG_OK : fail(CEG_ERR_HIP, "pinned buffer allocation failed");
+    for (int t = 0; t < R && !rc; ++t)
+        if (hipEventCreateWithFlags(&ev[t], hipEventDisableTiming) != hipSuccess) rc = fail(CEG_ERR_HIP, "event creation failed");
+    int nthreads = 8;
+    if (const char* env = std::getenv("CEG_HIP_COPY_THREADS")) nthreads = std::max(1, atoi(env));
+    for (int j = 0; j < nchunks && !rc; ++j) {
+        char* buf = ring + (size_t)(j % R) * slot;
+        if (j >= R && hipEventSynchronize(ev[j % R]) != hipSuccess) { rc = fail(CEG_ERR_HIP, "H2D copy failed"); break; }
+        const int64_t off = (int64_t)j * (int64_t)slot, len = std::min<int64_t>((int64_t)slot, payload - off);
+        std::atomic<bool> ok{true};
+        std::atomic<int64_t> next{0};
+        const int64_t piece = 1 << 20;
+        auto work = [&]() {
+            for (;;) {
+                const int64_t b = next.fetch_add(piece);
+                if (b >= len) return;
+                int64_t left = std::min(piece, len - b), at = b;
+                while (left > 0) {
+                    const ssize_t got = pread(fd, buf + at, (size_t)left, (off_t)(hbytes + off + at));
+                    if (got <= 0) { ok.store(false); return; }
+                    left -= got; at += got;
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nthreads; ++t) th.emplace_back(work);
+        work();
+        for (auto& x : th) x.join();
+        if (!ok.load()) { rc = fail(CEG_ERR_INVALID, "%s: read error", path); break; }
+        if (hipMemcpyAsync(reinterpret_cast<char*>(d_raw) + off, buf, (size_t)len, hipMemcpyHostToDevice, s_copy) != hipSuccess ||
+            hipEventRecord(ev[j % R], s_copy) != hipSuccess)
+            rc = fail(CEG_ERR_HIP, "hipMemcpyAsync H2D failed");
+    }
+    if (hipStreamSynchronize(s_copy) != hipSuccess && !rc) rc = fail(CEG_ERR_HIP, "H2D copy failed");
+    for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+    if (ring) pinned_release(ring);
+    if (!rc && scale != 1.0) {                       // grid .*= GRID_TO_KELVIN (grids.jl:78)
+        rc = ceg_scale_grid_device(d_raw, nfl, scale, device, s_copy);
+        if (!rc && hipStreamSynchronize(s_copy) != hipSuccess) rc = fail(CEG_ERR_HIP, "scaling kernel failed");
+    }
+    streams_release(s_comp);
+    if (!rc) rc = ceg_interp_create(handle, device, d_raw, 1, H.dims, H.size, H.shift, M, I, iscoulomb ? 0 : 1);
+    (void)hipFree(d_raw);
+    return rc;
+}
+
 extern "C" int ceg_release_cached_buffers(void)
 {
     std::lock_guard<std::mutex> lock(g_pinned_mutex);
@@ -1782,6 +2017,7 @@ extern "C" int ceg_release_cached_buffers(void)
             g_streams.erase(g_streams.begin() + t);
         }
     if (prev >= 0) (void)hipSetDevice(prev);
+    image_cache_release();
     block_cache_release();
     return CEG_OK;
 }

@@ -23,6 +23,8 @@ struct InterpGeom {
     double size[3], shift[3];
     int32_t dims[3];
     int32_t is_vdw;
+    int32_t trilinear;      // EnergyGrid.higherorder == false: the "no derivatives" branch of interpolate_grid (grids.jl:259-269)
+    int32_t _pad;
 };
 
 // 1-D cubic Hermite basis on [0,1]: value at 0, value at 1, slope at 0, slope at 1
@@ -70,6 +72,29 @@ __device__ __forceinline__ double interp_point(const InterpGeom& g, const float*
         i0 = i0 < 1 ? 1 : (i0 > ext[a] ? ext[a] : i0);
         p0[a] = i0;
         p1[a] = i0 + (i0 != ext[a] ? 1 : 0);
+    }
+    if (g.trilinear) {
+        // "no derivatives" (grids.jl:259-269): channel 1 at the 8 corners, trilinear weights, no blocking rule.  The reference
+        // indexes this branch as g.grid[x, y, z, 1] although the array is [z, y, x, channel] (:126-133, :227-244): the FIRST
+        // array index -- the one that runs along z -- receives the x cell index and vice versa.  Reproduced as written: an index
+        // beyond the axis it is applied to is a BoundsError in Julia and NaN here (cubic grids never get there).
+        const double mrx = 1.0 - r[0], mry = 1.0 - r[1], mrz = 1.0 - r[2];
+        auto at = [&](int a, int b, int c) -> double {        // g.grid[a, b, c, 1], 1-based; a indexes z, b y, c x
+            if (a < 1 || a > nz || b < 1 || b > ny || c < 1 || c > nx) return __builtin_nan("");
+            return (double)grid[8 * (((int64_t)(c - 1) * ny + (b - 1)) * nz + (a - 1))];
+        };
+        const int x0 = p0[0], y0 = p0[1], z0 = p0[2], x1 = p1[0], y1 = p1[1], z1 = p1[2];
+        {
+#pragma clang fp contract(off)
+            double ret = at(x0, y0, z0) * mrx * mry * mrz + at(x1, y0, z0) * r[0] * mry * mrz;
+            ret = ret + at(x0, y1, z0) * mrx * r[1] * mrz;
+            ret = ret + at(x0, y0, z1) * mrx * mry * r[2];
+            ret = ret + at(x1, y1, z0) * r[0] * r[1] * mrz;
+            ret = ret + at(x1, y0, z1) * r[0] * mry * r[2];
+            ret = ret + at(x0, y1, z1) * mrx * r[1] * r[2];
+            ret = ret + at(x1, y1, z1) * r[0] * r[1] * r[2];
+            return ret;
+        }
     }
     // node-major layout [x][y][z][8 channels]: the 8 channels of a corner are 32 contiguous bytes and
     // the two z neighbours of an (x, y) row 64 contiguous bytes

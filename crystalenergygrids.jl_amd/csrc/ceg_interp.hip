@@ -131,6 +131,13 @@ extern "C" int ceg_interp_create(ceg_interp_t** handle, int32_t device, const fl
     return CEG_OK;
 }
 
+extern "C" int ceg_interp_set_higherorder(ceg_interp_t* h, int32_t higherorder)
+{
+    if (!h) return ierr(CEG_ERR_INVALID, "bad argument");
+    h->g.trilinear = higherorder ? 0 : 1;
+    return CEG_OK;
+}
+
 extern "C" int ceg_interp_destroy(ceg_interp_t* h)
 {
     if (!h) return CEG_OK;

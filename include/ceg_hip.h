@@ -203,6 +203,11 @@ CEG_API int ceg_plan_create(ceg_plan_t** plan, int32_t device,
                     const int32_t dims[3], const double size[3], const double shift[3],
                     const double delta[3]);
 CEG_API int ceg_plan_destroy(ceg_plan_t* plan);
+/* The lattice-image list + bins of a plan (the ~1 ms host part of plan creation for a 10 k-atom framework) are kept on the device
+ * and shared between plans that need exactly the same list -- same framework, cell, cutoff, grid box, per-atom kind flags and
+ * charges --, which is what the K + 1 one-shot calls of one setup_RASPA and every later call on the same framework are; the
+ * last CEG_HIP_IMAGE_CACHE (default 6, 0 = off) lists are kept, ceg_release_cached_buffers drops them.  Counters since load: */
+CEG_API int ceg_image_cache_stats(int64_t* hits, int64_t* misses, int64_t* entries);
 
 /* 1 if the culled algorithm is valid for this plan (every perpendicular width of
  * `mat` is >= 2*cutoff, which ProbeSystem guarantees, src/probes.jl:24), else 0. */
@@ -310,10 +315,35 @@ CEG_API int ceg_plan_eval_points(ceg_plan_t* plan, int32_t which, int32_t algo,
  */
 typedef struct ceg_interp ceg_interp_t;
 
+/* What parse_grid (src/grids.jl:61-94) reads from a .grid file besides the payload. */
+typedef struct ceg_grid_header {
+    double  spacing;
+    int32_t dims[3];
+    int32_t has_mat;            /* 1 if the file ends with the 9 x f64 cell matrix (grids.jl:154,182), then in `mat` */
+    double  size[3], shift[3], delta[3], unitcell[3];
+    int32_t num_unitcell[3];
+    int32_t _pad;
+    double  ewald_precision;    /* Inf for a VdW grid (grids.jl:92) */
+    double  mat[9];             /* column-major */
+} ceg_grid_header_t;
+
 CEG_API int ceg_interp_create(ceg_interp_t** handle, int32_t device,
                               const float* grid, int32_t grid_on_device,
                               const int32_t dims[3], const double size[3], const double shift[3],
                               const double mat[9], const double invmat[9], int32_t is_vdw);
+/* A cached grid straight from its file ("Retrieved ... grid", src/raspa.jl:426-438 -> parse_grid, src/grids.jl:61-94): header
+ * parsed, payload streamed file -> pinned ring -> device, multiplied by `scale` (GRID_TO_KELVIN, grids.jl:78: each product formed
+ * in Float64 and rounded to Float32) on the device, node-major copy made -- no host array, no second upload.
+ *  iscoulomb   the file carries the Ewald precision after the header (136 bytes instead of 128); VdW grids get the 5e6 rule
+ *  mat,invmat  both NULL: the cell matrix stored at the end of the file is used (its inverse is formed here); else the unit-cell
+ *              matrix and its inverse as for ceg_interp_create (parse_grid's `mat` argument)
+ *  header_out  may be NULL */
+CEG_API int ceg_interp_create_from_file(ceg_interp_t** handle, int32_t device, const char* path, int32_t iscoulomb, double scale,
+                                const double* mat, const double* invmat, ceg_grid_header_t* header_out);
+/* EnergyGrid.higherorder (grids.jl:21-29): 1 (default) the tricubic branch; 0 the "no derivatives" branch of interpolate_grid
+ * (:259-269) -- channel 1 at the 8 corners, trilinear weights, no blocking rule, with the reference's index order for that branch
+ * (it addresses the [z, y, x, channel] array as [x, y, z, 1]); an index beyond its axis (a BoundsError in Julia) gives NaN. */
+CEG_API int ceg_interp_set_higherorder(ceg_interp_t* handle, int32_t higherorder);
 CEG_API int ceg_interp_destroy(ceg_interp_t* handle);
 /* points [3*n] cartesian A, out [n] K; host memory, synchronous */
 CEG_API int ceg_interp_points(ceg_interp_t* handle, const double* points, int64_t npoints, double* out);

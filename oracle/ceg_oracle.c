@@ -489,6 +489,58 @@ ORACLE_API double oracle_interpolate_grid(const float* grid, const int32_t dims[
     return ret;
 }
 
+/* interpolate_grid, branch `higherorder == false` (src/grids.jl:259-269): channel 1 only, trilinear weights, no blocking rule,
+ * sum in the reference's order.  The reference writes g.grid[x0,y0,z0,1] ... although the array is [z, y, x, channel]
+ * (:126-133, :227-244): the first array index, which runs along z, gets the x cell index and the third, which runs along x,
+ * the z cell index.  Restated as written; an index outside the axis it lands on is a BoundsError in Julia -> NaN here. */
+ORACLE_API double oracle_interpolate_grid_noderiv(const float* grid, const int32_t dims[3], const double size[3],
+                                                  const double shift[3], const double mat[9], const double invmat[9],
+                                                  const double point[3])
+{
+    double abc[3], frac[3], np_[3], shifted[3];
+    matvec3(abc, invmat, point);
+    for (int i = 0; i < 3; ++i) frac[i] = abc[i] - floor(abc[i]);
+    matvec3(np_, mat, frac);
+    for (int i = 0; i < 3; ++i) shifted[i] = (np_[i] - shift[i]) * (double)dims[i] / size[i] + 1;
+    const int64_t nx = dims[0] + 1, ny = dims[1] + 1, nz = dims[2] + 1;
+    const int64_t ext[3] = {nx, ny, nz};
+    int64_t p0[3], p1[3];
+    double r[3];
+    for (int i = 0; i < 3; ++i) {
+        p0[i] = (int64_t)floor(shifted[i]);
+        p1[i] = p0[i] + (p0[i] != ext[i]);
+        r[i] = shifted[i] - (double)p0[i];
+    }
+    const double rx = r[0], ry = r[1], rz = r[2], mrx = 1 - rx, mry = 1 - ry, mrz = 1 - rz;
+    const int64_t x0 = p0[0], y0 = p0[1], z0 = p0[2], x1 = p1[0], y1 = p1[1], z1 = p1[2];
+    /* g.grid[a, b, c, 1] of the [z, y, x, channel] array, 1-based: a runs along z, b along y, c along x */
+#define GA_(a, b, c) (((a) < 1 || (a) > nz || (b) < 1 || (b) > ny || (c) < 1 || (c) > nx) ? (double)NAN \
+                      : (double)grid[(((c) - 1) * ny + ((b) - 1)) * nz + ((a) - 1)])
+    double ret = GA_(x0, y0, z0) * mrx * mry * mrz + GA_(x1, y0, z0) * rx * mry * mrz;
+    ret = ret + GA_(x0, y1, z0) * mrx * ry * mrz;
+    ret = ret + GA_(x0, y0, z1) * mrx * mry * rz;
+    ret = ret + GA_(x1, y1, z0) * rx * ry * mrz;
+    ret = ret + GA_(x1, y0, z1) * rx * mry * rz;
+    ret = ret + GA_(x0, y1, z1) * mrx * ry * rz;
+    ret = ret + GA_(x1, y1, z1) * rx * ry * rz;
+#undef GA_
+    return ret;
+}
+
+ORACLE_API void oracle_interpolate_points_noderiv(const float* grid, const int32_t dims[3], const double size[3],
+                                                  const double shift[3], const double mat[9], const double invmat[9],
+                                                  const double* points, int64_t n, double* out, int32_t nthreads)
+{
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < n; ++p)
+        out[p] = oracle_interpolate_grid_noderiv(grid, dims, size, shift, mat, invmat, points + 3 * p);
+}
+
 ORACLE_API void oracle_interpolate_points(const float* grid, const int32_t dims[3], const double size[3],
                                           const double shift[3], const double mat[9], const double invmat[9],
                                           int is_vdw, const double* coeff, const double* points, int64_t n,

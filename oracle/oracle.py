@@ -65,6 +65,8 @@ def lib() -> C.CDLL:
         l.oracle_points_coulomb.restype = C.c_int
         l.oracle_points_coulomb.argtypes = [_dp, _dp, C.c_int64, _dp, _dp, C.c_int, C.c_double, C.c_double,
                                             C.c_double, _dp, C.c_int64, _dp, C.c_int32]
+        l.oracle_interpolate_points_noderiv.restype = None
+        l.oracle_interpolate_points_noderiv.argtypes = [_fp, _i32p, _dp, _dp, _dp, _dp, _dp, C.c_int64, _dp, C.c_int32]
         l.oracle_interpolate_points.restype = None
         l.oracle_interpolate_points.argtypes = [_fp, _i32p, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp, C.c_int64, _dp, C.c_int32]
         l.oracle_reciprocal_energies.restype = None
@@ -230,6 +232,10 @@ def interpolate_points(g, points, nthreads=0) -> np.ndarray:
     coeff = np.ascontiguousarray(tricubic_coeff(), dtype=np.float64)
     pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
     out = np.empty(len(pts), dtype=np.float64)
+    if not g.higherorder:          # the "no derivatives" branch (grids.jl:259-269): channel 1, trilinear, the reference's index order
+        lib().oracle_interpolate_points_noderiv(grid.ctypes.data_as(_fp), dims.ctypes.data_as(_i32p), _d(size), _d(shift),
+                                                _d(_cm(cs.cell.mat)), _d(_cm(cs.cell.invmat)), _d(pts), len(pts), _d(out), nthreads)
+        return out
     lib().oracle_interpolate_points(grid.ctypes.data_as(_fp), dims.ctypes.data_as(_i32p), _d(size), _d(shift),
                                     _d(_cm(cs.cell.mat)), _d(_cm(cs.cell.invmat)),
                                     1 if g.ewald_precision == math.inf else 0, _d(coeff), _d(pts), len(pts), _d(out), nthreads)

@@ -1215,3 +1215,116 @@ def test_setup_raspa_builds_missing_grids_in_one_pass(hip_lib, oracle, tmp_path)
         assert na.grids[0].grid.shape[0] == 8 and np.isfinite(ceg.energy_point(na, np.array([[3.1, 4.2, 5.3]]))[0])
     finally:
         ceg.setdir_RASPA(golden)
+
+
+def test_image_cache_is_shared_and_changes_nothing(hip_lib, monkeypatch):
+    """The lattice-image list of a plan is cached on the device and shared between plans that need the same one (the K + 1
+    one-shot calls of a setup_RASPA; ceg_image_cache_stats): same framework + same per-atom flags -> a hit, another probe whose
+    active kinds differ or a Coulomb plan -> its own list; results bit-identical with the cache switched off."""
+    import ctypes as C
+
+    def stats():
+        h, m, e = C.c_int64(), C.c_int64(), C.c_int64()
+        hip_lib.ceg_image_cache_stats(C.byref(h), C.byref(m), C.byref(e))
+        return h.value, m.value, e.value
+
+    hip_lib.ceg_release_cached_buffers()
+    ws = {a: W.fixture_workload("CHA_1.4_3b4eeb96", a, 0.7) for a in ("C_co2", "O_co2", "Ar")}
+    h0, m0, _ = stats()
+    g1 = G.build_vdw_array(ws["C_co2"].probe_vdw, ws["C_co2"].cset)
+    g2 = G.build_vdw_array(ws["O_co2"].probe_vdw, ws["O_co2"].cset)      # same active kinds (every framework atom): shared list
+    g3 = G.build_vdw_array(ws["Ar"].probe_vdw, ws["Ar"].cset)            # Si / Al carry no Ar rule: another list
+    g4 = G.build_vdw_array(ws["C_co2"].probe_vdw, ws["C_co2"].cset)
+    gc = G.build_coulomb_array(ws["Ar"].probe_coulomb, ws["Ar"].alpha, ws["Ar"].cset)
+    gc2 = G.build_coulomb_array(ws["Ar"].probe_coulomb, ws["Ar"].alpha, ws["Ar"].cset)
+    h1, m1, e1 = stats()
+    assert (h1 - h0, m1 - m0) == (3, 3) and e1 == 3, (h1 - h0, m1 - m0, e1)
+    assert np.array_equal(g1.view(np.int32), g4.view(np.int32)) and np.array_equal(gc.view(np.int32), gc2.view(np.int32))
+    monkeypatch.setenv("CEG_HIP_IMAGE_CACHE", "0")
+    for a, g in (("C_co2", g1), ("O_co2", g2), ("Ar", g3)):
+        assert np.array_equal(G.build_vdw_array(ws[a].probe_vdw, ws[a].cset).view(np.int32), g.view(np.int32)), a
+    assert np.array_equal(G.build_coulomb_array(ws["Ar"].probe_coulomb, ws["Ar"].alpha, ws["Ar"].cset).view(np.int32), gc.view(np.int32))
+    assert stats()[0] == h1                                               # switched off: no look-ups
+    monkeypatch.delenv("CEG_HIP_IMAGE_CACHE")
+    hip_lib.ceg_release_cached_buffers()
+    assert stats()[2] == 0
+
+
+def test_cached_grid_file_straight_to_the_device(hip_lib, oracle, tmp_path, forcefield):
+    """ceg_interp_create_from_file: the reference's "Retrieved ... grid" path (raspa.jl:426-438 -> parse_grid, grids.jl:61-94)
+    without the host array.  The handle made from the file interpolates bit-identically to parse_grid + GridInterpolator(g),
+    the header it reports is parse_grid's, a Coulomb file (136-byte header) and a VdW file, with and without the `mat` argument;
+    truncated / missing files are errors."""
+    from ceg_hip.interp import GridInterpolator
+    fw = ceg.load_framework_RASPA("CIT-7", "BoulfelfelSholl2021")
+    ceg.create_grid_vdw(tmp_path / "v.grid", fw, forcefield, 0.35, "Ar")
+    ceg.create_grid_coulomb(tmp_path / "c.grid", fw, forcefield, 0.35, ceg.initialize_ewald(fw))
+    rng = np.random.default_rng(9)
+    pts = rng.uniform(-40, 60, (5000, 3))
+    for name, isc in (("v.grid", False), ("c.grid", True)):
+        eg = ceg.parse_grid(tmp_path / name, isc)
+        host = GridInterpolator(eg)
+        ref = host(pts)
+        for mat in (None, fw.mat):
+            it, hdr = GridInterpolator.from_file(tmp_path / name, isc, mat=mat, with_header=True)
+            got = it(pts)
+            if mat is not None:            # the caller's matrices, as parse_grid(file, iscoulomb, mat): same bits in, same bits out
+                assert np.array_equal(got, ref), name
+            else:                          # the file's own matrix, inverted in the library: the wrap differs in the last bit
+                m = ref != 1e100
+                assert np.array_equal(got == 1e100, ~m) and np.allclose(got[m], ref[m], rtol=1e-9, atol=1e-9 * np.median(np.abs(ref[m])))
+            assert tuple(hdr.dims) == tuple(int(x) for x in eg.csetup.dims) and tuple(hdr.num_unitcell) == eg.num_unitcell == (2, 3, 3)
+            assert np.array_equal(np.array(hdr.size), eg.csetup.size) and np.array_equal(np.array(hdr.shift), eg.csetup.shift)
+            assert hdr.has_mat == 1 and hdr.spacing == eg.csetup.spacing
+            assert (hdr.ewald_precision == 1e-6) if isc else math.isinf(hdr.ewald_precision)
+            it.close()
+        host.close()
+        assert (ref == 1e100).any() == (not isc)                       # the VdW blocking rule came along
+        lit = oracle.interpolate_points(eg, pts[:500])
+        m = lit != 1e100
+        assert np.all(np.abs(ref[:500][m] - lit[m]) <= 1e-9 * np.abs(lit[m]) + 1e-10 * np.median(np.abs(lit[m])))
+    data = (tmp_path / "v.grid").read_bytes()
+    (tmp_path / "short.grid").write_bytes(data[: len(data) // 2])
+    for bad in ("short.grid", "missing.grid"):
+        with pytest.raises(_abi.CegError) as ei:
+            GridInterpolator.from_file(tmp_path / bad, False)
+        assert ei.value.code == -1
+    (tmp_path / "nomat.grid").write_bytes(data[:-72])                  # a RASPA-made file has no trailing matrix (grids.jl:80-90)
+    with pytest.raises(_abi.CegError):
+        GridInterpolator.from_file(tmp_path / "nomat.grid", False)
+    it = GridInterpolator.from_file(tmp_path / "nomat.grid", False, mat=fw.mat)
+    assert np.array_equal(it(pts[:100]), GridInterpolator(ceg.parse_grid(tmp_path / "v.grid", False, fw.mat))(pts[:100]))
+    it.close()
+
+
+def test_interpolation_without_derivatives(hip_lib, oracle):
+    """EnergyGrid.higherorder == false: the trilinear branch of interpolate_grid (grids.jl:259-269), which addresses the
+    [z, y, x, channel] array as [x, y, z, 1].  GPU (ceg_interp_set_higherorder), host mirror and oracle agree; on a cubic grid
+    every point is in bounds, on a non-cubic one the out-of-bounds pattern (Julia: BoundsError; here NaN / IndexError) matches."""
+    from ceg_hip.interp import GridInterpolator
+    rng = np.random.default_rng(21)
+    for dims in ((21, 21, 21), (25, 17, 21)):
+        mat = np.diag([20.0, 20.0, 20.0]) + np.array([[0, 1.5, -0.7], [0, 0, 2.1], [0, 0, 0]])
+        cset = W.grid_setup_with_dims(mat, dims)
+        nx, ny, nz = cset.npoints
+        grid = rng.normal(size=(8, nx, ny, nz)).astype(np.float32)
+        eg = G.EnergyGrid(cset, (1, 1, 1), math.inf, False, grid)
+        pts = rng.uniform(-30, 50, (3000, 3))
+        ref = oracle.interpolate_points(eg, pts)
+        it = GridInterpolator(eg)
+        got = it(pts)
+        it.close()
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        ok = ~np.isnan(ref)
+        assert np.array_equal(got[ok], ref[ok])                       # same operation order, no contraction: bitwise
+        assert ok.all() == (len(set(dims)) == 1) and ok.any()
+        for q in range(40):
+            if ok[q]:
+                # (the mirror's numpy mat-vec rounds the wrapped position differently in the last bit: 1e-14 in r)
+                assert G.interpolate_grid(eg, pts[q]) == pytest.approx(ref[q], rel=1e-10, abs=1e-12)
+            else:
+                with pytest.raises(IndexError):
+                    G.interpolate_grid(eg, pts[q])
+        # and the tricubic branch of the same data is something else entirely
+        eg3 = G.EnergyGrid(cset, (1, 1, 1), 1e-6, True, grid)
+        assert not np.allclose(oracle.interpolate_points(eg3, pts[ok][:50]), ref[ok][:50])

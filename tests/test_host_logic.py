@@ -374,3 +374,26 @@ def test_bench_cpu_baseline_leg(monkeypatch):
         assert cb["cores"] == O.usable_cpus() and 0.01 < cb["parallel_efficiency"] < 4.0      # not 1 after the single-thread probe
         assert cb["pair_checks_per_s_per_thread"] == pytest.approx(cb["pair_checks_per_s"] / cb["cores"])
         assert "preallocated" in cb["sample"]
+
+
+def test_interpolate_grid_without_derivatives_host_mirror_vs_oracle(oracle):
+    """The "no derivatives" branch of interpolate_grid (grids.jl:259-269) in the host mirror and in the oracle: same values where
+    the reference's [x, y, z] addressing of its [z, y, x] array stays in bounds, IndexError / NaN where Julia raises BoundsError."""
+    import math
+    from ceg_hip import grids as G, workloads as W
+    rng = np.random.default_rng(21)
+    for dims in ((21, 21, 21), (25, 17, 21)):
+        mat = np.diag([20.0, 20.0, 20.0]) + np.array([[0, 1.5, -0.7], [0, 0, 2.1], [0, 0, 0]])
+        cset = W.grid_setup_with_dims(mat, dims)
+        nx, ny, nz = cset.npoints
+        eg = G.EnergyGrid(cset, (1, 1, 1), math.inf, False, rng.normal(size=(8, nx, ny, nz)).astype(np.float32))
+        pts = rng.uniform(-30, 50, (400, 3))
+        ref = oracle.interpolate_points(eg, pts)
+        ok = ~np.isnan(ref)
+        assert ok.all() == (len(set(dims)) == 1) and ok.any()
+        for q in range(60):
+            if ok[q]:
+                assert G.interpolate_grid(eg, pts[q]) == pytest.approx(ref[q], rel=1e-10, abs=1e-12)
+            else:
+                with pytest.raises(IndexError):
+                    G.interpolate_grid(eg, pts[q])
