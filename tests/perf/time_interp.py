@@ -33,6 +33,15 @@ e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 5
 print(f"GPU interpolate_grid: {n} random points on a {nx}x{ny}x{nz} grid ({d_grid.numel()*4/1e6:.0f} MB): {ms:.3f} ms -> {n/ms*1e3:.3e} points/s; "
       f"gathered bytes {n*256/ms*1e3/1e9:.0f} GB/s (64 floats/point)")
+# roofline.  Algorithmic bytes per position: 8 corners x 8 channels x 4 B = 256 B read (the node-major copy makes
+# them 4 contiguous 64-B pieces: the two z neighbours of an (x, y) corner pair are adjacent) + 24 B position in + 8 B energy out.
+# The 270 MB grid exceeds the 256 MiB Infinity Cache and the positions are random: every piece is an HBM access; if the fabric moves
+# whole 128-B lines for a 64-B piece the traffic is 2 x that.  Bound: HBM (8 TB/s), not the ALU (64 weighted terms = ~250 flops per
+# position = 2.3 TFLOP/s at this rate, 3 % of the FP64 peak).
+alg = n * (256 + 32) / (ms * 1e-3)
+print(f"roofline k_interpolate: algorithmic {256 + 32} B/position -> {alg/1e12:.2f} TB/s = {alg/8e12:.2f} of the 8 TB/s HBM peak "
+      f"(with 128-B line granularity of the 64-B pieces: {n * (512 + 32) / (ms * 1e-3) / 8e12:.2f}); FP64 work ~250 flops/position = "
+      f"{n * 250 / (ms * 1e-3) / 78.6e12:.3f} of the vector peak -> HBM / gather-fabric bound")
 m = 200000
 hp = pts[:m].cpu().numpy()
 t = time.perf_counter(); ref = O.interpolate_points(eg, hp); dt = time.perf_counter() - t

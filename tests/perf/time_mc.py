@@ -50,6 +50,17 @@ for nbatch, reps in ((1, 2000), (16, 1000), (1024, 200), (65536, 10)):
     dt, e = bench(nbatch, reps)
     print(f"GPU  batch {nbatch:6d}: {dt * 1e6:9.1f} us per call (trial launch + every second call an accept) = {dt * 1e6 / nbatch:9.3f} us per trial placement")
 
+# roofline.  Algorithmic work of ONE placement of a 3-atom CO2 among 64 CO2 (192 guest atoms), 1368 k-vectors:
+# interpolation 3 atoms x 2 grids x 256 B gathered = 1.5 KB and ~1500 flops; pair sum 3 x 189 tests x 47 + in-cutoff rules ~ 30 kflop;
+# reciprocal 3 x 1368 x 16 + 1368 x 10 + tables ~ 85 kflop: ~0.12 Mflop and 2 KB per placement.  At batch 1 the launch is TWO
+# workgroups (current position + the trial) on 256 CUs: 15 us of kernel + 14 us of launch / completion latency against a
+# speed-of-light of 0.12 Mflop / 78.6 TFLOP/s = 1.5 ns -- latency bound by four orders of magnitude, which is why the per-placement
+# cost keeps falling up to batches of ~10^4 placements (the figure to read is the large-batch one).
+dt_big = bench(65536, 10)[0]
+fl = 65537 * (3 * 1368 * 16.0 + 1368 * 10.0 + 3 * 51 * 40.0 + 3 * 189 * 47.0 + 60 * 72.0 + 1500.0)
+print(f"roofline k_mc_trial, batch 65536: ~{fl / 65537 / 1e3:.0f} kflop/placement -> {fl / dt_big / 1e12:.2f} TFLOP/s = {fl / dt_big / 78.6e12:.3f} of the FP64 "
+      f"vector peak; batch 1: latency bound (2 workgroups on 256 CUs)")
+
 # CPU: the oracle's three sums for the same molecule, one thread, amortised over 2000 placements (no per-call overhead)
 idx = mols[7 % len(mols)]
 cur = mc.positions[idx[0]][idx[1]]

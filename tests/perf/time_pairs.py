@@ -41,6 +41,15 @@ e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 5
 print(f"GPU single_contribution_vdw: {n} trial CO2 placements x {len(pos)} guest atoms: {ms:.3f} ms -> {n/ms*1e3:.3e} placements/s "
       f"({n*3*len(pos)/ms*1e3:.3e} pair tests/s)")
+# roofline.  Algorithmic FP64 work: every (trial atom, guest atom) pair is distance-tested with the reference's
+# unsafe_periodic_distance2! (utils.jl:294-302): 3 subtractions + invmat*d (15) + wrap (9) + mat*f (15) + norm (5) = 47 flops; the
+# ~10 % of pairs inside the cutoff add the pair rule (LJ 12 flops, CoulombEwaldDirect ~60 with exp / erfc at nominal 20 / 40).
+# Bytes: the guest atoms (32 B each) are read once per workgroup from L2, 72 B per placement in, 8 B out -> compute bound.
+npair = n * 3.0 * len(pos)
+flops = npair * 47.0 + 0.10 * npair * 72.0
+print(f"roofline k_pairs: {flops / n:.0f} algorithmic flops/placement -> {flops / (ms * 1e-3) / 1e12:.2f} TFLOP/s = "
+      f"{flops / (ms * 1e-3) / 78.6e12:.3f} of the FP64 vector peak (exhaustive loop; the neighbour-cell path tests fewer pairs); "
+      f"HBM {n * 80 / (ms * 1e-3) / 1e9:.1f} GB/s (negligible)")
 m = 4000
 hp = trial[:m].cpu().numpy()
 t = time.perf_counter(); ref = O.single_contribution_vdw(mc, (0, 0), hp); dt = time.perf_counter() - t

@@ -37,6 +37,16 @@ for molname in ("Na", "CO2"):
     nk = len(ef.kfactors)
     print(f"GPU compute_ewald {molname}: {n} placements x {nk} k-vectors x {na} atoms: {ms:.3f} ms -> {n/ms*1e3:.3e} placements/s "
           f"({n*nk*na/ms*1e3:.3e} atom-kvec/s)")
+    # roofline.  Algorithmic FP64 work per placement: per atom and k-vector the product of three table entries
+    # (2 complex multiplications = 12 flops), the charge (2) and the accumulation into the structure factor (2) = 16 flops; per
+    # k-vector the two energy terms 2 kf Re(conj(F) S) + kf |S|^2 = 10 flops; per atom the (kx+1) + (2ky+1) + (2kz+1) table entries
+    # by sincospi (~40 flops each).  Bytes: 24 B per atom in, 8 B out, tables and k-vector constants live in LDS -> compute bound.
+    ks = np.asarray(ef.kspace.ks)
+    ntab = int(ks[0] + 1 + 2 * ks[1] + 1 + 2 * ks[2] + 1)
+    flops = n * (na * nk * 16.0 + nk * 10.0 + na * ntab * 40.0)
+    print(f"roofline k_recip {molname}: {flops / n:.0f} algorithmic flops/placement -> {flops / (ms * 1e-3) / 1e12:.2f} TFLOP/s = "
+          f"{flops / (ms * 1e-3) / 78.6e12:.3f} of the FP64 vector peak; HBM {n * (24 * na + 8) / (ms * 1e-3) / 1e9:.1f} GB/s (negligible) -> "
+          f"bound by the per-lane LDS table look-ups + complex products (latency / LDS pipe), not by HBM")
     m = 20000
     hp = pos[:m].cpu().numpy()
     t = time.perf_counter(); ref = O.reciprocal_energies(ef, mol, hp); dt = time.perf_counter() - t
