@@ -1744,9 +1744,28 @@ int resident_pipeline(int mode, int slab_index, int d, int target, int b, int e,
     const int nchunks = (e - b + cx - 1) / cx;
     float* d_out = nullptr;
     hipEvent_t ev = nullptr;
+    // Can this device write into the target's memory?  (xGMI peers of one node: yes.)  If not -- or with CEG_HIP_NO_PEER=1, a
+    // rehearsal aid -- the slab is not pushed chunk by chunk with hipMemcpyPeerAsync but travels through a pinned host buffer once
+    // it is complete (D2H on this device, H2D on the target), and a note says so.
+    bool peer = true;
     if (!direct) {
-        if (d != target) (void)hipDeviceEnablePeerAccess(target, 0);        // already enabled / not possible: the copy still works
-        (void)hipGetLastError();
+        if (d != target) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, d, target) != hipSuccess) can = 0;
+            (void)hipGetLastError();
+            if (can) {
+                (void)hipDeviceEnablePeerAccess(target, 0);                 // "already enabled" is fine
+                (void)hipGetLastError();
+            }
+            peer = can != 0;
+        }
+        if (std::getenv("CEG_HIP_NO_PEER")) peer = false;
+        if (!peer) {
+            static std::atomic<bool> said{false};
+            if (!said.exchange(true))
+                fprintf(stderr, "[ceg_hip] note: no peer access from device %d to device %d%s: slabs of the device-resident build travel "
+                                "through pinned host memory\n", d, target, std::getenv("CEG_HIP_NO_PEER") ? " (CEG_HIP_NO_PEER)" : "");
+        }
         d_out = static_cast<float*>(device_acquire(d, sizeof(float) * 8 * slab_pts));
         if (!d_out || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) rc = bad(CEG_ERR_HIP, "allocation of the slab buffer failed");
     }
@@ -1758,7 +1777,7 @@ int resident_pipeline(int mode, int slab_index, int d, int target, int b, int e,
         rc = (mode == MODE_VDW) ? ceg_plan_build_vdw(plan, lambda, threshold, cb, ce, out, stride, origin, CEG_ALGO_AUTO, s_comp)
                                 : ceg_plan_build_coulomb(plan, lambda, threshold, cb, ce, out, stride, origin, CEG_ALGO_AUTO, s_comp);
         if (rc) { *err = g_err; break; }
-        if (direct) continue;
+        if (direct || !peer) continue;
         if (hipEventRecord(ev, s_comp) != hipSuccess || hipStreamWaitEvent(s_copy, ev, 0) != hipSuccess) { rc = bad(CEG_ERR_HIP, "event failed"); break; }
         const size_t cpts = (size_t)(ce - cb) * plane;
         for (int c = 0; c < 8 && !rc; ++c)
@@ -1768,6 +1787,18 @@ int resident_pipeline(int mode, int slab_index, int d, int target, int b, int e,
     }
     if (hipStreamSynchronize(s_comp) != hipSuccess && !rc) rc = bad(CEG_ERR_HIP, "kernel execution failed");
     if (hipStreamSynchronize(s_copy) != hipSuccess && !rc) rc = bad(CEG_ERR_HIP, "peer copy failed");
+    if (!rc && !direct && !peer) {                         // host-staged hand-over of the finished slab
+        float* h_buf = static_cast<float*>(pinned_acquire(sizeof(float) * 8 * (size_t)slab_pts));
+        if (!h_buf) rc = bad(CEG_ERR_HIP, "pinned buffer allocation failed");
+        if (!rc && hipMemcpy(h_buf, d_out, sizeof(float) * 8 * (size_t)slab_pts, hipMemcpyDeviceToHost) != hipSuccess) rc = bad(CEG_ERR_HIP, "D2H of the slab failed");
+        if (!rc && hipSetDevice(target) != hipSuccess) rc = bad(CEG_ERR_HIP, "hipSetDevice(target) failed");
+        for (int c = 0; c < 8 && !rc; ++c)
+            if (hipMemcpy(d_grid + (size_t)c * npts + (size_t)b * plane, h_buf + (size_t)c * slab_pts, sizeof(float) * (size_t)slab_pts,
+                          hipMemcpyHostToDevice) != hipSuccess)
+                rc = bad(CEG_ERR_HIP, "H2D of the slab failed");
+        (void)hipSetDevice(d);
+        if (h_buf) pinned_release(h_buf);
+    }
     if (ev) (void)hipEventDestroy(ev);
     if (d_out) device_release(d_out);
     streams_release(s_comp);

@@ -663,6 +663,12 @@ def test_device_resident_oneshot(hip_lib, monkeypatch):
     for ng in (2, 3, 4) if n < 2 else (min(n, 4),):
         assert np.array_equal(G.build_vdw_device(w.probe_vdw, w.cset, ngpus=ng).cpu().numpy(), host_v, equal_nan=True), ng
         assert np.array_equal(G.build_coulomb_device(w.probe_coulomb, w.alpha, w.cset, ngpus=ng).cpu().numpy(), host_c, equal_nan=True), ng
+    # devices without peer access (forced: CEG_HIP_NO_PEER): the finished slabs travel through pinned host memory instead
+    monkeypatch.setenv("CEG_HIP_NO_PEER", "1")
+    ng = 3 if n < 2 else min(n, 4)
+    assert np.array_equal(G.build_vdw_device(w.probe_vdw, w.cset, ngpus=ng).cpu().numpy(), host_v, equal_nan=True)
+    assert np.array_equal(G.build_coulomb_device(w.probe_coulomb, w.alpha, w.cset, ngpus=ng).cpu().numpy(), host_c, equal_nan=True)
+    monkeypatch.delenv("CEG_HIP_NO_PEER")
     if n < 2:
         monkeypatch.delenv("CEG_HIP_OVERSUBSCRIBE")
         with pytest.raises(_abi.CegError):
