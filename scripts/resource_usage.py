@@ -19,9 +19,9 @@ for line in out.splitlines():
         if m:
             rec[key] = int(m.group(1))
     if "lds" in rec and "name" in rec:
-        m = re.match(r"_ZN3ceg8k_culledILi(\d)ELb(\d)ELi(\d)ELi(\d)E", rec["name"])
+        m = re.match(r"_ZN3ceg8k_culledILi(\d)ELb(\d)ELi(\d)ELi(\d)ELi(\d)EE", rec["name"])
         if m:
-            mode, pts, vdwk, ewk = (int(x) for x in m.groups())
-            print(f"k_culled<{MODE[mode]:7s} {'points' if pts else 'grid  '} VDWK={vdwk} EWK={ewk}>  VGPR {rec.get('vgpr'):3d}  SGPR {rec.get('sgpr'):3d}  "
+            mode, pts, vdwk, ewk, npr = (int(x) for x in m.groups())
+            print(f"k_culled<{MODE[mode]:7s} {'points' if pts else 'grid  '} VDWK={vdwk} EWK={ewk} NP={npr}>  VGPR {rec.get('vgpr'):3d}  SGPR {rec.get('sgpr'):3d}  "
                   f"scratch {rec.get('scratch'):3d} B/lane  spills S {rec.get('sspill'):3d} V {rec.get('vspill'):3d}  LDS {rec.get('lds'):6d} B  occupancy {rec.get('occ')}")
         rec = {}

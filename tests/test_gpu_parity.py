@@ -1332,3 +1332,57 @@ def test_interpolation_without_derivatives(hip_lib, oracle):
         # and the tricubic branch of the same data is something else entirely
         eg3 = G.EnergyGrid(cset, (1, 1, 1), 1e-6, True, grid)
         assert not np.allclose(oracle.interpolate_points(eg3, pts[ok][:50]), ref[ok][:50])
+
+
+@pytest.mark.parametrize("name,lengths,angles", [
+    ("skewed-60", (31.0, 31.0, 31.0), (60.0, 60.0, 60.0)),             # safemin2 < cutoff2: the stale-vector branch is live
+    ("skewed-mixed", (30.0, 33.0, 36.0), (65.0, 110.0, 75.0)),
+    ("near-ortho", (26.0, 26.0, 26.0), (91.5, 88.6, 90.9)),            # ortho flag: images dropped like the reference does
+    ("orthorhombic", (25.0, 27.0, 30.0), (90.0, 90.0, 90.0)),
+])
+def test_multi_probe_cells_and_min_image_branches(hip_lib, oracle, name, lengths, angles, monkeypatch):
+    """The multi-probe kernels in the cells that exercise the min-image selection rule (wrap-boundary images, the stale image
+    vector of utils.jl:234-245, the ortho shortcut): three synthetic Lennard-Jones probes (one with a shifted rule, one with a
+    kind it does not interact with, one whose rule is a LJ + CoulombEwaldDirect sum) + Coulomb, points that fall on atoms; every
+    grid against the oracle, and against the same request through ceg_grids_multi on 1 and 3 (oversubscribed) slabs."""
+    import torch
+    import zlib
+    from ceg_hip.plan import MultiGridPlan
+    mat = mat_from_parameters(lengths, angles)
+    rng = np.random.default_rng(zlib.crc32(name.encode()) + 7)
+    n = 160
+    pos = random_atoms(mat, n, rng)
+    kinds = rng.integers(1, 5, n)
+    kinds[kinds == 2] = 4                                       # no Buckingham kind: P (5) would not be Lennard-Jones-only
+    q = rng.uniform(-1.2, 1.9, n)
+    probes, pc = synthetic_probes(mat, pos, kinds, q, probes=(6, 5, 7))
+    cset = W.grid_setup_with_dims(mat, (21, 17, 19))
+    pos[0] = cset.shift + cset.size / cset.dims * np.array([3, 4, 5])      # an atom exactly on a grid point
+    probes, pc = synthetic_probes(mat, pos, kinds, q, probes=(6, 5, 7))
+    alpha = 0.26505830360350674
+    nx, ny, nz = cset.npoints
+    dev = torch.device("cuda", 0)
+    plan = MultiGridPlan(cset, probes, pc, alpha)
+    outs = [torch.full((8, nx, ny, nz), float("nan"), dtype=torch.float32, device=dev) for _ in range(4)]
+    plan.build([o.data_ptr() for o in outs[:3]], outs[3].data_ptr(), nx * ny * nz, 0, nx)
+    torch.cuda.synchronize()
+    got = [o.cpu().numpy() for o in outs]
+    plan.close()
+    lam, thr = G.vdw_scaling()
+    for k, pr in enumerate(probes):
+        compare_grids(got[k], oracle.grid_vdw(pr, cset, lam, thr)[0], f"multi/{name}/probe{k}")
+    lam, thr = G.coulomb_scaling()
+    refc = oracle.grid_coulomb(pc, alpha, cset, lam, thr)[0]
+    compare_grids(got[3], refc, f"multi/{name}/coulomb")
+    assert np.isnan(refc).any() or np.isinf(oracle.points_coulomb(pc, alpha, pos[:1])).any()
+    for ng in (1, 3):
+        if ng > hip_lib.ceg_device_count():
+            monkeypatch.setenv("CEG_HIP_OVERSUBSCRIBE", "1")
+        vg, cg = G.build_multi_arrays(probes, pc, alpha, cset, ngpus=ng)
+        for k in range(3):
+            assert np.array_equal(vg[k].view(np.int32), got[k].view(np.int32)), (name, ng, k)
+        assert np.array_equal(cg.view(np.int32), got[3].view(np.int32)), (name, ng)
+    vg, cg = G.build_multi_arrays(probes[:2], None, 0.0, cset)      # VdW grids only, no charges in the plan
+    for k in range(2):
+        compare_grids(vg[k], got[k], f"multi/{name}/vdw-only plan/probe{k}")
+    assert cg is None

@@ -12,7 +12,8 @@ from ceg_hip.workloads import grid_setup_with_dims
 
 def tiny_forcefield(cutoff: float = 12.0, hs_radius: float = 1.5, generic: bool = False) -> ForceField:
     """kinds: 1 LJ-shifted, 2 Buckingham+HardSphere(hs_radius), 3 none, 4 LJ (other params) -- or,
-    with generic=True, a LJ+Buckingham sum that has no fast class in the kernel; probe = 5."""
+    with generic=True, a LJ+Buckingham sum that has no fast class in the kernel; probe = 5 (P).  Probes 6 (Q) and 7 (R) are
+    Lennard-Jones-only against all four kinds (Q: none against C, LJ + CoulombEwaldDirect against D; R: none against B)."""
     lj = InteractionRule(FF.LennardJones, [107.69, 3.15], 0.0, False)
     lj = InteractionRule(FF.LennardJones, [107.69, 3.15], lj(cutoff), False)
     buck = InteractionRuleSum([InteractionRule(FF.HardSphere, [hs_radius, 0.0]), InteractionRule(FF.Buckingham, [5.581e7, 3.985, 9.167e5]),
@@ -21,15 +22,24 @@ def tiny_forcefield(cutoff: float = 12.0, hs_radius: float = 1.5, generic: bool 
     lj2 = InteractionRule(FF.LennardJones, [262.0, 2.396])
     if generic:
         lj2 = InteractionRuleSum([InteractionRule(FF.LennardJones, [40.0, 2.9]), InteractionRule(FF.Buckingham, [3.0e6, 3.2, 2.0e4])])
-    n = 5
+    n = 7
     inter = [[none] * n for _ in range(n)]
     for k, r in enumerate((lj, buck, none, lj2)):
         inter[k][4] = inter[4][k] = r
-    sdict = {"A": 1, "B": 2, "C": 3, "D": 4, "P": 5}
+    # two more probes, Lennard-Jones against every framework kind they meet (what a multi-probe plan takes): Q (6) and R (7)
+    ljq = [InteractionRule(FF.LennardJones, [55.0, 3.4]), InteractionRule(FF.LennardJones, [81.5, 2.9]), none,
+           InteractionRuleSum([InteractionRule(FF.LennardJones, [23.0, 3.05]), InteractionRule(FF.CoulombEwaldDirect, [0.265, 0.3, -0.6], 0.0, False)])]
+    ljq[0] = InteractionRule(FF.LennardJones, [55.0, 3.4], ljq[0](cutoff), False)               # shifted, like kind A with P
+    ljr = [InteractionRule(FF.LennardJones, [140.0, 3.3]), none, InteractionRule(FF.LennardJones, [12.0, 3.9]),
+           InteractionRule(FF.LennardJones, [66.0, 2.75])]
+    for k in range(4):
+        inter[k][5] = inter[5][k] = ljq[k]
+        inter[k][6] = inter[6][k] = ljr[k]
+    sdict = {"A": 1, "B": 2, "C": 3, "D": 4, "P": 5, "Q": 6, "R": 7}
     return ForceField(inter, sdict, list(sdict), cutoff, "tiny")
 
 
-def synthetic_probes(mat, positions, kinds, charges, cutoff: float = 12.0, **ffkw):
+def synthetic_probes(mat, positions, kinds, charges, cutoff: float = 12.0, probes=None, **ffkw):
     """(vdw probe, coulomb probe) over an explicit supercell `mat` -- bypasses find_supercell so
     that cells violating the 2*cutoff rule can be tested too."""
     ff = tiny_forcefield(cutoff, **ffkw)
@@ -40,6 +50,8 @@ def synthetic_probes(mat, positions, kinds, charges, cutoff: float = 12.0, **ffk
     inv = np.linalg.inv(mat)
     pv = ProbeSystem(pos, mat, inv, ff, kinds, np.empty(0), 5)
     pc = ProbeSystem(pos, mat, inv, ff, kinds, q, 0)
+    if probes is not None:         # one VdW ProbeSystem per requested probe index (5 = P, 6 = Q, 7 = R)
+        return [ProbeSystem(pos, mat, inv, ff, kinds, np.empty(0), p) for p in probes], pc
     return pv, pc
 
 
