@@ -962,8 +962,8 @@ static int create_impl(ceg_plan_t** plan, int32_t device,
             }
         }
         if (!rc && p->nprobes > 0) {
-            if (p->has_charge && !p->ew2)
-                rc = fail(CEG_ERR_UNSUPPORTED, "multi-probe plans with charges need the r^2-indexed Ewald tables (alpha * cutoff <= 5)");
+            // (without the r^2-indexed Ewald tables -- alpha * cutoff > 5, or a fit that misses its tolerance -- the Coulomb grid is
+            //  built by its own launch with the erfcx / libm-grade arithmetic and only the VdW grids share a pass: ceg_plan_build_multi)
             hc.nprobes = p->nprobes;
             for (int q = 0; q < p->nprobes && !rc; ++q) {
                 ceg_plan::ProbeTab& t = p->probes[q];
@@ -1174,11 +1174,12 @@ extern "C" int ceg_plan_build_multi(ceg_plan_t* p, double lambda_vdw, double thr
     if (!guard.ok) return fail(CEG_ERR_HIP, "hipSetDevice(%d) failed", p->device);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSuccess;
+    const int ewk = p->ew2 ? 2 : (p->fast_ewald ? 1 : 0);        // real-space Ewald arithmetic available to this plan
     auto single = [&](int mode, int q) {          // one probe (q >= 0) and / or the Coulomb grid: the single-probe kernels
         Output o = base;
         o.vdw = q >= 0 ? d_out_vdw[q] : nullptr;
         o.coulomb = mode != MODE_VDW ? d_out_coulomb : nullptr;
-        return launch_culled(mode, q >= 0 ? p->probes[q].d_pc : p->d_pc, p->g, 1, 2, o, Points{nullptr, 0}, st);
+        return launch_culled(mode, q >= 0 ? p->probes[q].d_pc : p->d_pc, p->g, 1, ewk, o, Points{nullptr, 0}, st);
     };
     auto multi = [&](int mode, const int* idx, int np) {
         Output o = base;
@@ -1191,6 +1192,7 @@ extern "C" int ceg_plan_build_multi(ceg_plan_t* p, double lambda_vdw, double thr
         int fused_np = CEG_MAX_PROBES_FUSED;          // probes that share the Coulomb launch (CEG_HIP_MULTI_FUSED_NP = 0 | 1 | 2: measurement aid)
         if (const char* env = std::getenv("CEG_HIP_MULTI_FUSED_NP")) fused_np = std::max(0, std::min(CEG_MAX_PROBES_FUSED, atoi(env)));
         fused_np = std::min<int>(fused_np, (int)req.size());
+        if (!p->ew2) fused_np = 0;                    // the fused variants are built on the r^2-indexed tables
         if (fused_np >= 2) e = multi(MODE_FUSED, &req[0], 2);
         else if (fused_np == 1) e = single(MODE_FUSED, req[0]);
         else e = single(MODE_COULOMB, -1);

@@ -39,7 +39,10 @@ while done < n_cfg:
     # tabulated Buckingham class of the culled kernel)
     palette = [np.array([1, 2, 3, 4]), np.array([1, 3, 4]), np.array([2, 3])][int(rng.integers(0, 3))]
     stats["palette%d" % len(palette)] = stats.get("palette%d" % len(palette), 0) + 1
-    pv, pc = synthetic_probes(mat, pos, palette[rng.integers(0, len(palette), n)], rng.uniform(-1.5, 1.5, n), cutoff=cutoff, generic=generic, hs_radius=hs)
+    kinds_used = palette[rng.integers(0, len(palette), n)]
+    charges_used = rng.uniform(-1.5, 1.5, n)
+    multi_ok = 2 not in palette                      # probe P (5) is Buckingham against kind 2: not a multi-probe candidate then
+    pv, pc = synthetic_probes(mat, pos, kinds_used, charges_used, cutoff=cutoff, generic=generic, hs_radius=hs)
     ortho, safemin2 = pv.periodic_setup()
     stats["ortho" if ortho else ("stale" if safemin2 < cutoff ** 2 else "plain")] += 1
     stats["generic"] += int(generic)
@@ -63,7 +66,20 @@ while done < n_cfg:
         lam, thr = G.vdw_scaling(); ref, _ = O.grid_vdw(pv, cset, lam, thr)
         compare_grids(G.build_vdw_array(pv, cset), ref, what + "/grid vdw")
         lam, thr = G.coulomb_scaling(); ref, _ = O.grid_coulomb(pc, alpha, cset, lam, thr)
+        refc = ref
         compare_grids(G.build_coulomb_array(pc, alpha, cset), ref, what + "/grid coulomb")
+        if multi_ok and not generic:
+            # round 3: the same framework through a multi-probe pass (2-3 Lennard-Jones probes + the Coulomb grid in one call)
+            nprobe = int(rng.integers(2, 4))
+            order = [int(x) for x in rng.permutation([5, 6, 7])[:nprobe]]
+            probes, _pc = synthetic_probes(mat, pos, kinds_used, charges_used, cutoff=cutoff, probes=order, hs_radius=hs)
+            vg, cg = G.build_multi_arrays(probes, pc if rng.random() < 0.8 else None, alpha, cset)
+            lam, thr = G.vdw_scaling()
+            for k, pr in enumerate(probes):
+                compare_grids(vg[k], O.grid_vdw(pr, cset, lam, thr)[0], what + f"/multi probe {order[k]}")
+            if cg is not None:
+                compare_grids(cg, refc, what + "/multi coulomb")
+            stats["multi"] = stats.get("multi", 0) + 1
     except AssertionError as e:
         fails += 1
         print("FAIL", what, "::", str(e)[:300], flush=True)
