@@ -91,6 +91,7 @@ struct ceg_plan {
     std::shared_ptr<void> images;          // owner of the lattice-image list + bins on the device (an ImageSet, shared between plans: image cache)
     ImageBins ib{};
     bool images_built = false;
+    bool images_from_cache = false;
     PlanConst* d_pc = nullptr;   // device copy of {g, ib, rt, tables}
     double* d_erfcx = nullptr;
     double* d_exp2 = nullptr;
@@ -450,9 +451,10 @@ int build_images(ceg_plan* p)
         p->ib.kind = p->has_rules ? p->d_imgkind : nullptr;
         p->ib.atoms = p->d_atoms;
         p->images_built = true;
+        p->images_from_cache = true;
         return CEG_OK;
     }
-    g_image_misses.fetch_add(1);
+    if (cap > 0) g_image_misses.fetch_add(1);
     struct Img { double x, y, z, q; int32_t kind; int32_t bin; int32_t atom; };
     std::vector<Img> imgs;
     imgs.reserve((size_t)p->natoms * 8);
@@ -890,7 +892,7 @@ static int create_impl(ceg_plan_t** plan, int32_t device,
     }
     stamp("atom / rule tables uploaded");
     if (!rc && p->can_cull) rc = build_images(p);
-    stamp(p->images && p->images.use_count() > 1 && g_image_hits.load() > 0 ? "images (cache / built)" : "images built + uploaded");
+    stamp(p->images_from_cache ? "images: cache hit" : "images built + uploaded");
     if (!rc && p->can_cull) {
         PlanConst hc{};
         hc.g = p->g;
