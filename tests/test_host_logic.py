@@ -397,3 +397,47 @@ def test_interpolate_grid_without_derivatives_host_mirror_vs_oracle(oracle):
             else:
                 with pytest.raises(IndexError):
                     G.interpolate_grid(eg, pts[q])
+
+
+def test_round3_entry_points_validate_and_have_no_cpu_path(tmp_path):
+    """The multi-probe build, the .grid -> device loader and the higher-order switch validate their arguments before touching a
+    device and, with valid arguments on a box without a GPU, fail with CEG_ERR_NO_DEVICE -- never a CPU result."""
+    import ctypes as C
+    from ceg_hip.plan import MultiGridPlan
+    lib = _abi.load_library()
+    w1 = W.fixture_workload("CIT-7", "C_co2", 2.0)
+    w2 = W.fixture_workload("CIT-7", "O_co2", 2.0)
+    # host-side checks of the wrapper: probe count, one framework for all probes
+    with pytest.raises(ValueError):
+        MultiGridPlan(w1.cset, [], w1.probe_coulomb, w1.alpha)
+    other = W.fixture_workload("CHA_1.4_3b4eeb96", "Ar", 2.0)
+    with pytest.raises(ValueError):
+        MultiGridPlan(w1.cset, [w1.probe_vdw, other.probe_vdw], None, 0.0)
+    # C side: nprobes out of range / NULL tables are CEG_ERR_INVALID whatever the machine
+    h = C.c_void_p()
+    dims, size, shift, delta = G._grid_args(w1.cset)
+    pos = np.ascontiguousarray(w1.probe_vdw.positions, dtype=np.float64)
+    kinds = np.ascontiguousarray(w1.probe_vdw.atomkinds, dtype=np.int64)
+    mat, inv = G._matT(w1.probe_vdw.mat), G._matT(w1.probe_vdw.invmat)
+    tabs = [p.forcefield.rule_table(p.probe) for p in (w1.probe_vdw, w2.probe_vdw)]
+    rules_pp = (C.c_void_p * 2)(*[t[0].ctypes.data for t in tabs])
+    offs_pp = (C.c_void_p * 2)(*[t[1].ctypes.data for t in tabs])
+    geo = (_abi.i32ptr(dims), _abi.dptr(size), _abi.dptr(shift), _abi.dptr(delta))
+    args = lambda n, rp, op: (C.byref(h), 0, _abi.dptr(pos), _abi.i64ptr(kinds), None, len(kinds), _abi.dptr(mat), _abi.dptr(inv), 0, 1e9, 144.0,
+                              n, rp, op, w1.forcefield.nkinds, 0.0, *geo)
+    assert lib.ceg_plan_create_multi(*args(0, rules_pp, offs_pp)) == -1
+    assert lib.ceg_plan_create_multi(*args(5, rules_pp, offs_pp)) == -1 and b"nprobes" in lib.ceg_last_error()
+    assert lib.ceg_plan_create_multi(*args(2, None, offs_pp)) == -1
+    assert lib.ceg_plan_build_multi(None, 1.0, 1.0, 1.0, 1.0, 0, 1, None, None, 1, 0, None) == -1
+    assert lib.ceg_plan_num_probes(None) == 0
+    assert lib.ceg_interp_set_higherorder(None, 0) == -1
+    assert lib.ceg_interp_create_from_file(C.byref(h), 0, None, 0, 1.0, None, None, None) == -1
+    assert lib.ceg_interp_create_from_file(C.byref(h), 0, b"/nonexistent.grid", 0, 1.0, _abi.dptr(mat), None, None) == -1      # mat without invmat
+    if lib.ceg_device_count() > 0:
+        return
+    assert lib.ceg_plan_create_multi(*args(2, rules_pp, offs_pp)) == -2 and b"no HIP device" in lib.ceg_last_error()
+    with pytest.raises(_abi.CegError) as ei:
+        G.build_multi_arrays([w1.probe_vdw, w2.probe_vdw], w1.probe_coulomb, w1.alpha, w1.cset)
+    assert ei.value.code == -2
+    (tmp_path / "x.grid").write_bytes(b"\0" * 400)
+    assert lib.ceg_interp_create_from_file(C.byref(h), 0, str(tmp_path / "x.grid").encode(), 0, 1.0, None, None, None) == -2
