@@ -833,6 +833,9 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK, NP), culled_waves(M
                 meta = (kd & META_KINDMASK) | (simple ? META_SIMPLE : 0) | (hasvdw ? META_HASVDW : 0) |
                        (vclass == 2 ? META_BUCK : 0);
             }
+#ifdef CEG_SKIP_TESTS           // measurement aid (with CEG_STAGING_ONLY): row scan + image loads only, nothing kept, no compaction writes
+            keep = keep && (P.x == 12345.678);
+#endif
             // Kept candidates are compacted into five consecutive groups, so that the hot loops below run without a
             // per-candidate class test (no record flag to read, no scalar branch around the VdW part):
             //   [0, nvi)        image provably the wrapped one for the whole tile, kind has a VdW rule, interior (see above)
@@ -1142,6 +1145,10 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK, NP), culled_waves(M
         if (valid) write_results<MODE>(g, out, true, pidx, i, j, k, av, ac, smallest_d2);
         return;
     }
+#ifdef CEG_SKIP_OUTPUT          // measurement aid: no _set_gridpoint! arithmetic, no transpose, no stores (one dummy store keeps the sums alive)
+    if (av.v + ac.v == 12345.678 && lane == 0) out.vdw[0] = 1.0f;
+    return;
+#endif
     // ---- grid mode: the NW tiles of a workgroup are consecutive along z (the fastest array
     // axis), so the workgroup transposes its results through LDS and writes rows of 4*NW
     // contiguous floats (64 B at NW = 4) per (channel, i, j) instead of 16-B fragments.
