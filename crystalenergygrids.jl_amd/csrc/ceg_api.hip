@@ -1954,8 +1954,13 @@ extern "C" int ceg_interp_create_from_file(ceg_interp_t** handle, int32_t device
     const int64_t payload = nfl * (int64_t)sizeof(float);
     const off_t fsize = lseek(fd, 0, SEEK_END);
     if (fsize < (off_t)(hbytes + payload)) return fail(CEG_ERR_INVALID, "%s: file shorter than its header says", path);
+    // header + payload [+ the 72-byte cell matrix] and nothing else: a VdW file opened as a Coulomb one (or the reverse) is off by the
+    // 8 bytes of the Ewald precision and is refused here instead of being read 8 bytes out of step
+    if (fsize != (off_t)(hbytes + payload) && fsize != (off_t)(hbytes + payload + 72))
+        return fail(CEG_ERR_INVALID, "%s: %lld bytes do not make a %s grid of %d x %d x %d points (wrong iscoulomb?)", path, (long long)fsize,
+                    iscoulomb ? "Coulomb" : "VdW", H.dims[0] + 1, H.dims[1] + 1, H.dims[2] + 1);
     H.has_mat = 0;
-    if (fsize >= (off_t)(hbytes + payload + 72) && pread(fd, H.mat, 72, (off_t)(hbytes + payload)) == 72) H.has_mat = 1;   // :154 / :182
+    if (fsize == (off_t)(hbytes + payload + 72) && pread(fd, H.mat, 72, (off_t)(hbytes + payload)) == 72) H.has_mat = 1;   // :154 / :182
     double M[9], I[9];
     if (mat) { memcpy(M, mat, sizeof M); memcpy(I, invmat, sizeof I); }
     else {

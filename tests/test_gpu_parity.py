@@ -1293,6 +1293,10 @@ def test_cached_grid_file_straight_to_the_device(hip_lib, oracle, tmp_path, forc
         with pytest.raises(_abi.CegError) as ei:
             GridInterpolator.from_file(tmp_path / bad, False)
         assert ei.value.code == -1
+    for wrong, isc in (("v.grid", True), ("c.grid", False)):           # a VdW file opened as a Coulomb grid and the reverse
+        with pytest.raises(_abi.CegError) as ei:
+            GridInterpolator.from_file(tmp_path / wrong, isc)
+        assert ei.value.code == -1 and "iscoulomb" in str(ei.value)
     (tmp_path / "nomat.grid").write_bytes(data[:-72])                  # a RASPA-made file has no trailing matrix (grids.jl:80-90)
     with pytest.raises(_abi.CegError):
         GridInterpolator.from_file(tmp_path / "nomat.grid", False)
