@@ -311,6 +311,40 @@ function interp_handle(g::CEG.EnergyGrid; device=0)
     h[]
 end
 
+# struct ceg_grid_header (include/ceg_hip.h): what parse_grid (src/grids.jl:61-94) reads besides the payload
+struct CegGridHeader
+    spacing::Float64
+    dims::NTuple{3,Int32}
+    has_mat::Int32
+    size::NTuple{3,Float64}
+    shift::NTuple{3,Float64}
+    delta::NTuple{3,Float64}
+    unitcell::NTuple{3,Float64}
+    num_unitcell::NTuple{3,Int32}
+    _pad::Int32
+    ewald_precision::Float64
+    mat::NTuple{9,Float64}
+end
+
+"""
+    interp_handle_from_file(path, iscoulomb; mat=nothing, device=0) -> (handle, header)
+
+The GPU interpolation handle of a CACHED grid straight from its file ("Retrieved ... grid", src/raspa.jl:426-438): what
+`parse_grid(path, iscoulomb, mat)` + `interp_handle` do, without the host array -- the payload is streamed to the device and multiplied
+by `GRID_TO_KELVIN` there (src/grids.jl:78).  `mat`: the unit-cell matrix as for `parse_grid` (Å, unitless); `nothing` uses the one
+stored at the end of the file.
+"""
+function interp_handle_from_file(path::AbstractString, iscoulomb::Bool; mat=nothing, device=0)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    hdr = Ref{CegGridHeader}()
+    m = mat isa Nothing ? Float64[] : Vector{Float64}(vec(Matrix{Float64}(mat)))
+    im = mat isa Nothing ? Float64[] : Vector{Float64}(vec(inv(Matrix{Float64}(mat))))
+    GC.@preserve m im _check(ccall((:ceg_interp_create_from_file, LIB[]), Cint,
+        (Ref{Ptr{Cvoid}}, Int32, Cstring, Int32, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+        h, device, path, iscoulomb, GRID_TO_KELVIN, (mat isa Nothing ? C_NULL : pointer(m)), (mat isa Nothing ? C_NULL : pointer(im)), hdr))
+    h[], hdr[]
+end
+
 "interpolate_grid(g, p) for every p of `positions` -> Vector{Float64} (K)"
 function interp_points(h::Ptr{Cvoid}, positions)
     pts = _pts(positions); out = Vector{Float64}(undef, length(positions))
