@@ -318,6 +318,33 @@ def main():
             gather_mode = cands[best][1]
     elif args.gather == "auto":
         gather_mode = "staged"
+    # Last line of defence for the first run on real links: ONE guarded step of the pipelined exchange before anything is timed.  If
+    # it raises on any rank, every rank drops to the simplest path there is -- contiguous x-slabs, one all-gather per channel after the
+    # kernels (allgather_grid) -- and the line says so in exchange.mode.  (A rank that hangs cannot be rescued from inside.)
+    fallback_reason = None
+    if pipe is not None and pipe.exchange and world > 1:
+        ok = True
+        try:
+            if os.environ.get("CEG_BENCH_FAIL_PIPELINE") == "1":            # test hook
+                raise RuntimeError("injected failure of the pipelined exchange (CEG_BENCH_FAIL_PIPELINE)")
+            step()
+            torch.cuda.synchronize()
+        except Exception as exc:              # noqa: BLE001
+            ok = False
+            fallback_reason = repr(exc)
+            print(f"[bench] pipelined exchange failed on rank {rank}: {exc!r}", file=sys.stderr)
+        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if not bool(flag[0] > 0.5):
+            fallback_reason = fallback_reason or "another rank failed"
+            print("[bench] falling back to contiguous slabs + one all-gather per channel", file=sys.stderr)
+            pipe, cyc, joint = None, None, None
+            b, e = slab_range(nx, world, rank)
+            n_local = e - b
+            loc_v = torch.empty((8, n_local, ny, nz), dtype=torch.float32, device=dev) if need_v else None
+            loc_c = torch.empty((8, n_local, ny, nz), dtype=torch.float32, device=dev) if need_c else None
+            locs = [t for t in (loc_v, loc_c) if t is not None]
+            gather_mode = "slab (fallback)"
     # (the first launches after the set-up phase run below the steady clock: 16-18, 14.1, 13.6 then 13.4 ms on an idle card,
     # scripts/clock_ramp.py; three untimed launches belong to the set-up, whatever --warmup says)
     for _ in range(PREWARM_STEPS):
@@ -486,7 +513,8 @@ def main():
         if multi:
             # gather time reported separately.  compute_ms = span of this rank's kernels
             # (max over ranks); what is left of the step is the part of the exchange that was not hidden
-            out["exchange"] = {"compute_ms": kern_ms, "exposed_ms": max(0.0, ms - kern_ms), "mode": gather_mode if cyc is not None else "slab", "autotune_ms": autotune,
+            out["exchange"] = {"compute_ms": kern_ms, "exposed_ms": max(0.0, ms - kern_ms),
+                               "mode": gather_mode if (cyc is not None or fallback_reason) else "slab", "autotune_ms": autotune, "fallback_reason": fallback_reason,
                                "bytes_gathered_per_rank": 32.0 * npts * ngrids * (world - 1) / world, "backend": "nccl (RCCL over xGMI)" if args.backend == "nccl" else "gloo (rehearsal)"}
         if world == 1 and args.cpu_rows != 0:
             out["cpu_baseline"] = cpu_baseline(w, args.mode, args.cpu_rows)

@@ -996,15 +996,19 @@ def test_bench_two_and_three_ranks_on_one_gpu(hip_lib):
     import subprocess
     import sys
     root = Path(__file__).resolve().parent.parent
-    for nranks, dims, mode in ((2, 63, "staged"), (3, 63, "slab")):
+    for nranks, dims, mode in ((2, 63, "staged"), (3, 63, "slab"), (2, 63, "fallback")):
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), str(root / "bench.py"), "--gpus", str(nranks), "--backend", "gloo", "--dims", str(dims),
                "--steps", "2", "--warmup", "1", "--cpu-rows", "0"] + (["--gather", "auto"] if mode == "staged" else [])
-        # (--gather auto is opt-in since round 3; one of its candidates is made to raise: it must be skipped, not fatal)
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env={**os.environ, "CEG_BENCH_FAIL_CANDIDATE": "4 chunks, inplace"})
+        # (--gather auto is opt-in since round 3; one of its candidates is made to raise: it must be skipped, not fatal.  "fallback": the
+        #  pipelined exchange itself raises in its guarded first step -> contiguous slabs + one all-gather per channel, still a valid line)
+        env = {**os.environ, "CEG_BENCH_FAIL_CANDIDATE": "4 chunks, inplace"}
+        if mode == "fallback":
+            env["CEG_BENCH_FAIL_PIPELINE"] = "1"
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stderr[-3000:]
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         assert len(lines) == 1, r.stdout[-2000:]
@@ -1016,9 +1020,12 @@ def test_bench_two_and_three_ranks_on_one_gpu(hip_lib):
             done = {k: v for k, v in tried.items() if v is not None}
             assert d["exchange"]["mode"] in ("staged", "inplace") and len(done) >= 3 and all(v > 0 for v in done.values())
             assert {k.split(", ")[1] for k in tried} == {"staged", "inplace"} and "8 chunks, staged" in done
+        elif mode == "fallback":
+            assert d["exchange"]["mode"] == "slab (fallback)" and "injected" in d["exchange"]["fallback_reason"]
+            assert "x-slab sharding" in d["config"]["parallelism"]
         else:
             assert d["exchange"]["mode"] == mode
-        assert d["selfcheck"]["max_rel_err"] <= 1e-6 and d["selfcheck"]["points"] > 0
+        assert d["selfcheck"]["max_rel_err"] <= 1e-6 and d["selfcheck"]["points"] > 0 and d["selfcheck"]["ok"]
         assert d["exchange"]["bytes_gathered_per_rank"] > 0
 
 
