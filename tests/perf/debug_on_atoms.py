@@ -2,7 +2,7 @@
 the oracle differ, and how far is each atom from those points (in units that show a cutoff decision)?"""
 import os, sys
 here = os.path.dirname(os.path.abspath(__file__))
-sys.path[:0] = [os.path.join(here, '..', '..', 'crystalenergygrids.jl_amd'), os.path.join(here, '..', '..'), os.path.join(here, '..', '..', 'tests')]
+sys.path[:0] = [os.path.join(here, '..', '..', 'crystalenergygrids.jl_amd'), os.path.join(here, '..', '..'), os.path.join(here, '..')]
 import numpy as np
 from ceg_hip import grids as G, workloads as W
 from oracle import oracle as O
