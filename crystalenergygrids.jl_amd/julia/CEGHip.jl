@@ -269,7 +269,7 @@ function prebuild_grids!(framework, pff, syst_mol; gridstep=0.15u"Å", supercell
     needcoulomb = any(!iszero(syst_mol[i,:atomic_charge])::Bool for i in 1:length(syst_mol))
     kinds = ProbeSystem(syst_framework, forcefield).atomkinds
     todo = [i for (i, atom) in enumerate(atoms) if CEG.needsvdwgrid(forcefield, atom) && (new || !isfile(vdws[i])) &&
-            lj_only(forcefield, forcefield.sdict[CEG.get_atom_name(atom)], kinds)]
+            lj_only(forcefield, forcefield.sdict[Symbol(CEG.get_atom_name(atom))], kinds)]   # sdict keys as in src/probes.jl:23,59
     want_c = needcoulomb && (new || !isfile(coulomb_grid_path))
     for lo in 1:4:max(length(todo), 1)
         part = todo[lo:min(lo+3, length(todo))]
