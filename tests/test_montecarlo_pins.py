@@ -42,10 +42,12 @@ def oracle_grids(oracle, forcefield, monkeypatch):
         kind, what = g.key
         pk = (id(g.fw), kind if kind == "coulomb" else what)
         if pk not in probes:
-            probes[pk] = ProbeSystem.build(g.fw, forcefield) if kind == "coulomb" else ProbeSystem.build(g.fw, forcefield, what)
+            # (the framework object is kept in the entry: id() of a collected object can be handed out again, and "Mini" would then be
+            #  served the ProbeSystem of "MiniRef" -- seen once as a one-off failure of test_one_atom_frameworks_in_supercells)
+            probes[pk] = (g.fw, ProbeSystem.build(g.fw, forcefield) if kind == "coulomb" else ProbeSystem.build(g.fw, forcefield, what))
         if kind == "vdw":
-            return interpolate_with_oracle(oracle, g.csetup, probes[pk], point)
-        return interpolate_with_oracle(oracle, g.csetup, probes[pk], point, what)
+            return interpolate_with_oracle(oracle, g.csetup, probes[pk][1], point)
+        return interpolate_with_oracle(oracle, g.csetup, probes[pk][1], point, what)
 
     monkeypatch.setattr(M, "retrieve_or_create_grid", fake_retrieve)
     monkeypatch.setattr(M, "interpolate_grid", fake_interpolate)
