@@ -74,6 +74,8 @@ PROTOTYPES = {
         C.c_double, C.c_double, c_float_p, C.c_int32,
         C.c_char_p, C.c_char_p, C.c_int64, C.c_char_p, C.c_int64]),
     "ceg_release_cached_buffers": (C.c_int, []),
+    "ceg_host_grid_alloc": (c_float_p, [c_int32_p]),
+    "ceg_host_grid_free": (C.c_int, [c_float_p]),
     "ceg_plan_create": (C.c_int, [
         C.POINTER(C.c_void_p), C.c_int32,
         c_double_p, c_int64_p, c_double_p, C.c_int64,

@@ -100,9 +100,36 @@ def _file_frame(cset: GridCoordinatesSetup, num_unitcell, ewald_precision: Optio
     return buf.getvalue(), np.asarray(cset.cell.mat, dtype="<f8").T.tobytes()
 
 
-def build_vdw_array(probe: ProbeSystem, cset: GridCoordinatesSetup, ngpus: int = 1, file=None, num_unitcell=None) -> np.ndarray:
+def alloc_host_grid(cset: GridCoordinatesSetup) -> np.ndarray:
+    """A float32[8, nx, ny, nz] result array in page-locked memory of the library (``ceg_host_grid_alloc``): passed as ``out=`` to
+    ``build_vdw_array`` / ``build_coulomb_array`` / ``build_multi_arrays`` it lets every chunk be copied D2H straight to its place (no
+    pinned ring, no second pass by host threads).  The memory goes back to the library's cache when the array is collected."""
+    import weakref
+    lib = _abi.load_library()
+    dims = np.ascontiguousarray(cset.dims, dtype=np.int32)
+    ptr = lib.ceg_host_grid_alloc(_abi.i32ptr(dims))
+    if not ptr:
+        raise _abi.CegError(-3, (lib.ceg_last_error() or b"").decode())
+    nx, ny, nz = cset.npoints
+    arr = np.ctypeslib.as_array(ptr, shape=(8, nx, ny, nz))
+    addr = C.cast(ptr, C.c_void_p).value
+    weakref.finalize(arr, lambda a=addr: lib.ceg_host_grid_free(C.cast(a, _abi.c_float_p)))
+    return arr
+
+
+def _result_array(cset: GridCoordinatesSetup, out) -> np.ndarray:
+    nx, ny, nz = cset.npoints
+    if out is None:
+        return np.empty((8, nx, ny, nz), dtype=np.float32)
+    if out.shape != (8, nx, ny, nz) or out.dtype != np.float32 or not out.flags.c_contiguous:
+        raise ValueError("out must be a C-contiguous float32[8, nx, ny, nz] array")
+    return out
+
+
+def build_vdw_array(probe: ProbeSystem, cset: GridCoordinatesSetup, ngpus: int = 1, file=None, num_unitcell=None, out=None) -> np.ndarray:
     """The loop nest of grids.jl:144-150 on the GPU (``ceg_grid_vdw``).  With ``file`` the .grid file is
-    written by the library while the grid is being built (``ceg_grid_vdw_file``)."""
+    written by the library while the grid is being built (``ceg_grid_vdw_file``).  ``out``: result array to fill
+    (``alloc_host_grid`` gives a page-locked one: the call is then bounded by the PCIe transfer alone)."""
     lib = _abi.load_library()
     ff = probe.forcefield
     ff.check_vdw_grid(probe.probe, np.unique(probe.atomkinds))
@@ -110,8 +137,7 @@ def build_vdw_array(probe: ProbeSystem, cset: GridCoordinatesSetup, ngpus: int =
     ortho, safemin2 = probe.periodic_setup()
     lam, thr = vdw_scaling()
     dims, size, shift, delta = _grid_args(cset)
-    nx, ny, nz = cset.npoints
-    grid = np.empty((8, nx, ny, nz), dtype=np.float32)
+    grid = _result_array(cset, out)
     pos = np.ascontiguousarray(probe.positions, dtype=np.float64)
     kinds = np.ascontiguousarray(probe.atomkinds, dtype=np.int64)
     mat, invmat = _matT(probe.mat), _matT(probe.invmat)
@@ -130,14 +156,13 @@ def build_vdw_array(probe: ProbeSystem, cset: GridCoordinatesSetup, ngpus: int =
 
 
 def build_coulomb_array(probe: ProbeSystem, alpha: float, cset: GridCoordinatesSetup, ngpus: int = 1, file=None,
-                        num_unitcell=None, ewald_precision: float = 1e-6) -> np.ndarray:
+                        num_unitcell=None, ewald_precision: float = 1e-6, out=None) -> np.ndarray:
     """The loop nest of grids.jl:171-177 on the GPU (``ceg_grid_coulomb``; with ``file``: ``ceg_grid_coulomb_file``)."""
     lib = _abi.load_library()
     ortho, safemin2 = probe.periodic_setup()
     lam, thr = coulomb_scaling()
     dims, size, shift, delta = _grid_args(cset)
-    nx, ny, nz = cset.npoints
-    grid = np.empty((8, nx, ny, nz), dtype=np.float32)
+    grid = _result_array(cset, out)
     pos = np.ascontiguousarray(probe.positions, dtype=np.float64)
     q = np.ascontiguousarray(probe.charges, dtype=np.float64)
     mat, invmat = _matT(probe.mat), _matT(probe.invmat)
@@ -227,7 +252,8 @@ def create_grid_coulomb(file, framework, forcefield: ForceField, spacing: float,
                                ewald_precision=ewald.precision)
 
 
-def build_multi_arrays(probes, coulomb_probe: Optional[ProbeSystem], alpha: float, cset: GridCoordinatesSetup, ngpus: int = 1):
+def build_multi_arrays(probes, coulomb_probe: Optional[ProbeSystem], alpha: float, cset: GridCoordinatesSetup, ngpus: int = 1,
+                       pinned: bool = False):
     """All the grids of one setup from one pass over one lattice-image list (``ceg_grids_multi``): the VdW grid of every probe
     in ``probes`` (ProbeSystems of the same framework, Lennard-Jones-only: 1..4 of them) and, with ``coulomb_probe``, the
     Coulomb grid.  -> (list of float32[8, nx, ny, nz], float32[8, nx, ny, nz] or None)."""
@@ -246,8 +272,9 @@ def build_multi_arrays(probes, coulomb_probe: Optional[ProbeSystem], alpha: floa
     lc, tc = coulomb_scaling()
     dims, size, shift, delta = _grid_args(cset)
     nx, ny, nz = cset.npoints
-    vgrids = [np.empty((8, nx, ny, nz), dtype=np.float32) for _ in range(K)]
-    cgrid = np.empty((8, nx, ny, nz), dtype=np.float32) if coulomb_probe is not None else None
+    new = (lambda: alloc_host_grid(cset)) if pinned else (lambda: np.empty((8, nx, ny, nz), dtype=np.float32))
+    vgrids = [new() for _ in range(K)]
+    cgrid = new() if coulomb_probe is not None else None
     pos = np.ascontiguousarray(ref.positions, dtype=np.float64)
     kinds = np.ascontiguousarray(ref.atomkinds, dtype=np.int64)
     q = np.ascontiguousarray(coulomb_probe.charges, dtype=np.float64) if coulomb_probe is not None else None

@@ -1343,6 +1343,19 @@ void* pinned_acquire(size_t bytes)
     return ptr;
 }
 
+// true when [ptr, ptr + bytes) lies inside a page-locked buffer this library handed out (ceg_host_grid_alloc): the one-shot
+// pipelines then copy D2H straight to where the data belongs instead of through the ring + host threads
+bool pinned_owns(const void* ptr, size_t bytes)
+{
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    const char* q = static_cast<const char*>(ptr);
+    for (const auto& p : g_pinned) {
+        const char* base = static_cast<const char*>(p.ptr);
+        if (p.busy && q >= base && q + bytes <= base + p.bytes) return true;
+    }
+    return false;
+}
+
 void pinned_release(void* ptr)
 {
     std::lock_guard<std::mutex> lock(g_pinned_mutex);
@@ -1426,6 +1439,9 @@ int device_pipeline(int mode, int d, int b, int e, int nx, int64_t plane, const 
     const int nchunks = (e - b + cx - 1) / cx;
     const int R = std::min(3, nchunks);
     const size_t slot_floats = (size_t)8 * cx * plane;
+    // The caller's array is page-locked memory of this library (ceg_host_grid_alloc) and no file is written on the way: every chunk
+    // is copied D2H straight to its place -- no ring, no host threads, no second pass over the 537 MB.
+    const bool direct = grid != nullptr && fd < 0 && pinned_owns(grid, sizeof(float) * 8 * (size_t)npts);
     float* d_out = nullptr;
     float* h_ring = nullptr;
     hipStream_t s_comp = nullptr, s_copy = nullptr;
@@ -1438,7 +1454,7 @@ int device_pipeline(int mode, int d, int b, int e, int nx, int64_t plane, const 
     for (int j = 0; j < nchunks && ok; ++j)
         ok = hipEventCreateWithFlags(&ev_comp[j], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&ev_copy[j], hipEventDisableTiming) == hipSuccess;
-    if (ok) {
+    if (ok && !direct) {
         h_ring = static_cast<float*>(pinned_acquire(sizeof(float) * slot_floats * R));
         ok = h_ring != nullptr;
     }
@@ -1454,7 +1470,20 @@ int device_pipeline(int mode, int d, int b, int e, int nx, int64_t plane, const 
     }
     std::atomic<int> enqueued{0};
     stamp("kernels enqueued");
-    if (!rc) {
+    if (!rc && direct) {
+        for (int j = 0; j < nchunks && !rc; ++j) {
+            const int cb = b + j * cx, ce = std::min(e, cb + cx);
+            const size_t cpts = (size_t)(ce - cb) * plane;
+            if (hipStreamWaitEvent(s_copy, ev_comp[j], 0) != hipSuccess) rc = bad(CEG_ERR_HIP, "hipStreamWaitEvent failed");
+            // the 8 channel segments of the chunk as ONE strided copy (rows of cpts floats, pitches = channel strides)
+            if (!rc && hipMemcpy2DAsync(grid + (size_t)cb * plane, sizeof(float) * (size_t)npts, d_out + (size_t)(cb - b) * plane,
+                                        sizeof(float) * (size_t)slab_pts, sizeof(float) * cpts, 8, hipMemcpyDeviceToHost, s_copy) != hipSuccess)
+                rc = bad(CEG_ERR_HIP, "hipMemcpy2DAsync D2H failed");
+        }
+        stamp("copies enqueued (direct)");
+        if (hipStreamSynchronize(s_copy) != hipSuccess && !rc) rc = bad(CEG_ERR_HIP, "kernel execution or D2H copy failed");
+        stamp("grid in the caller's page-locked array");
+    } else if (!rc) {
         drain = std::thread([&]() {
             (void)hipSetDevice(d);
             for (int j = 0; j < nchunks; ++j) {
@@ -1633,6 +1662,8 @@ int multi_device_pipeline(int d, int b, int e, int nx, int64_t plane, const doub
     const int R = std::min(3, nchunks);
     const size_t grid_slot = (size_t)8 * cx * plane;           // floats of one grid in a ring slot
     const size_t slot_floats = grid_slot * NG;
+    bool direct = true;                                         // every output is page-locked memory of this library: copy straight into it
+    for (int gidx = 0; gidx < NG; ++gidx) direct = direct && pinned_owns(host[gidx], sizeof(float) * 8 * (size_t)npts);
     float* d_all = nullptr;                                     // NG slabs of 8 * slab_pts floats
     float* h_ring = nullptr;
     hipStream_t s_comp = nullptr, s_copy = nullptr;
@@ -1645,7 +1676,7 @@ int multi_device_pipeline(int d, int b, int e, int nx, int64_t plane, const doub
     for (int j = 0; j < nchunks && ok; ++j)
         ok = hipEventCreateWithFlags(&ev_comp[j], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&ev_copy[j], hipEventDisableTiming) == hipSuccess;
-    if (ok) {
+    if (ok && !direct) {
         h_ring = static_cast<float*>(pinned_acquire(sizeof(float) * slot_floats * R));
         ok = h_ring != nullptr;
     }
@@ -1665,7 +1696,20 @@ int multi_device_pipeline(int d, int b, int e, int nx, int64_t plane, const doub
         if (hipEventRecord(ev_comp[j], s_comp) != hipSuccess) rc = bad(CEG_ERR_HIP, "hipEventRecord failed");
     }
     stamp("kernels enqueued");
-    if (!rc) {
+    if (!rc && direct) {
+        for (int j = 0; j < nchunks && !rc; ++j) {
+            const int cb = b + j * cx, ce = std::min(e, cb + cx);
+            const size_t cpts = (size_t)(ce - cb) * plane;
+            if (hipStreamWaitEvent(s_copy, ev_comp[j], 0) != hipSuccess) rc = bad(CEG_ERR_HIP, "hipStreamWaitEvent failed");
+            for (int gidx = 0; gidx < NG && !rc; ++gidx)          // per grid ONE strided copy: 8 rows of cpts floats, pitches = channel strides
+                if (hipMemcpy2DAsync(host[gidx] + (size_t)cb * plane, sizeof(float) * (size_t)npts,
+                                     d_all + (size_t)gidx * 8 * slab_pts + (size_t)(cb - b) * plane, sizeof(float) * (size_t)slab_pts,
+                                     sizeof(float) * cpts, 8, hipMemcpyDeviceToHost, s_copy) != hipSuccess)
+                    rc = bad(CEG_ERR_HIP, "hipMemcpy2DAsync D2H failed");
+        }
+        if (hipStreamSynchronize(s_copy) != hipSuccess && !rc) rc = bad(CEG_ERR_HIP, "kernel execution or D2H copy failed");
+        stamp("grids in the caller's page-locked arrays");
+    } else if (!rc) {
         drain = std::thread([&]() {
             (void)hipSetDevice(d);
             for (int j = 0; j < nchunks; ++j) {
@@ -1912,6 +1956,29 @@ extern "C" int ceg_grids_multi(const double* pos, const int64_t* atomkind, const
     if (prev >= 0) (void)hipSetDevice(prev);
     for (int d = 0; d < ngpus; ++d)
         if (rcs[d]) return fail(rcs[d], "%s", errs[d].c_str());
+    return CEG_OK;
+}
+
+// ------------------------------------------------------------------ page-locked result arrays
+// What the one-shot entry points hand back is 537 MB (256^3) per grid; into an ordinary host array that is D2H into a pinned ring
+// plus a second pass by host threads (first touch of fresh pages).  A caller that lets the LIBRARY allocate the result gets
+// page-locked memory (kept in the per-process cache, so the page-locking is paid once) and the pipelines copy every chunk straight
+// to its place: the call is then bounded by the D2H alone.
+extern "C" float* ceg_host_grid_alloc(const int32_t dims[3])
+{
+    if (!dims || dims[0] < 1 || dims[1] < 1 || dims[2] < 1) { (void)fail(CEG_ERR_INVALID, "bad dims"); return nullptr; }
+    if (ceg_device_count() <= 0) { (void)fail(CEG_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)"); return nullptr; }
+    const size_t bytes = sizeof(float) * 8 * (size_t)(dims[0] + 1) * (size_t)(dims[1] + 1) * (size_t)(dims[2] + 1);
+    void* p = pinned_acquire(bytes);
+    if (!p) (void)fail(CEG_ERR_HIP, "page-locked allocation of %zu bytes failed", bytes);
+    return static_cast<float*>(p);
+}
+
+extern "C" int ceg_host_grid_free(float* grid)
+{
+    if (!grid) return CEG_OK;
+    if (!pinned_owns(grid, 1)) return fail(CEG_ERR_INVALID, "not an array of ceg_host_grid_alloc");
+    pinned_release(grid);          // back to the cache; ceg_release_cached_buffers unpins it
     return CEG_OK;
 }
 

@@ -132,11 +132,27 @@ function fill_grid_coulomb!(grid::Array{Cfloat,4}, probe::ProbeSystem, ewald::Ew
     grid
 end
 
+# Result arrays.  ENV["CEG_HIP_PINNED_RESULT"] = "1": the grid array is page-locked memory of the library (ceg_host_grid_alloc) wrapped as
+# an Array -- the build then copies every chunk D2H straight to its place (256^3 VdW grid: 10.5 instead of 13.6 ms) -- and goes back to the
+# library's cache when the Array is finalized.  Off by default: the memory stays page-locked until Julia's GC collects the Array.
+pinned_results() = get(ENV, "CEG_HIP_PINNED_RESULT", "0") == "1"
+
+function result_array(cset::GridCoordinatesSetup)
+    dims = (cset.dims[3]+1, cset.dims[2]+1, cset.dims[1]+1, 8)
+    pinned_results() || return Array{Cfloat,4}(undef, dims...)
+    d = Int32[cset.dims...]
+    ptr = GC.@preserve d ccall((:ceg_host_grid_alloc, LIB[]), Ptr{Cfloat}, (Ptr{Int32},), d)
+    ptr == C_NULL && error("libceg_hip: " * unsafe_string(ccall((:ceg_last_error, LIB[]), Cstring, ())))
+    grid = unsafe_wrap(Array, ptr, dims; own=false)
+    finalizer(g -> ccall((:ceg_host_grid_free, LIB[]), Cint, (Ptr{Cfloat},), pointer(g)), grid)
+    grid
+end
+
 # The two methods below are the reference's (src/grids.jl:137-185) with the `@threads` loop nest
 # replaced by one call; every other line is unchanged.
 function create_grid_vdw(file, framework::AbstractSystem{3}, forcefield::ForceField, spacing::TÅ, atom::Symbol)
     cset, num_unitcell = CEG._setup_grid_common(framework, spacing, forcefield.cutoff)
-    grid = Array{Cfloat,4}(undef, cset.dims[3]+1, cset.dims[2]+1, cset.dims[1]+1, 8)
+    grid = result_array(cset)            # reference: Array{Cfloat,4}(undef, cset.dims[3]+1, cset.dims[2]+1, cset.dims[1]+1, 8)
     probe_vdw = ProbeSystem(framework, forcefield, atom)
     λ⁻¹ = GRID_TO_KELVIN
     λ = inv(λ⁻¹)
@@ -152,7 +168,7 @@ end
 function create_grid_coulomb(file, framework::AbstractSystem{3}, forcefield::ForceField, spacing::TÅ, _ewald=nothing)
     cset, num_unitcell = CEG._setup_grid_common(framework, spacing, 12.0u"Å")
     ewald = _ewald isa EwaldFramework ? _ewald : CEG.initialize_ewald(framework, num_unitcell)
-    grid = Array{Cfloat,4}(undef, cset.dims[3]+1, cset.dims[2]+1, cset.dims[1]+1, 8)
+    grid = result_array(cset)
     probe_coulomb = ProbeSystem(framework, forcefield)
     λ = ustrip(u"K*Å/e_au^2", COULOMBIC_CONVERSION_FACTOR)/GRID_TO_KELVIN
     λ⁻¹e7 = inv(λ)*1e7
@@ -225,7 +241,7 @@ end
 """
 function create_grids_multi(vdw_files, coulomb_file, framework::AbstractSystem{3}, forcefield::ForceField, spacing::TÅ, atoms::Vector{Symbol}, _ewald=nothing)
     cset, num_unitcell = CEG._setup_grid_common(framework, spacing, forcefield.cutoff)
-    newgrid() = Array{Cfloat,4}(undef, cset.dims[3]+1, cset.dims[2]+1, cset.dims[1]+1, 8)
+    newgrid() = result_array(cset)
     probes = [ProbeSystem(framework, forcefield, atom) for atom in atoms]
     vgrids = [newgrid() for _ in atoms]
     if coulomb_file === nothing

@@ -1397,3 +1397,43 @@ def test_multi_probe_cells_and_min_image_branches(hip_lib, oracle, name, lengths
     for k in range(2):
         compare_grids(vg[k], got[k], f"multi/{name}/vdw-only plan/probe{k}")
     assert cg is None
+
+
+def test_page_locked_result_arrays(hip_lib, monkeypatch):
+    """ceg_host_grid_alloc: a result array in page-locked memory of the library makes the one-shot pipelines copy every chunk D2H straight
+    to its place (no ring, no host threads).  Bit-identical to the ordinary route for ceg_grid_vdw / ceg_grid_coulomb / ceg_grids_multi,
+    one and three (oversubscribed) slabs, several chunks; the memory returns to the cache and is reused; foreign pointers are refused."""
+    import ctypes as C
+    import gc
+    w = W.fixture_workload("CHA_1.4_3b4eeb96", "C_co2", 0.3)              # 109 x 102 x 95 points x 8 channels = 34 MB: several chunks
+    w2 = W.fixture_workload("CHA_1.4_3b4eeb96", "O_co2", 0.3)
+    for ng in (1, 3):
+        if ng > hip_lib.ceg_device_count():
+            monkeypatch.setenv("CEG_HIP_OVERSUBSCRIBE", "1")
+        # (the reference is the ordinary route with the SAME slab split: a slab that does not start on a multiple of 4 planes shifts
+        #  the tiles, which reorders the FP64 sums -- a one-ULP difference in a value or two against the one-slab build)
+        ref_v = G.build_vdw_array(w.probe_vdw, w.cset, ngpus=ng)
+        ref_c = G.build_coulomb_array(w.probe_coulomb, w.alpha, w.cset, ngpus=ng)
+        out = G.alloc_host_grid(w.cset)
+        out[:] = np.nan
+        got = G.build_vdw_array(w.probe_vdw, w.cset, ngpus=ng, out=out)
+        assert got is out and np.array_equal(out.view(np.int32), ref_v.view(np.int32)), ng
+        out[:] = np.nan
+        G.build_coulomb_array(w.probe_coulomb, w.alpha, w.cset, ngpus=ng, out=out)
+        assert np.array_equal(out.view(np.int32), ref_c.view(np.int32)), ng
+        addr = out.ctypes.data
+        del out, got
+        gc.collect()
+        again = G.alloc_host_grid(w.cset)                              # the array went back to the cache: same memory again
+        assert again.ctypes.data == addr
+        del again
+        gc.collect()
+    vg, cg = G.build_multi_arrays([w.probe_vdw, w2.probe_vdw], w.probe_coulomb, w.alpha, w.cset, pinned=True)
+    vr, cr = G.build_multi_arrays([w.probe_vdw, w2.probe_vdw], w.probe_coulomb, w.alpha, w.cset)
+    assert all(np.array_equal(a.view(np.int32), b.view(np.int32)) for a, b in zip(vg + [cg], vr + [cr]))
+    with pytest.raises(ValueError):
+        G.build_vdw_array(w.probe_vdw, w.cset, out=np.empty((8, 3, 3, 3), dtype=np.float32))
+    foreign = np.zeros(16, dtype=np.float32)
+    assert hip_lib.ceg_host_grid_free(foreign.ctypes.data_as(_abi.c_float_p)) == -1 and hip_lib.ceg_host_grid_free(None) == 0
+    bad = np.array([0, 3, 3], dtype=np.int32)
+    assert not hip_lib.ceg_host_grid_alloc(_abi.i32ptr(bad))
