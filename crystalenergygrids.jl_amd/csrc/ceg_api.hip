@@ -1508,10 +1508,10 @@ int device_pipeline(int mode, int d, int b, int e, int nx, int64_t plane, const 
             const size_t cpts = (size_t)(ce - cb) * plane;
             float* slot = h_ring + (size_t)(j % R) * slot_floats;
             if (hipStreamWaitEvent(s_copy, ev_comp[j], 0) != hipSuccess) rc = bad(CEG_ERR_HIP, "hipStreamWaitEvent failed");
-            for (int c = 0; c < 8 && !rc; ++c)
-                if (hipMemcpyAsync(slot + (size_t)c * cpts, d_out + (size_t)c * slab_pts + (size_t)(cb - b) * plane, sizeof(float) * cpts,
-                                   hipMemcpyDeviceToHost, s_copy) != hipSuccess)
-                    rc = bad(CEG_ERR_HIP, "hipMemcpyAsync D2H failed");
+            // the chunk's 8 channel segments as one strided copy into the slot ([8][cpts])
+            if (!rc && hipMemcpy2DAsync(slot, sizeof(float) * cpts, d_out + (size_t)(cb - b) * plane, sizeof(float) * (size_t)slab_pts,
+                                        sizeof(float) * cpts, 8, hipMemcpyDeviceToHost, s_copy) != hipSuccess)
+                rc = bad(CEG_ERR_HIP, "hipMemcpy2DAsync D2H failed");
             if (!rc && hipEventRecord(ev_copy[j], s_copy) != hipSuccess) rc = bad(CEG_ERR_HIP, "hipEventRecord failed");
             if (rc) drain_rc.store(rc);
             enqueued.store(j + 1);
@@ -1734,11 +1734,10 @@ int multi_device_pipeline(int d, int b, int e, int nx, int64_t plane, const doub
             float* slot = h_ring + (size_t)(j % R) * slot_floats;
             if (hipStreamWaitEvent(s_copy, ev_comp[j], 0) != hipSuccess) rc = bad(CEG_ERR_HIP, "hipStreamWaitEvent failed");
             for (int gidx = 0; gidx < NG && !rc; ++gidx)
-                for (int c = 0; c < 8 && !rc; ++c)
-                    if (hipMemcpyAsync(slot + (size_t)gidx * grid_slot + (size_t)c * cpts,
-                                       d_all + (size_t)gidx * 8 * slab_pts + (size_t)c * slab_pts + (size_t)(cb - b) * plane, sizeof(float) * cpts,
-                                       hipMemcpyDeviceToHost, s_copy) != hipSuccess)
-                        rc = bad(CEG_ERR_HIP, "hipMemcpyAsync D2H failed");
+                if (hipMemcpy2DAsync(slot + (size_t)gidx * grid_slot, sizeof(float) * cpts,
+                                     d_all + (size_t)gidx * 8 * slab_pts + (size_t)(cb - b) * plane, sizeof(float) * (size_t)slab_pts,
+                                     sizeof(float) * cpts, 8, hipMemcpyDeviceToHost, s_copy) != hipSuccess)
+                    rc = bad(CEG_ERR_HIP, "hipMemcpy2DAsync D2H failed");
             if (!rc && hipEventRecord(ev_copy[j], s_copy) != hipSuccess) rc = bad(CEG_ERR_HIP, "hipEventRecord failed");
             if (rc) drain_rc.store(rc);
             enqueued.store(j + 1);
