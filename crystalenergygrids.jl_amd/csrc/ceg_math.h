@@ -209,4 +209,35 @@ __device__ __forceinline__ double erfcx_poly(double x)
     return p;
 }
 
+// sin(2 pi u), cos(2 pi u) for any finite u of moderate size (|u| < 2^20, say): u is reduced to [-1/2, 1/2] and to the octant
+// |2 pi v| <= pi/4 exactly (v = u - k/4), then the Cephes minimax polynomials of sin / cos on that interval; max abs error 1.9e-16
+// (checked against extended precision on 2e6 random arguments).  ~35 instructions where ocml's sincospi, which also handles
+// huge and non-finite arguments, takes ~230: the reciprocal-space tables of ceg_recip / ceg_mc are built from it.
+__device__ __forceinline__ void sincos_2pi(double u, double& s, double& c)
+{
+    u -= rint(u);
+    const double k = rint(4.0 * u);                       // -2 .. 2
+    const double v = __builtin_fma(k, -0.25, u);          // exact
+    const double x = v * 6.283185307179586476925;
+    const double z = x * x;
+    double ps = 1.58962301576546568060e-10;
+    ps = __builtin_fma(ps, z, -2.50507477628578072866e-8);
+    ps = __builtin_fma(ps, z, 2.75573136213857245213e-6);
+    ps = __builtin_fma(ps, z, -1.98412698295895385996e-4);
+    ps = __builtin_fma(ps, z, 8.33333333332211858878e-3);
+    ps = __builtin_fma(ps, z, -1.66666666666666307295e-1);
+    const double sinx = __builtin_fma(x * z, ps, x);
+    double pc = -1.13585365213876817300e-11;
+    pc = __builtin_fma(pc, z, 2.08757008419747316778e-9);
+    pc = __builtin_fma(pc, z, -2.75573141792967388112e-7);
+    pc = __builtin_fma(pc, z, 2.48015872888517045348e-5);
+    pc = __builtin_fma(pc, z, -1.38888888888730564116e-3);
+    pc = __builtin_fma(pc, z, 4.16666666666665929218e-2);
+    const double cosx = __builtin_fma(z * z, pc, __builtin_fma(z, -0.5, 1.0));
+    const int q = (int)k & 3;                             // angle = x + q pi/2
+    const double a = (q & 1) ? cosx : sinx, b = (q & 1) ? sinx : cosx;
+    s = (q & 2) ? -a : a;
+    c = ((q + 1) & 2) ? -b : b;
+}
+
 }  // namespace ceg

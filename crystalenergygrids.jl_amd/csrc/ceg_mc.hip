@@ -108,7 +108,7 @@ __device__ __forceinline__ void unpack(double w, int& kind, int& mol)
 }
 
 // e^{2 pi i m f} tables of `m_atoms` atoms at s_pos (setup_Eik / move_one_system!, src/ewald.jl:109-146,352-366),
-// by sincospi of the exact angle; entry t of atom a at tab[a * stride + t]: t in [0, kx] -> x, then y (m = -ky..ky), then z
+// by sine / cosine of the exact angle (ceg_math.h sincos_2pi); entry t of atom a at tab[a * stride + t]: t in [0, kx] -> x, then y (m = -ky..ky), then z
 __device__ __forceinline__ void fill_tables(const McView& v, const double* s_pos, int m_atoms, double2* tab, int stride, int tid, int nthreads)
 {
     const int kx = v.ks[0], ky = v.ks[1], kz = v.ks[2];
@@ -124,7 +124,7 @@ __device__ __forceinline__ void fill_tables(const McView& v, const double* s_pos
         else { f = I[2] * x + I[5] * y + I[8] * z; mm = t - nxp - nyp - kz; }
         const double ff = f - rint(f);
         double s, c;
-        sincospi(2.0 * (double)mm * ff, &s, &c);
+        ceg::sincos_2pi((double)mm * ff, s, c);
         tab[e] = make_double2(c, s);
     }
 }

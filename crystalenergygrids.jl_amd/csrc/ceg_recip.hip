@@ -4,17 +4,27 @@
 //
 // One wave64 per placement of the molecule.  The wave first fills, in LDS, the three tables
 // e^{2 pi i m f_x} (m = 0..kx), e^{2 pi i m f_y} (m = -ky..ky), e^{2 pi i m f_z} (m = -kz..kz) of
-// every atom -- by sincospi of the exact angle instead of the reference's repeated complex
-// multiplication (same values, smaller rounding error) -- then the lanes stride over the k-vectors
-// (coalesced reads of ijk / kfactor / framework structure factor), each forming
-// S_a(k) = sum_atoms q Ex[i] Ey[j] Ez[k] from the tables, and a wave reduction finishes the two
-// sums.  ~nk * natoms * 20 flops per placement; no MFMA (complex products with per-lane table
-// lookups, not a contraction with a shared operand).
+// every atom -- by sine and cosine of the exact angle (ceg_math.h sincos_2pi) instead of the reference's repeated complex
+// multiplication (same values, smaller rounding error).  The k-vectors are then walked the way the
+// reference stores them (kspace.kindices, src/ewald.jl:213-236): as ROWS (j, k) x (i = i0 .. i0+len-1).
+// ceg_recip_create regroups the flat list into such rows, cuts them into segments of <= SEG k-vectors and
+// deals the segments, longest first, to the 64 lanes; a lane forms Ey[j] Ez[k] q ONCE per segment and atom
+// (the charge rides on the z table) and steps along i with Ex[i+1] = Ex[i] Ex[1] -- per k-vector and atom 8 FMAs and no LDS access, where the
+// first version of this kernel (three per-lane table reads + a 32-byte constant record per k-vector) was
+// bound by the LDS pipe at 0.19 of the FP64 peak.  The per-k-vector constants (kf Re S_f, kf Im S_f, kf)
+// sit in [slot][lane] planes: conflict-free 8-byte reads, zero in the padding slots, so that a round runs
+// to its longest segment without lane masks.  A wave reduction finishes the two sums.  No MFMA: complex
+// products with per-lane operands, not a contraction with a shared operand.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <map>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "../../include/ceg_hip.h"
+#include "ceg_math.h"
 
 extern "C" void ceg_set_last_error_(const char* msg);
 
@@ -22,7 +32,9 @@ namespace {
 
 constexpr int MAX_ATOMS = 16;       // atoms per molecule held in LDS
 constexpr int MAX_TAB = 400;        // (kx+1) + (2ky+1) + (2kz+1) per atom
-constexpr int WAVES = 4;            // placements per workgroup
+constexpr int MAX_WAVES = 8;        // placements in flight per workgroup (the constants in LDS are shared: two workgroups = 4 waves per SIMD);
+                                    // fewer (4, 2, 1) when the tables of a large molecule / k-space would not fit
+constexpr int SEG = 10;             // k-vectors per segment (structure-factor accumulators a lane holds); the switch in k_recip lists 1..SEG
 
 struct RecipGeom {
     double invmat[9];
@@ -32,87 +44,118 @@ struct RecipGeom {
     double energy_net_charges, static_contribution;
 };
 
-// k-space constants of one k-vector as the kernel reads them from LDS: packed (i, j, k) and the three
-// products the energy needs -- E = 2 sum(A sr + B si) + sum(kf (sr^2 + si^2)), A = kf Re S_f, B = kf Im S_f
-struct KPack {
-    double A, B, kf;
-    int32_t ijk;          // i | (j + 128) << 8 | (k + 128) << 16
-    int32_t _pad;
-};
-
-__global__ __launch_bounds__(64 * WAVES) void k_recip(RecipGeom g, const int32_t* __restrict__ ijk,
-                                                       const double* __restrict__ kf, const double* __restrict__ sfre,
-                                                       const double* __restrict__ sfim, int64_t nk,
-                                                       const double* __restrict__ pos, int64_t n, double* __restrict__ out,
-                                                       int tab_stride, int per_wave, int k_in_lds)
+// One round of k_recip for segments of LEN k-vectors: the structure factor of the molecule at (i0 + s, j, k), s < LEN, then the two
+// energy sums with the constants of the round's slots (at[s * 64] of each plane).
+template <int LEN>
+__device__ __forceinline__ void recip_round(const RecipGeom& g, const double2* tab, int tab_stride, int nxp, int nyp, int i0, int jj, int kk,
+                                            const double* cA, const double* cB, const double* ckf, size_t at, double& fa, double& aa)
 {
-    // dynamic LDS: [k_in_lds ? nk : 0] KPack, then [WAVES][natoms][tab_stride] double2
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    KPack* s_k = reinterpret_cast<KPack*>(s_raw);
-    double2* s_tab = reinterpret_cast<double2*>(s_raw + (k_in_lds ? sizeof(KPack) * (size_t)nk : 0));
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (k_in_lds) {
-        // every placement of the workgroup reads all k-vectors: stage them once (32 B per k-vector)
-        for (int64_t q = threadIdx.x; q < nk; q += 64 * WAVES) {
-            KPack kp;
-            const double t = kf[q];
-            kp.A = t * sfre[q]; kp.B = t * sfim[q]; kp.kf = t;
-            kp.ijk = ijk[3 * q] | ((ijk[3 * q + 1] + 128) << 8) | ((ijk[3 * q + 2] + 128) << 16);
-            kp._pad = 0;
-            s_k[q] = kp;
+    double sr[LEN], si[LEN];
+#pragma unroll
+    for (int s = 0; s < LEN; ++s) sr[s] = si[s] = 0.0;
+    for (int a = 0; a < g.natoms; ++a) {
+        const double2* ta = tab + a * tab_stride;
+        const double2 ey = ta[nxp + jj], ez = ta[nxp + nyp + kk], e1 = ta[nxp > 1 ? 1 : 0];
+        double2 ex = ta[i0];
+        const double cr = ey.x * ez.x - ey.y * ez.y, ci = ey.x * ez.y + ey.y * ez.x;      // c*Eiky*Eikz: the z table carries the charge
+#pragma unroll
+        for (int s = 0; s < LEN; ++s) {
+            sr[s] += ex.x * cr - ex.y * ci;
+            si[s] += ex.x * ci + ex.y * cr;
+            if (s + 1 < LEN) {
+                const double nx = ex.x * e1.x - ex.y * e1.y;
+                ex.y = ex.x * e1.y + ex.y * e1.x;
+                ex.x = nx;
+            }
         }
+    }
+#pragma unroll
+    for (int s = 0; s < LEN; ++s) {
+        const size_t idx = at + (size_t)s * 64;
+        fa += cA[idx] * sr[s] + cB[idx] * si[s];
+        aa += ckf[idx] * (sr[s] * sr[s] + si[s] * si[s]);
+    }
+}
+
+// g_desc[r * 64 + lane]: segment of `lane` in round r: i0 | (j + ky) << 9 | (k + kz) << 18 | L_r << 27 (nine bits each: MAX_TAB < 512; L_r = longest segment of the
+// round, the same in every lane).  g_c: three planes [ns * 64] of the constants A = kf Re S_f, B = kf Im S_f, kf by (slot, lane):
+// the slots of round r are the L_r following those of round r - 1.
+template <bool C_IN_LDS, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_recip(RecipGeom g, const int32_t* __restrict__ g_desc, const double* __restrict__ g_c,
+                                                       int nrounds, int ns, const double* __restrict__ pos, int64_t n,
+                                                       double* __restrict__ out, int tab_stride, int per_wave)
+{
+    // dynamic LDS: [C_IN_LDS: 3 ns 64 doubles, nrounds 64 int32 (padded to 16 B)], then [WAVES][natoms][tab_stride] double2
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    const size_t cdoubles = C_IN_LDS ? (size_t)3 * ns * 64 : 0;
+    const size_t dints = C_IN_LDS ? (((size_t)nrounds * 64 + 3) & ~(size_t)3) : 0;
+    double* s_c = reinterpret_cast<double*>(s_raw);
+    int32_t* s_desc = reinterpret_cast<int32_t*>(s_raw + cdoubles * sizeof(double));
+    double2* s_tab = reinterpret_cast<double2*>(s_raw + cdoubles * sizeof(double) + dints * sizeof(int32_t));
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (C_IN_LDS) {
+        // every placement of the workgroup reads all constants: stage them once
+        for (size_t t = threadIdx.x; t < cdoubles; t += 64 * WAVES) s_c[t] = g_c[t];
+        for (int t = threadIdx.x; t < nrounds * 64; t += 64 * WAVES) s_desc[t] = g_desc[t];
         __syncthreads();
     }
+    const double* cA = C_IN_LDS ? s_c : g_c;
+    const double* cB = cA + (size_t)ns * 64;
+    const double* ckf = cB + (size_t)ns * 64;
+    const int32_t* desc = C_IN_LDS ? s_desc : g_desc;
     const int kx = g.ks[0], ky = g.ks[1], kz = g.ks[2];
     const int nxp = kx + 1, nyp = 2 * ky + 1, nzp = 2 * kz + 1;
     double2* tab = s_tab + (size_t)wave * g.natoms * tab_stride;
     const double* I = g.invmat;
     const int64_t p0 = ((int64_t)blockIdx.x * WAVES + wave) * per_wave;
-    for (int64_t p = p0; p < p0 + per_wave && p < n; ++p) {
+    const int64_t p1 = p0 + per_wave < n ? p0 + per_wave : n;
+    // the coordinates of a placement (3 natoms <= 48 doubles) are fetched by the lanes one placement ahead and handed over through LDS
+    __shared__ double s_pos[MAX_WAVES][3 * MAX_ATOMS];
+    __shared__ double s_q[MAX_ATOMS];
+    if (threadIdx.x < MAX_ATOMS) s_q[threadIdx.x] = (int)threadIdx.x < g.natoms ? g.q[threadIdx.x] : 0.0;
+    __syncthreads();
+    const int nc = 3 * g.natoms;
+    double next = (lane < nc && p0 < p1) ? pos[(size_t)p0 * nc + lane] : 0.0;
+    for (int64_t p = p0; p < p1; ++p) {
+        if (lane < nc) s_pos[wave][lane] = next;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nc && p + 1 < p1) next = pos[(size_t)(p + 1) * nc + lane];
         // ---- tables: entry t of atom a = exp(2 pi i m f), m and the axis decoded from t
-        for (int a = 0; a < g.natoms; ++a) {
-            const double* r = pos + ((size_t)p * g.natoms + a) * 3;
-            const double fx = I[0] * r[0] + I[3] * r[1] + I[6] * r[2];
-            const double fy = I[1] * r[0] + I[4] * r[1] + I[7] * r[2];
-            const double fz = I[2] * r[0] + I[5] * r[1] + I[8] * r[2];
-            for (int t = lane; t < nxp + nyp + nzp; t += 64) {
-                double f;
-                int m;
-                if (t < nxp) { f = fx; m = t; }
-                else if (t < nxp + nyp) { f = fy; m = t - nxp - ky; }
-                else { f = fz; m = t - nxp - nyp - kz; }
+        for (int t = lane; t < nxp + nyp + nzp; t += 64) {
+            const int ax = t < nxp ? 0 : (t < nxp + nyp ? 1 : 2);
+            const int m = ax == 0 ? t : (ax == 1 ? t - nxp - ky : t - nxp - nyp - kz);
+            const double i0 = I[ax], i1 = I[ax + 3], i2 = I[ax + 6];
+            for (int a = 0; a < g.natoms; ++a) {
+                const double* r = s_pos[wave] + 3 * a;
+                const double f = i0 * r[0] + i1 * r[1] + i2 * r[2];
                 const double ff = f - rint(f);                   // exp(2 pi i m f) is periodic in f
-                double s, c;
-                sincospi(2.0 * (double)m * ff, &s, &c);
-                tab[a * tab_stride + t] = make_double2(c, s);
+                double sn, cs;
+                ceg::sincos_2pi((double)m * ff, sn, cs);
+                const double w = ax == 2 ? s_q[a] : 1.0;          // the charge rides on the z factor
+                tab[a * tab_stride + t] = make_double2(w * cs, w * sn);
             }
         }
         __builtin_amdgcn_wave_barrier();
-        // ---- k-vector loop
+        // ---- rounds: one segment (j, k, i0 .. i0 + L - 1) per lane
         double fa = 0.0, aa = 0.0;
-        for (int64_t q = lane; q < nk; q += 64) {
-            int i, j, k;
-            double A, B, t;
-            if (k_in_lds) {
-                const KPack kp = s_k[q];
-                i = kp.ijk & 0xff; j = ((kp.ijk >> 8) & 0xff) - 128; k = ((kp.ijk >> 16) & 0xff) - 128;
-                A = kp.A; B = kp.B; t = kp.kf;
-            } else {
-                i = ijk[3 * q]; j = ijk[3 * q + 1]; k = ijk[3 * q + 2];
-                t = kf[q]; A = t * sfre[q]; B = t * sfim[q];
+        int slot = 0;
+        for (int r = 0; r < nrounds; ++r) {
+            const int d = desc[r * 64 + lane];
+            const int L = __builtin_amdgcn_readfirstlane(d >> 27);
+            const int i0 = d & 0x1ff, jj = (d >> 9) & 0x1ff, kk = (d >> 18) & 0x1ff;
+            switch (L) {        // one branch-free body per round length: the loads of a round are then scheduled ahead of its arithmetic
+            case 1: recip_round<1>(g, tab, tab_stride, nxp, nyp, i0, jj, kk, cA, cB, ckf, (size_t)slot * 64 + lane, fa, aa); break;
+            case 2: recip_round<2>(g, tab, tab_stride, nxp, nyp, i0, jj, kk, cA, cB, ckf, (size_t)slot * 64 + lane, fa, aa); break;
+            case 3: recip_round<3>(g, tab, tab_stride, nxp, nyp, i0, jj, kk, cA, cB, ckf, (size_t)slot * 64 + lane, fa, aa); break;
+            case 4: recip_round<4>(g, tab, tab_stride, nxp, nyp, i0, jj, kk, cA, cB, ckf, (size_t)slot * 64 + lane, fa, aa); break;
+            case 5: recip_round<5>(g, tab, tab_stride, nxp, nyp, i0, jj, kk, cA, cB, ckf, (size_t)slot * 64 + lane, fa, aa); break;
+            case 6: recip_round<6>(g, tab, tab_stride, nxp, nyp, i0, jj, kk, cA, cB, ckf, (size_t)slot * 64 + lane, fa, aa); break;
+            case 7: recip_round<7>(g, tab, tab_stride, nxp, nyp, i0, jj, kk, cA, cB, ckf, (size_t)slot * 64 + lane, fa, aa); break;
+            case 8: recip_round<8>(g, tab, tab_stride, nxp, nyp, i0, jj, kk, cA, cB, ckf, (size_t)slot * 64 + lane, fa, aa); break;
+            case 9: recip_round<9>(g, tab, tab_stride, nxp, nyp, i0, jj, kk, cA, cB, ckf, (size_t)slot * 64 + lane, fa, aa); break;
+            default: recip_round<SEG>(g, tab, tab_stride, nxp, nyp, i0, jj, kk, cA, cB, ckf, (size_t)slot * 64 + lane, fa, aa); break;
             }
-            double sr = 0.0, si = 0.0;
-            for (int a = 0; a < g.natoms; ++a) {
-                const double2 ex = tab[a * tab_stride + i];
-                const double2 ey = tab[a * tab_stride + nxp + ky + j];
-                const double2 ez = tab[a * tab_stride + nxp + nyp + kz + k];
-                const double yr = ey.x * ez.x - ey.y * ez.y, yi = ey.x * ez.y + ey.y * ez.x;      // Eiky*Eikz
-                const double cr = g.q[a] * yr, ci = g.q[a] * yi;                                  // c*Eik_yz
-                sr += ex.x * cr - ex.y * ci;
-                si += ex.x * ci + ex.y * cr;
-            }
-            fa += A * sr + B * si;
-            aa += t * (sr * sr + si * si);
+            slot += L;
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -137,9 +180,93 @@ struct ceg_recip {
     int64_t nk = 0;
     int32_t ks[3] = {0, 0, 0};
     double invmat[9];
-    int32_t* d_ijk = nullptr;
-    double *d_kf = nullptr, *d_re = nullptr, *d_im = nullptr;
+    // the k-vectors regrouped into rows (j, k) x (i0 .. i0 + len - 1), cut into segments and dealt to the lanes (see the kernel)
+    int nrounds = 0, ns = 0;
+    std::vector<int64_t> slot_of;       // plane index (slot * 64 + lane) of k-vector q
+    std::vector<double> h_kf;
+    int32_t* d_desc = nullptr;
+    double* d_c = nullptr;              // planes A, B, kf: [3][ns * 64]
 };
+
+namespace {
+
+// Regroup the flat k-vector list: rows of consecutive i at fixed (j, k), cut into segments of <= seg k-vectors of nearly equal length,
+// sorted by length (longest first) and dealt to the lanes in rounds of 64 -- the segments of one round have nearly the same length,
+// so a round that runs to its longest segment wastes little.  Returns the padded slot count.
+struct Layout {
+    int nrounds = 0, ns = 0;
+    std::vector<int32_t> desc;
+    std::vector<int64_t> slot_of;
+};
+Layout build_layout(const int32_t* ijk, int64_t nk, const int32_t ks[3], int seg)
+{
+    std::map<std::pair<int, int>, std::vector<std::pair<int, int64_t>>> rows;        // (j, k) -> (i, q)
+    for (int64_t q = 0; q < nk; ++q) rows[{ijk[3 * q + 1], ijk[3 * q + 2]}].push_back({ijk[3 * q], q});
+    struct Seg { int j, k, i0, len; std::vector<int64_t> q; };
+    std::vector<Seg> segs;
+    for (auto& kv : rows) {
+        auto& v = kv.second;
+        std::sort(v.begin(), v.end());
+        size_t b = 0;
+        while (b < v.size()) {
+            size_t e = b + 1;
+            while (e < v.size() && v[e].first == v[e - 1].first + 1) ++e;          // run of consecutive i (a repeated i starts a new run)
+            const int len = (int)(e - b), parts = (len + seg - 1) / seg;
+            size_t at = b;
+            for (int part = 0; part < parts; ++part) {
+                const int l = len / parts + (part < len % parts ? 1 : 0);
+                Seg s{kv.first.first, kv.first.second, v[at].first, l, {}};
+                for (int t = 0; t < l; ++t) s.q.push_back(v[at + t].second);
+                segs.push_back(std::move(s));
+                at += l;
+            }
+            b = e;
+        }
+    }
+    std::stable_sort(segs.begin(), segs.end(), [](const Seg& a, const Seg& b) { return a.len > b.len; });
+    Layout out;
+    out.nrounds = (int)((segs.size() + 63) / 64);
+    out.desc.assign((size_t)out.nrounds * 64, 0);
+    out.slot_of.assign((size_t)nk, 0);
+    int slot = 0;
+    for (int r = 0; r < out.nrounds; ++r) {
+        const int L = segs[(size_t)r * 64].len;
+        for (int l = 0; l < 64; ++l) {
+            const size_t si = (size_t)r * 64 + l;
+            const int lane = (r & 1) ? 63 - l : l;
+            int32_t d = (ks[1] << 9) | (ks[2] << 18);                              // padding: j = k = i0 = 0, all constants zero
+            if (si < segs.size()) {
+                const Seg& s = segs[si];
+                d = s.i0 | ((s.j + ks[1]) << 9) | ((s.k + ks[2]) << 18);
+                for (int t = 0; t < s.len; ++t) out.slot_of[(size_t)s.q[t]] = (int64_t)(slot + t) * 64 + lane;
+            }
+            out.desc[(size_t)r * 64 + lane] = d | (L << 27);
+        }
+        slot += L;
+    }
+    out.ns = slot;
+    return out;
+}
+
+// cost model of a layout for the choice of the segment length: per round and atom one Ey Ez q product + table reads (~14 FP64
+// instructions' worth), per slot 8 FMAs per atom + 5 for the energy; two atoms assumed
+double layout_cost(const Layout& l) { return 2.0 * 14.0 * l.nrounds + (2.0 * 8.0 + 5.0) * l.ns; }
+
+int upload_constants(ceg_recip* h, const double* sf_re, const double* sf_im)
+{
+    const size_t plane = (size_t)h->ns * 64;
+    std::vector<double> c(3 * std::max<size_t>(plane, 1), 0.0);
+    for (int64_t q = 0; q < h->nk; ++q) {
+        const double t = h->h_kf[(size_t)q];
+        const size_t at = (size_t)h->slot_of[(size_t)q];
+        c[at] = t * sf_re[q];
+        c[plane + at] = t * sf_im[q];
+        c[2 * plane + at] = t;
+    }
+    return hipMemcpy(h->d_c, c.data(), 3 * plane * sizeof(double), hipMemcpyHostToDevice) == hipSuccess ? 0 : 1;
+}
+
+}  // namespace
 
 extern "C" int ceg_recip_create(ceg_recip_t** handle, int32_t device, const int32_t* kvec_ijk, const double* kfactors,
                                 const double* sf_re, const double* sf_im, int64_t nk, const int32_t ks[3],
@@ -163,16 +290,24 @@ extern "C" int ceg_recip_create(ceg_recip_t** handle, int32_t device, const int3
     h->nk = nk;
     for (int a = 0; a < 3; ++a) h->ks[a] = ks[a];
     for (int a = 0; a < 9; ++a) h->invmat[a] = invmat[a];
-    const size_t m = nk > 0 ? (size_t)nk : 1;
-    bool ok = hipMalloc((void**)&h->d_ijk, m * 3 * sizeof(int32_t)) == hipSuccess &&
-              hipMalloc((void**)&h->d_kf, m * sizeof(double)) == hipSuccess &&
-              hipMalloc((void**)&h->d_re, m * sizeof(double)) == hipSuccess &&
-              hipMalloc((void**)&h->d_im, m * sizeof(double)) == hipSuccess;
+    Layout best;
+    if (nk > 0) {
+        best = build_layout(kvec_ijk, nk, ks, SEG);
+        for (int seg = SEG - 1; seg >= 3; --seg) {                 // shorter segments can fill the last round better
+            Layout l = build_layout(kvec_ijk, nk, ks, seg);
+            if (layout_cost(l) < layout_cost(best)) best = std::move(l);
+        }
+    }
+    h->nrounds = best.nrounds;
+    h->ns = best.ns;
+    h->slot_of = std::move(best.slot_of);
+    h->h_kf.assign(kfactors, kfactors + nk);
+    const size_t plane = std::max<size_t>((size_t)h->ns * 64, 1), nd = std::max<size_t>((size_t)h->nrounds * 64, 1);
+    bool ok = hipMalloc((void**)&h->d_desc, nd * sizeof(int32_t)) == hipSuccess &&
+              hipMalloc((void**)&h->d_c, 3 * plane * sizeof(double)) == hipSuccess;
     if (ok && nk > 0)
-        ok = hipMemcpy(h->d_ijk, kvec_ijk, nk * 3 * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess &&
-             hipMemcpy(h->d_kf, kfactors, nk * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
-             hipMemcpy(h->d_re, sf_re, nk * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
-             hipMemcpy(h->d_im, sf_im, nk * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+        ok = hipMemcpy(h->d_desc, best.desc.data(), best.desc.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess &&
+             upload_constants(h, sf_re, sf_im) == 0;
     if (prev >= 0) (void)hipSetDevice(prev);
     if (!ok) {
         ceg_recip_destroy(h);
@@ -191,8 +326,7 @@ extern "C" int ceg_recip_set_structure_factor(ceg_recip_t* h, const double* sf_r
     if (hipSetDevice(h->device) != hipSuccess) return rerr(CEG_ERR_HIP, "hipSetDevice failed");
     // hipMemcpy from pageable memory is synchronous with respect to earlier work on the null stream;
     // launches on other streams must be ordered by the caller (documented in INTEGRATION.md)
-    const bool ok = hipMemcpy(h->d_re, sf_re, h->nk * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
-                    hipMemcpy(h->d_im, sf_im, h->nk * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+    const bool ok = upload_constants(h, sf_re, sf_im) == 0;
     if (prev >= 0) (void)hipSetDevice(prev);
     return ok ? CEG_OK : rerr(CEG_ERR_HIP, "could not upload the structure factor");
 }
@@ -203,10 +337,8 @@ extern "C" int ceg_recip_destroy(ceg_recip_t* h)
     int prev = -1;
     (void)hipGetDevice(&prev);
     if (hipSetDevice(h->device) == hipSuccess) {
-        (void)hipFree(h->d_ijk);
-        (void)hipFree(h->d_kf);
-        (void)hipFree(h->d_re);
-        (void)hipFree(h->d_im);
+        (void)hipFree(h->d_desc);
+        (void)hipFree(h->d_c);
     }
     if (prev >= 0) (void)hipSetDevice(prev);
     delete h;
@@ -228,26 +360,40 @@ extern "C" int ceg_recip_energy_device(ceg_recip_t* h, const double* d_positions
     g.energy_net_charges = energy_net_charges;
     g.static_contribution = static_contribution;
     const int tab_stride = h->ks[0] + 1 + 2 * h->ks[1] + 1 + 2 * h->ks[2] + 1;
-    const size_t tab_bytes = sizeof(double2) * (size_t)WAVES * natoms * tab_stride;
+    int waves = MAX_WAVES;
+    while (waves > 1 && sizeof(double2) * (size_t)waves * natoms * tab_stride > 40 * 1024) waves >>= 1;
+    const size_t tab_bytes = sizeof(double2) * (size_t)waves * natoms * tab_stride;
     if (tab_bytes > 64 * 1024) return rerr(CEG_ERR_UNSUPPORTED, "tables do not fit in LDS");
     // k-vector constants in LDS when they fit beside the tables (every placement reads all of them)
-    const size_t k_bytes = sizeof(KPack) * (size_t)h->nk;
-    const bool small_k = h->ks[1] < 128 && h->ks[2] < 128 && h->ks[0] < 256;
-    const int k_in_lds = (small_k && tab_bytes + k_bytes <= 60 * 1024) ? 1 : 0;
-    const size_t lds = tab_bytes + (k_in_lds ? k_bytes : 0);
-    // placements per wave: amortise the staging of the k-vectors, but keep >= ~4 workgroups per CU in flight
+    const size_t c_bytes = sizeof(double) * 3 * (size_t)h->ns * 64 + sizeof(int32_t) * ((((size_t)h->nrounds * 64) + 3) & ~(size_t)3);
+    const bool c_in_lds = tab_bytes + c_bytes <= 64 * 1024;
+    const size_t lds = tab_bytes + (c_in_lds ? c_bytes : 0);
+    // placements per wave: amortise the staging of the constants, but keep >= ~4 workgroups per CU in flight
     int per_wave = 1;
-    if (k_in_lds) {
+    if (c_in_lds) {
         per_wave = 8;
-        while (per_wave > 1 && n / ((int64_t)per_wave * WAVES) < 2048) per_wave >>= 1;
+        while (per_wave > 1 && n / ((int64_t)per_wave * waves) < 2048) per_wave >>= 1;
     }
-    const int64_t nblocks = (n + (int64_t)WAVES * per_wave - 1) / ((int64_t)WAVES * per_wave);
+    const int64_t nblocks = (n + (int64_t)waves * per_wave - 1) / ((int64_t)waves * per_wave);
     if (nblocks > 0x7fffffffLL) return rerr(CEG_ERR_INVALID, "too many placements");
     int prev = -1;
     (void)hipGetDevice(&prev);
     if (hipSetDevice(h->device) != hipSuccess) return rerr(CEG_ERR_HIP, "hipSetDevice failed");
-    hipLaunchKernelGGL(k_recip, dim3((unsigned)nblocks), dim3(64 * WAVES), lds, (hipStream_t)stream, g, h->d_ijk, h->d_kf,
-                       h->d_re, h->d_im, h->nk, d_positions, n, d_out, tab_stride, per_wave, k_in_lds);
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3((unsigned)nblocks), dim3(64 * waves), lds, (hipStream_t)stream, g, h->d_desc, h->d_c,
+                           h->nrounds, h->ns, d_positions, n, d_out, tab_stride, per_wave);
+    };
+    if (c_in_lds) {
+        if (waves == 8) launch(k_recip<true, 8>);
+        else if (waves == 4) launch(k_recip<true, 4>);
+        else if (waves == 2) launch(k_recip<true, 2>);
+        else launch(k_recip<true, 1>);
+    } else {
+        if (waves == 8) launch(k_recip<false, 8>);
+        else if (waves == 4) launch(k_recip<false, 4>);
+        else if (waves == 2) launch(k_recip<false, 2>);
+        else launch(k_recip<false, 1>);
+    }
     const hipError_t e = hipGetLastError();
     if (prev >= 0) (void)hipSetDevice(prev);
     if (e != hipSuccess) return rerr(CEG_ERR_HIP, hipGetErrorString(e));

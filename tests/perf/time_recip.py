@@ -40,13 +40,15 @@ for molname in ("Na", "CO2"):
     # roofline.  Algorithmic FP64 work per placement: per atom and k-vector the product of three table entries
     # (2 complex multiplications = 12 flops), the charge (2) and the accumulation into the structure factor (2) = 16 flops; per
     # k-vector the two energy terms 2 kf Re(conj(F) S) + kf |S|^2 = 10 flops; per atom the (kx+1) + (2ky+1) + (2kz+1) table entries
-    # by sincospi (~40 flops each).  Bytes: 24 B per atom in, 8 B out, tables and k-vector constants live in LDS -> compute bound.
+    # (sine + cosine, ~40 flops each).  Bytes: 24 B per atom in, 8 B out, tables and k-vector constants live in LDS -> compute bound.
+    # (The kernel walks the k-vectors as rows (j, k) x i, so the Ey Ez q product is formed once per row segment and the step along i
+    # is one complex product: it executes fewer flops per k-vector than this count, which is kept so that rounds compare.)
     ks = np.asarray(ef.kspace.ks)
     ntab = int(ks[0] + 1 + 2 * ks[1] + 1 + 2 * ks[2] + 1)
     flops = n * (na * nk * 16.0 + nk * 10.0 + na * ntab * 40.0)
     print(f"roofline k_recip {molname}: {flops / n:.0f} algorithmic flops/placement -> {flops / (ms * 1e-3) / 1e12:.2f} TFLOP/s = "
           f"{flops / (ms * 1e-3) / 78.6e12:.3f} of the FP64 vector peak; HBM {n * (24 * na + 8) / (ms * 1e-3) / 1e9:.1f} GB/s (negligible) -> "
-          f"bound by the per-lane LDS table look-ups + complex products (latency / LDS pipe), not by HBM")
+          f"FP64 VALU issue (scripts/pmc_kernel.sh: issue utilisation 0.79 / 0.90 for Na / CO2, two thirds of the VALU instructions FP64)")
     m = 20000
     hp = pos[:m].cpu().numpy()
     t = time.perf_counter(); ref = O.reciprocal_energies(ef, mol, hp); dt = time.perf_counter() - t

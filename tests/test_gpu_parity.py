@@ -707,6 +707,64 @@ def test_reciprocal_batch_vs_oracle(hip_lib, oracle):
         rec.close()
 
 
+def test_reciprocal_rows_layout_edge_cases(hip_lib, oracle):
+    """The row / segment layout of ceg_recip (round 3): a k-space too large for the LDS copy of its constants (precision 1e-12:
+    the planes stay in global memory), the k-vectors handed over in a shuffled order (regrouped into rows by ceg_recip_create),
+    a 16-atom rigid molecule, and a replaced structure factor -- each against the oracle / against the sorted order."""
+    import ctypes as C
+    from ceg_hip.energy import ReciprocalEwald
+    from ceg_hip.ewald import ewald_context_constants
+    rng = np.random.default_rng(77)
+    fw = ceg.load_framework_RASPA("CIT-7", "BoulfelfelSholl2021")
+    co2 = ceg.load_molecule_RASPA("CO2", "TraPPE", "BoulfelfelSholl2021")
+    base = np.asarray(co2.position, dtype=np.float64).reshape(-1, 3)
+    pos = rng.uniform(-30, 50, (257, 1, 3)) + base[None]
+    for precision in (1e-6, 1e-12):
+        ef = ceg.initialize_ewald(fw, None, precision)
+        nk = len(ef.kfactors)
+        assert (nk > 4000) == (precision < 1e-9)          # 1e-12: > 64 KB of constants
+        rec = ReciprocalEwald(ef)
+        got = rec.energies(co2, pos)
+        ref = oracle.reciprocal_energies(ef, co2, pos)
+        assert np.all(np.abs(got - ref) <= 1e-10 * np.abs(ref) + 1e-11 * np.abs(ref).max()), precision
+        rec.close()
+        # shuffled order through the C ABI
+        perm = rng.permutation(nk)
+        ijk = np.ascontiguousarray(np.asarray(ef.kvec_ijk, dtype=np.int32)[perm])
+        kf = np.ascontiguousarray(np.asarray(ef.kfactors, dtype=np.float64)[perm])
+        sf = np.asarray(ef.StoreRigidChargeFramework)[perm]
+        re_, im_ = np.ascontiguousarray(sf.real), np.ascontiguousarray(sf.imag)
+        ks = np.asarray(ef.kspace.ks, dtype=np.int32)
+        inv = np.ascontiguousarray(np.asarray(ef.invmat, dtype=np.float64).T.reshape(-1))      # column-major
+        h = C.c_void_p()
+        _abi.check(hip_lib, hip_lib.ceg_recip_create(C.byref(h), 0, _abi.i32ptr(ijk.reshape(-1)), _abi.dptr(kf), _abi.dptr(re_),
+                                                     _abi.dptr(im_), nk, _abi.i32ptr(ks), _abi.dptr(inv)))
+        q = np.ascontiguousarray(co2.atomic_charge, dtype=np.float64)
+        enc, static = ewald_context_constants(ef, ((co2,),))
+        out = np.empty(len(pos))
+        _abi.check(hip_lib, hip_lib.ceg_recip_energy(h, _abi.dptr(pos.reshape(-1)), _abi.dptr(q), len(q), len(pos), enc, static, _abi.dptr(out)))
+        assert np.all(np.abs(out - got) <= 1e-12 * np.abs(got).max())
+        # a replaced structure factor (single_contribution_ewald's "rest") and both constants zero
+        sf2 = sf * np.exp(1j * rng.uniform(0, 6.28, nk))
+        _abi.check(hip_lib, hip_lib.ceg_recip_set_structure_factor(h, _abi.dptr(np.ascontiguousarray(sf2.real)), _abi.dptr(np.ascontiguousarray(sf2.imag))))
+        out2 = np.empty(len(pos))
+        _abi.check(hip_lib, hip_lib.ceg_recip_energy(h, _abi.dptr(pos.reshape(-1)), _abi.dptr(q), len(q), len(pos), 0.0, 0.0, _abi.dptr(out2)))
+        frac = np.einsum("ij,naj->nai", np.asarray(ef.invmat), pos.reshape(len(pos), -1, 3))
+        S = (q[None, :, None] * np.exp(2j * np.pi * np.einsum("nai,ki->nak", frac, ijk.astype(np.float64)))).sum(axis=1)     # [n, nk]
+        want = 2.0 * (kf * (np.conj(sf2)[None] * S).real).sum(axis=1) + (kf * np.abs(S) ** 2).sum(axis=1)
+        assert np.all(np.abs(out2 - want) <= 1e-9 * np.abs(want).max())
+        # 16 atoms (the most the kernel holds)
+        big = rng.uniform(-5, 5, (33, 16, 3))
+        q16 = np.ascontiguousarray(rng.uniform(-1, 1, 16))
+        out3 = np.empty(len(big))
+        _abi.check(hip_lib, hip_lib.ceg_recip_energy(h, _abi.dptr(big.reshape(-1)), _abi.dptr(q16), 16, len(big), 0.0, 0.0, _abi.dptr(out3)))
+        frac = np.einsum("ij,naj->nai", np.asarray(ef.invmat), big)
+        S = (q16[None, :, None] * np.exp(2j * np.pi * np.einsum("nai,ki->nak", frac, ijk.astype(np.float64)))).sum(axis=1)
+        want = 2.0 * (kf * (np.conj(sf2)[None] * S).real).sum(axis=1) + (kf * np.abs(S) ** 2).sum(axis=1)
+        assert np.all(np.abs(out3 - want) <= 1e-9 * np.abs(want).max())
+        hip_lib.ceg_recip_destroy(h)
+
+
 def _local_minima(grid, tolerance=1e-2, faces_only=False):
     """CEG.local_minima (basins.jl:40-98): strict minimum over the 26 periodic neighbours (or the 6
     face neighbours), kept when within ``tolerance`` of the global one; sorted like Julia's
