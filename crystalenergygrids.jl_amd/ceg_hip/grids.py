@@ -294,8 +294,9 @@ def create_grids_multi(vdw_files, coulomb_file, framework, forcefield: ForceFiel
     """``create_grid_vdw`` (grids.jl:137-157) for every atom of ``atoms`` and -- with ``coulomb_file`` -- ``create_grid_coulomb``
     (grids.jl:159-185) of one framework in ONE pass: the files are byte-identical in format to the ones the two functions write
     (same header / payload / trailer writer), the payloads come from ``ceg_grids_multi``.  This is the call pattern of
-    setup_RASPA (raspa.jl:497-520) collapsed into one call.  Atoms whose rules are not Lennard-Jones-only cannot share the
-    pass (the library says so): the caller builds those with ``create_grid_vdw``."""
+    setup_RASPA (raspa.jl:497-520) collapsed into one call.  Several atoms share the pass only when each is Lennard-Jones-only against the
+    framework (the library says so otherwise: the caller builds those with ``create_grid_vdw``); a single atom of any rule class
+    shares it with the Coulomb grid."""
     atoms = list(atoms)
     assert len(vdw_files) == len(atoms) and 1 <= len(atoms) <= 4
     cset, num_unitcell = _setup_grid_common(framework, spacing, forcefield.cutoff)

@@ -119,7 +119,8 @@ class MultiGridPlan:
     guest atom and one ``create_grid_coulomb`` (raspa.jl:497-520) -- from one lattice-image list in one pass.
 
     ``probes``: ProbeSystems of the same framework (same positions / kinds / cutoff), one per probe atom, every one
-    Lennard-Jones-only against the kinds present (``_abi.CegError`` with code -5 otherwise: build that probe alone)."""
+    Lennard-Jones-only against the kinds present when there are several (``_abi.CegError`` with code -5 otherwise: build that probe
+    alone); ONE probe may have any rule class and then shares the fused single-probe pass with the Coulomb grid."""
     MAX_PROBES = 4
 
     def __init__(self, cset: GridCoordinatesSetup, probes, coulomb: Optional[ProbeSystem] = None, alpha: float = 0.0,

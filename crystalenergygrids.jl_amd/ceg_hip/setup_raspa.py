@@ -132,16 +132,21 @@ def setup_RASPA(framework, pff, molecule, ffname_molecule: Optional[str] = None,
     # The reference builds the missing grids one after the other (raspa.jl:497-520: one retrieve_or_create_grid for the
     # Coulomb grid, one per distinct atom of the molecule).  Here every grid that has to be CREATED is collected first and
     # built by one multi-probe call -- one lattice-image list, one pass over the framework (grids.create_grids_multi) --;
-    # retrieve_or_create_grid then finds the files and only parses them.  Atoms the multi-probe pass cannot take (rules that
-    # are not Lennard-Jones-only, e.g. a Buckingham cation) and anything the library refuses fall through to the one-by-one path.
+    # retrieve_or_create_grid then finds the files and only parses them.  Lennard-Jones-only atoms go in groups of four; an atom
+    # with another rule class (a Buckingham cation) cannot share accumulating loops with other atoms but still shares its pass
+    # with the Coulomb grid when no Lennard-Jones group takes that; anything the library refuses falls through to the one-by-one path.
+    written = set()                                               # files the multi-probe calls below have just created
     if multi and not isinstance(framework, np.ndarray) and not math.isinf(cutoff) and cutoff == 12.0:
-        missing = [i for i, atom in enumerate(rev_atomdict)
-                   if vdws[i] and forcefield.needsvdwgrid(atom) and forcefield.lj_only_probe(atom, syst_framework)
-                   and (new or not os.path.isfile(vdws[i]))]
+        todo = [i for i, atom in enumerate(rev_atomdict)
+                if vdws[i] and forcefield.needsvdwgrid(atom) and (new or not os.path.isfile(vdws[i]))]
+        missing = [i for i in todo if forcefield.lj_only_probe(rev_atomdict[i], syst_framework)]
+        others = [i for i in todo if i not in missing]
         want_c = bool(needcoulomb and coulomb_grid_path and (new or not os.path.isfile(coulomb_grid_path)))
-        for lo in range(0, len(missing), 4):
-            part = missing[lo:lo + 4]
-            with_c = want_c and lo == 0
+        groups = [missing[lo:lo + 4] for lo in range(0, len(missing), 4)]
+        if want_c and not groups and others:
+            groups = [others[:1]]                                 # one probe of any class + the Coulomb grid: the fused single-probe kernel
+        for n, part in enumerate(groups):
+            with_c = want_c and n == 0
             if len(part) + int(with_c) < 2:
                 continue                                          # a single grid: the ordinary path does it
             for pth in [vdws[i] for i in part] + ([coulomb_grid_path] if with_c else []):
@@ -149,16 +154,16 @@ def setup_RASPA(framework, pff, molecule, ffname_molecule: Optional[str] = None,
             try:
                 create_grids_multi([vdws[i] for i in part], coulomb_grid_path if with_c else None, syst_framework, forcefield,
                                    gridstep, [rev_atomdict[i] for i in part], ewald if with_c else None, ngpus)
+                written.update([vdws[i] for i in part] + ([coulomb_grid_path] if with_c else []))
             except _abi.CegError as exc:
                 if exc.code != -5:                                # CEG_ERR_UNSUPPORTED: one by one instead
                     raise
-        new = False if missing or want_c else new                 # whatever was asked anew has just been written
     if needcoulomb:
         if isinstance(framework, np.ndarray):
             coulomb = EnergyGrid.trivial(True)
         else:
             coulomb = retrieve_or_create_grid(coulomb_grid_path, syst_framework, forcefield, gridstep, ewald,
-                                              mat, new, cutoff, ngpus)
+                                              mat, new and coulomb_grid_path not in written, cutoff, ngpus)
     else:
         coulomb = EnergyGrid.trivial(True)
 
@@ -167,7 +172,7 @@ def setup_RASPA(framework, pff, molecule, ffname_molecule: Optional[str] = None,
         if isinstance(framework, np.ndarray):
             grids[i] = EnergyGrid.trivial(True)
         else:
-            grids[i] = retrieve_or_create_grid(vdws[i], syst_framework, forcefield, gridstep, atom, mat, new,
-                                               cutoff, ngpus)
+            grids[i] = retrieve_or_create_grid(vdws[i], syst_framework, forcefield, gridstep, atom, mat,
+                                               new and vdws[i] not in written, cutoff, ngpus)
     charges = [float(q) for q in syst_mol.atomic_charge]
     return CrystalEnergySetup(syst_framework, syst_mol, coulomb, charges, grids, atomsidx, ewald, forcefield, block)

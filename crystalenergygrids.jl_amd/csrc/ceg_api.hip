@@ -851,10 +851,12 @@ static int create_impl(ceg_plan_t** plan, int32_t device,
             for (int q = 0; q < nprobes; ++q) {
                 if (q > 0)
                     if (int rc = convert_rules(p, mrules[q], moffset[q], nkinds)) { delete p; return rc; }
-                if (p->vdwk != 1 || p->r_exact2 != CEG_R_EXACT2) {
+                // several probes share accumulating loops written for Lennard-Jones; ONE probe of any rule class (a Buckingham
+                // cation) runs the single-probe kernels and still shares its pass with the Coulomb grid
+                if (nprobes > 1 && (p->vdwk != 1 || p->r_exact2 != CEG_R_EXACT2)) {
                     delete p;
-                    return fail(CEG_ERR_UNSUPPORTED, "multi-probe plans take Lennard-Jones-only probes (probe %d has another rule class "
-                                                     "against a framework kind that is present): build that grid with its own plan", q);
+                    return fail(CEG_ERR_UNSUPPORTED, "multi-probe plans of several probes take Lennard-Jones-only probes (probe %d has another "
+                                                     "rule class against a framework kind that is present): build that grid with a plan of its own", q);
                 }
                 ceg_plan::ProbeTab& t = p->probes[q];
                 t.rules = p->h_rules; t.offset = p->h_offset; t.fast = p->h_fast;
@@ -1181,7 +1183,7 @@ extern "C" int ceg_plan_build_multi(ceg_plan_t* p, double lambda_vdw, double thr
         Output o = base;
         o.vdw = q >= 0 ? d_out_vdw[q] : nullptr;
         o.coulomb = mode != MODE_VDW ? d_out_coulomb : nullptr;
-        return launch_culled(mode, q >= 0 ? p->probes[q].d_pc : p->d_pc, p->g, 1, ewk, o, Points{nullptr, 0}, st);
+        return launch_culled(mode, q >= 0 ? p->probes[q].d_pc : p->d_pc, p->g, p->nprobes == 1 ? p->vdwk : 1, ewk, o, Points{nullptr, 0}, st);
     };
     auto multi = [&](int mode, const int* idx, int np) {
         Output o = base;
@@ -1194,7 +1196,7 @@ extern "C" int ceg_plan_build_multi(ceg_plan_t* p, double lambda_vdw, double thr
         int fused_np = CEG_MAX_PROBES_FUSED;          // probes that share the Coulomb launch (CEG_HIP_MULTI_FUSED_NP = 0 | 1 | 2: measurement aid)
         if (const char* env = std::getenv("CEG_HIP_MULTI_FUSED_NP")) fused_np = std::max(0, std::min(CEG_MAX_PROBES_FUSED, atoi(env)));
         fused_np = std::min<int>(fused_np, (int)req.size());
-        if (!p->ew2) fused_np = 0;                    // the fused variants are built on the r^2-indexed tables
+        if (!p->ew2 && p->nprobes > 1) fused_np = 0;  // the fused multi-probe variants are built on the r^2-indexed tables
         if (fused_np >= 2) e = multi(MODE_FUSED, &req[0], 2);
         else if (fused_np == 1) e = single(MODE_FUSED, req[0]);
         else e = single(MODE_COULOMB, -1);

@@ -236,7 +236,7 @@ end
 """
     create_grids_multi(vdw_files, coulomb_file, framework, forcefield, spacing, atoms, _ewald=nothing)
 
-`create_grid_vdw` (src/grids.jl:137-157) for every atom of `atoms` (1 to 4, Lennard-Jones-only against the framework) and, unless
+`create_grid_vdw` (src/grids.jl:137-157) for every atom of `atoms` (2 to 4 Lennard-Jones-only ones, or 1 of any rule class) and, unless
 `coulomb_file === nothing`, `create_grid_coulomb` (:159-185) in one GPU pass; the files are written by the reference's own lines.
 """
 function create_grids_multi(vdw_files, coulomb_file, framework::AbstractSystem{3}, forcefield::ForceField, spacing::TÅ, atoms::Vector{Symbol}, _ewald=nothing)
@@ -272,8 +272,8 @@ end
 
 Call with the arguments of `setup_RASPA` (src/raspa.jl:472-531) right before it: every grid that `setup_RASPA` would have to
 create -- same paths (`grid_locations`, :403-419), same conditions (`retrieve_or_create_grid`, :420-439) -- is created here by
-`create_grids_multi`, four probes at a time; `setup_RASPA` then only retrieves.  Atoms that are not Lennard-Jones-only
-(a Buckingham cation) are left to `create_grid_vdw`.
+`create_grids_multi`, four probes at a time; `setup_RASPA` then only retrieves.  An atom that is not Lennard-Jones-only
+(a Buckingham cation) shares its pass with the Coulomb grid when no Lennard-Jones group does, and is left to `create_grid_vdw` otherwise.
 """
 function prebuild_grids!(framework, pff, syst_mol; gridstep=0.15u"Å", supercell=nothing, new=false, cutoff=12.0u"Å")
     (framework isa AbstractMatrix || isinf(cutoff) || cutoff != 12.0u"Å") && return nothing
@@ -284,12 +284,15 @@ function prebuild_grids!(framework, pff, syst_mol; gridstep=0.15u"Å", supercell
     coulomb_grid_path, vdws = CEG.grid_locations(framework, pff, forcefield, atoms, gridstep, supercell)
     needcoulomb = any(!iszero(syst_mol[i,:atomic_charge])::Bool for i in 1:length(syst_mol))
     kinds = ProbeSystem(syst_framework, forcefield).atomkinds
-    todo = [i for (i, atom) in enumerate(atoms) if CEG.needsvdwgrid(forcefield, atom) && (new || !isfile(vdws[i])) &&
-            lj_only(forcefield, forcefield.sdict[Symbol(CEG.get_atom_name(atom))], kinds)]   # sdict keys as in src/probes.jl:23,59
+    todo = [i for (i, atom) in enumerate(atoms) if CEG.needsvdwgrid(forcefield, atom) && (new || !isfile(vdws[i]))]
+    islj(i) = lj_only(forcefield, forcefield.sdict[Symbol(CEG.get_atom_name(atoms[i]))], kinds)   # sdict keys as in src/probes.jl:23,59
+    lj = filter(islj, todo)
     want_c = needcoulomb && (new || !isfile(coulomb_grid_path))
-    for lo in 1:4:max(length(todo), 1)
-        part = todo[lo:min(lo+3, length(todo))]
-        with_c = want_c && lo == 1
+    groups = [lj[lo:min(lo+3, length(lj))] for lo in 1:4:length(lj)]
+    # one atom of another rule class (a Buckingham cation) still shares its pass with the Coulomb grid (fused single-probe kernel)
+    isempty(groups) && want_c && any(!islj, todo) && (groups = [[first(filter(!islj, todo))]])
+    for (n, part) in enumerate(groups)
+        with_c = want_c && n == 1
         length(part) + with_c < 2 && continue
         foreach(p -> mkpath(dirname(p)), vdws[part]); with_c && mkpath(dirname(coulomb_grid_path))
         create_grids_multi(vdws[part], with_c ? coulomb_grid_path : nothing, syst_framework, forcefield, gridstep, atoms[part],

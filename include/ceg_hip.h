@@ -261,9 +261,11 @@ CEG_API int ceg_plan_build_fused(ceg_plan_t* plan,
  *
  *   nprobes       1 .. 4 (CEG_MAX_PROBES)
  *   rules[q], rule_offset[q]   the flattened column ff.interactions[:, probe_q] as for ceg_plan_create (same nkinds for all).
- *                 Every probe must be Lennard-Jones-only against the framework kinds that are present (at most one LJ rule per
- *                 kind; NoInteraction / CoulombEwaldDirect count as none) -- CEG_ERR_UNSUPPORTED otherwise: a Buckingham or
- *                 hard-sphere probe (a cation) gets its own ceg_plan_create plan.  charge may be NULL (VdW grids only).
+ *                 With nprobes > 1 every probe must be Lennard-Jones-only against the framework kinds that are present (at most
+ *                 one LJ rule per kind; NoInteraction / CoulombEwaldDirect count as none) -- CEG_ERR_UNSUPPORTED otherwise.  A
+ *                 plan of ONE probe takes any rule class ceg_plan_create takes (a Buckingham / hard-sphere cation): its VdW
+ *                 grid and the Coulomb grid then come out of one pass of the fused single-probe kernel.  charge may be NULL
+ *                 (VdW grids only).
  *   d_out_vdw     [nprobes] device pointers, NULL entries are skipped; d_out_coulomb may be NULL.  Layout, channel_stride,
  *                 i_begin / i_end / i_origin, lambda / threshold and the asynchronous stream semantics as ceg_plan_build_*.
  *
@@ -283,7 +285,7 @@ CEG_API int ceg_plan_create_multi(ceg_plan_t** plan, int32_t device,
 CEG_API int ceg_plan_num_probes(const ceg_plan_t* plan);    /* 0 for an ordinary plan */
 /* One-shot form (what the Julia binding calls once per setup_RASPA): host arrays out, grids_vdw [nprobes] (NULL entries skipped),
  * grid_coulomb may be NULL; the x-slabs are spread over `ngpus` devices and every device pipelines compute / D2H / host copy as
- * ceg_grid_vdw does.  A probe that is not Lennard-Jones-only -> CEG_ERR_UNSUPPORTED and nothing is written. */
+ * ceg_grid_vdw does.  Several probes of which one is not Lennard-Jones-only -> CEG_ERR_UNSUPPORTED and nothing is written. */
 CEG_API int ceg_grids_multi(const double* pos, const int64_t* atomkind, const double* charge, int64_t natoms,
                     const double mat[9], const double invmat[9], int32_t ortho, double safemin2, double cutoff2,
                     int32_t nprobes, const ceg_rule_t* const* rules, const int32_t* const* rule_offset, int32_t nkinds, double alpha,

@@ -67,3 +67,5 @@ case("CHA fixture @ 0.15 A", ("C_co2", "O_co2"), lambda a: W.fixture_workload("C
 case("roofline workload", ("C_co2", "O_co2"), lambda a: W.roofline_workload(a, 255))
 case("roofline workload", ("C_co2", "O_co2", "N_n2"), lambda a: W.roofline_workload(a, 255))
 case("roofline workload", ("C_co2", "O_co2", "N_n2", "Ar"), lambda a: W.roofline_workload(a, 255))
+# one probe of another rule class (Na: Buckingham + hard sphere): a one-probe plan shares the fused single-probe pass with the Coulomb grid
+case("roofline workload", ("Na",), lambda a: W.roofline_workload(a, 255))

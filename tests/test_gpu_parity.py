@@ -1246,11 +1246,38 @@ def test_multi_probe_plan_rejects_non_lj_probes(hip_lib):
     assert ei.value.code == -5 and "Lennard-Jones" in str(ei.value)
 
 
+def test_one_probe_of_any_rule_class_shares_the_pass_with_the_coulomb_grid(hip_lib, oracle):
+    """A multi-probe call with ONE probe takes any rule class (Na: Buckingham + hard sphere): its VdW grid and the Coulomb grid
+    come out of the fused single-probe kernel -- bit-identical to ceg_plan_build_fused of an ordinary plan, and the oracle's values."""
+    w = W.fixture_workload("CHA_1.4_3b4eeb96", "Na", 0.7)
+    (gv,), gc = G.build_multi_arrays([w.probe_vdw], w.probe_coulomb, w.alpha, w.cset)
+    lv, tv = G.vdw_scaling()
+    lc, tc = G.coulomb_scaling()
+    rv, _ = oracle.grid_vdw(w.probe_vdw, w.cset, lv, tv)
+    rc, _ = oracle.grid_coulomb(w.probe_coulomb, w.alpha, w.cset, lc, tc)
+    compare_grids(gv, rv, "one-probe multi call / Na VdW vs oracle", floor0=0.0)
+    compare_grids(gc, rc, "one-probe multi call / Coulomb vs oracle", floor0=0.0)
+    import torch
+    nx, ny, nz = w.cset.npoints
+    plan = GridPlan(w.cset, w.probe_vdw, w.probe_coulomb, w.alpha)
+    dv = torch.empty((8, nx, ny, nz), dtype=torch.float32, device="cuda")
+    dc = torch.empty_like(dv)
+    plan.build_fused(dv.data_ptr(), dc.data_ptr(), nx * ny * nz, 0, nx)
+    torch.cuda.synchronize()
+    plan.close()
+    assert np.array_equal(dv.cpu().numpy().view(np.uint32), gv.view(np.uint32))
+    assert np.array_equal(dc.cpu().numpy().view(np.uint32), gc.view(np.uint32))
+    # a VdW-only one-probe call as well
+    (gv2,), none = G.build_multi_arrays([w.probe_vdw], None, 0.0, w.cset)
+    assert none is None
+    compare_grids(gv2, rv, "one-probe multi call, VdW only / Na vs oracle", floor0=0.0)
+
+
 def test_setup_raspa_builds_missing_grids_in_one_pass(hip_lib, oracle, tmp_path):
     """setup_RASPA for CO2 in CIT-7 (raspa.jl:472-531): the three grids it needs -- C_co2, O_co2, Coulomb -- are created by ONE
     multi-probe call (grids.create_grids_multi) instead of three builds; the files have the reference's format (parse_grid reads
     them), hold the oracle's values, and the resulting CrystalEnergySetup gives the same energy_point as the one-by-one path.
-    Na (Buckingham + hard sphere) cannot share the pass and still gets its grid through create_grid_vdw."""
+    Na (Buckingham + hard sphere) shares ONE pass with the Coulomb grid (one-probe call)."""
     import shutil
     golden = Path(__file__).parent / "golden" / "raspa"
     try:
@@ -1279,9 +1306,21 @@ def test_setup_raspa_builds_missing_grids_in_one_pass(hip_lib, oracle, tmp_path)
         pos = np.array([[3.1, 4.2, 5.3], [3.1, 4.2, 6.46], [3.1, 4.2, 4.14]])
         ea, eb = ceg.energy_point(a, pos), ceg.energy_point(b, pos)
         assert ea[0] == pytest.approx(eb[0], rel=1e-6) and ea[1] == pytest.approx(eb[1], rel=1e-6)
-        # a cation: not Lennard-Jones-only -> one by one, same API
-        na = ceg.setup_RASPA("CIT-7", "BoulfelfelSholl2021", "Na", gridstep=0.6)
+        # a cation: not Lennard-Jones-only -> its VdW grid and the Coulomb grid still share ONE pass (fused single-probe kernel);
+        # the same values as the one-by-one path
+        calls = []
+        real = G.create_grids_multi
+        import ceg_hip.setup_raspa as SR
+        SR.create_grids_multi = lambda *a, **k: (calls.append(a[5]), real(*a, **k))[1]
+        try:
+            na = ceg.setup_RASPA("CIT-7", "BoulfelfelSholl2021", "Na", gridstep=0.6, new=True)
+        finally:
+            SR.create_grids_multi = real
+        assert len(calls) == 1 and len(calls[0]) == 1, calls
+        na1 = ceg.setup_RASPA("CIT-7", "BoulfelfelSholl2021", "Na", gridstep=0.6, new=True, multi=False)
         assert na.grids[0].grid.shape[0] == 8 and np.isfinite(ceg.energy_point(na, np.array([[3.1, 4.2, 5.3]]))[0])
+        compare_grids(np.ascontiguousarray(na.grids[0].grid), np.ascontiguousarray(na1.grids[0].grid), "Na VdW: shared pass vs one by one", sentinel=1.9e7 * ceg.GRID_TO_KELVIN, floor0=0.0)
+        compare_grids(np.ascontiguousarray(na.coulomb.grid), np.ascontiguousarray(na1.coulomb.grid), "Na Coulomb: shared pass vs one by one", sentinel=1.9e7 * ceg.GRID_TO_KELVIN, floor0=0.0)
     finally:
         ceg.setdir_RASPA(golden)
 
