@@ -80,6 +80,13 @@ while done < n_cfg:
             if cg is not None:
                 compare_grids(cg, refc, what + "/multi coulomb")
             stats["multi"] = stats.get("multi", 0) + 1
+        if rng.random() < 0.5:
+            # round 3: ONE probe of whatever rule class this configuration has + the Coulomb grid through the one-probe multi call
+            (v1,), c1 = G.build_multi_arrays([pv], pc, alpha, cset)
+            lam, thr = G.vdw_scaling()
+            compare_grids(v1, O.grid_vdw(pv, cset, lam, thr)[0], what + "/one-probe multi vdw")
+            compare_grids(c1, refc, what + "/one-probe multi coulomb")
+            stats["oneprobe"] = stats.get("oneprobe", 0) + 1
     except AssertionError as e:
         fails += 1
         print("FAIL", what, "::", str(e)[:300], flush=True)
