@@ -126,6 +126,7 @@ PROTOTYPES = {
         C.POINTER(C.c_void_p), C.c_int32, c_int32_p, c_double_p, c_double_p, c_double_p, C.c_int64,
         c_int32_p, c_double_p]),
     "ceg_recip_destroy": (C.c_int, [C.c_void_p]),
+    "ceg_recip_layout": (C.c_int, [c_int32_p, C.c_int64, c_int32_p, c_int32_p, c_int32_p, C.c_void_p, C.c_void_p]),
     "ceg_recip_energy": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.c_int32, C.c_int64, C.c_double, C.c_double, c_double_p]),
     "ceg_block_from_grid": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, c_int32_p, C.c_double, C.c_void_p]),
     "ceg_block_spheres": (C.c_int, [C.c_int32, c_int32_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int32, C.c_double,

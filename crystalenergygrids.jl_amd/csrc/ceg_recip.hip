@@ -268,6 +268,43 @@ int upload_constants(ceg_recip* h, const double* sf_re, const double* sf_im)
 
 }  // namespace
 
+// the layout choice of ceg_recip_create, host side only
+static Layout choose_layout(const int32_t* kvec_ijk, int64_t nk, const int32_t ks[3])
+{
+    Layout best;
+    if (nk > 0) {
+        best = build_layout(kvec_ijk, nk, ks, SEG);
+        for (int seg = SEG - 1; seg >= 3; --seg) {                 // shorter segments can fill the last round better
+            Layout l = build_layout(kvec_ijk, nk, ks, seg);
+            if (layout_cost(l) < layout_cost(best)) best = std::move(l);
+        }
+    }
+    return best;
+}
+
+static int check_kspace(const int32_t* kvec_ijk, int64_t nk, const int32_t ks[3])
+{
+    if (ks[0] < 0 || ks[1] < 0 || ks[2] < 0 || ks[0] + 1 + 2 * ks[1] + 1 + 2 * ks[2] + 1 > MAX_TAB)
+        return rerr(CEG_ERR_UNSUPPORTED, "k-space box too large for the LDS tables");
+    for (int64_t q = 0; q < nk; ++q)
+        if (kvec_ijk[3 * q] < 0 || kvec_ijk[3 * q] > ks[0] || abs(kvec_ijk[3 * q + 1]) > ks[1] || abs(kvec_ijk[3 * q + 2]) > ks[2])
+            return rerr(CEG_ERR_INVALID, "k-vector outside the (kx, ky, kz) box");
+    return CEG_OK;
+}
+
+extern "C" int ceg_recip_layout(const int32_t* kvec_ijk, int64_t nk, const int32_t ks[3], int32_t* nrounds, int32_t* nslots,
+                                int64_t* slot_of, int32_t* desc)
+{
+    if (!ks || nk < 0 || (nk > 0 && !kvec_ijk) || !nrounds || !nslots) return rerr(CEG_ERR_INVALID, "bad argument");
+    if (int rc = check_kspace(kvec_ijk, nk, ks)) return rc;
+    const Layout l = choose_layout(kvec_ijk, nk, ks);
+    *nrounds = l.nrounds;
+    *nslots = l.ns;
+    if (slot_of) std::copy(l.slot_of.begin(), l.slot_of.end(), slot_of);
+    if (desc) std::copy(l.desc.begin(), l.desc.end(), desc);
+    return CEG_OK;
+}
+
 extern "C" int ceg_recip_create(ceg_recip_t** handle, int32_t device, const int32_t* kvec_ijk, const double* kfactors,
                                 const double* sf_re, const double* sf_im, int64_t nk, const int32_t ks[3],
                                 const double invmat[9])
@@ -275,11 +312,7 @@ extern "C" int ceg_recip_create(ceg_recip_t** handle, int32_t device, const int3
     if (!handle || !ks || !invmat || nk < 0 || (nk > 0 && (!kvec_ijk || !kfactors || !sf_re || !sf_im)))
         return rerr(CEG_ERR_INVALID, "bad argument");
     *handle = nullptr;
-    if (ks[0] < 0 || ks[1] < 0 || ks[2] < 0 || ks[0] + 1 + 2 * ks[1] + 1 + 2 * ks[2] + 1 > MAX_TAB)
-        return rerr(CEG_ERR_UNSUPPORTED, "k-space box too large for the LDS tables");
-    for (int64_t q = 0; q < nk; ++q)
-        if (kvec_ijk[3 * q] < 0 || kvec_ijk[3 * q] > ks[0] || abs(kvec_ijk[3 * q + 1]) > ks[1] || abs(kvec_ijk[3 * q + 2]) > ks[2])
-            return rerr(CEG_ERR_INVALID, "k-vector outside the (kx, ky, kz) box");
+    if (int rc = check_kspace(kvec_ijk, nk, ks)) return rc;
     if (ceg_device_count() <= 0) return rerr(CEG_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
     if (device < 0 || device >= ceg_device_count()) return rerr(CEG_ERR_NO_DEVICE, "device not present");
     int prev = -1;
@@ -290,14 +323,7 @@ extern "C" int ceg_recip_create(ceg_recip_t** handle, int32_t device, const int3
     h->nk = nk;
     for (int a = 0; a < 3; ++a) h->ks[a] = ks[a];
     for (int a = 0; a < 9; ++a) h->invmat[a] = invmat[a];
-    Layout best;
-    if (nk > 0) {
-        best = build_layout(kvec_ijk, nk, ks, SEG);
-        for (int seg = SEG - 1; seg >= 3; --seg) {                 // shorter segments can fill the last round better
-            Layout l = build_layout(kvec_ijk, nk, ks, seg);
-            if (layout_cost(l) < layout_cost(best)) best = std::move(l);
-        }
-    }
+    Layout best = choose_layout(kvec_ijk, nk, ks);
     h->nrounds = best.nrounds;
     h->ns = best.ns;
     h->slot_of = std::move(best.slot_of);

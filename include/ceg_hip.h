@@ -384,6 +384,13 @@ CEG_API int ceg_recip_create(ceg_recip_t** handle, int32_t device, const int32_t
                              const double* kfactors, const double* sf_re, const double* sf_im, int64_t nk,
                              const int32_t ks[3], const double invmat[9]);
 CEG_API int ceg_recip_destroy(ceg_recip_t* handle);
+/* Host side only (works without a device): the row / segment layout ceg_recip_create gives these k-vectors.  The kernel walks
+ * them as rows (j, k) x i = i0..i1 -- the structure of the reference's kspace.kindices (src/ewald.jl:213-236) --, cut into segments
+ * dealt to the 64 lanes in `nrounds` rounds; round r runs to its longest segment, `nslots` = the sum of those lengths.
+ *  slot_of [nk]            (may be NULL) slot * 64 + lane of every k-vector
+ *  desc    [nrounds * 64]  (may be NULL; size it from a first call) i0 | (j + ky) << 9 | (k + kz) << 18 | round length << 27 */
+CEG_API int ceg_recip_layout(const int32_t* kvec_ijk, int64_t nk, const int32_t ks[3], int32_t* nrounds, int32_t* nslots,
+                             int64_t* slot_of, int32_t* desc);
 /* positions [n][natoms][3] A, charges [natoms] e, out [n] K -- host memory, synchronous.
  * energy_net_charges / static_contribution: the two EwaldContext constants (src/ewald.jl:497-544). */
 CEG_API int ceg_recip_energy(ceg_recip_t* handle, const double* positions, const double* charges,

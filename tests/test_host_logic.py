@@ -123,6 +123,53 @@ def test_consumer_entry_points_reject_bad_arguments_and_have_no_cpu_path():
 
 
 # ------------------------------------------------------------------ geometry
+def test_reciprocal_row_layout_host_side():
+    """ceg_recip_layout (host only): the k-vectors of the CHA and CIT-7 fixtures regrouped into rows (j, k) x i, cut into segments and
+    dealt to 64 lanes.  Every k-vector gets its own slot; the k-vectors of a segment sit in consecutive slots of one lane with
+    consecutive i; a round is as long as its longest segment; few slots are padding; a shuffled list gives the same slot counts."""
+    import ctypes as C
+    lib = _abi.load_library()
+    rng = np.random.default_rng(3)
+    for name, sc, min_eff in (("CHA_1.4_3b4eeb96", (1, 1, 1), 0.85), ("CIT-7", None, 0.85)):
+        fw = ceg.load_framework_RASPA(name, "BoulfelfelSholl2021")
+        ef = ceg.initialize_ewald(fw, sc)
+        ks = np.asarray(ef.kspace.ks, dtype=np.int32)
+        for shuffle in (False, True):
+            ijk = np.asarray(ef.kvec_ijk, dtype=np.int32)
+            if shuffle:
+                ijk = ijk[rng.permutation(len(ijk))]
+            ijk = np.ascontiguousarray(ijk)
+            nk = len(ijk)
+            nr, ns = C.c_int32(), C.c_int32()
+            assert lib.ceg_recip_layout(_abi.i32ptr(ijk.reshape(-1)), nk, _abi.i32ptr(ks), C.byref(nr), C.byref(ns), None, None) == 0
+            slot = np.empty(nk, dtype=np.int64)
+            desc = np.empty(nr.value * 64, dtype=np.int32)
+            assert lib.ceg_recip_layout(_abi.i32ptr(ijk.reshape(-1)), nk, _abi.i32ptr(ks), C.byref(nr), C.byref(ns),
+                                        slot.ctypes.data, desc.ctypes.data) == 0
+            assert len(np.unique(slot)) == nk and slot.min() >= 0 and slot.max() < ns.value * 64
+            assert nk / (ns.value * 64) >= min_eff, (name, nk, ns.value)
+            L = desc >> 27
+            assert np.all(L.reshape(nr.value, 64) == L.reshape(nr.value, 64)[:, :1]) and L.reshape(nr.value, 64)[:, 0].sum() == ns.value
+            assert np.all(np.diff(L.reshape(nr.value, 64)[:, 0]) <= 0)          # longest segments first
+            first = np.concatenate([[0], np.cumsum(L.reshape(nr.value, 64)[:, 0])])
+            # every k-vector: its (round, lane) descriptor names its row, and its slot is the segment start + (i - i0)
+            s_idx, lane = slot // 64, slot % 64
+            rnd = np.searchsorted(first, s_idx, side="right") - 1
+            d = desc.reshape(nr.value, 64)[rnd, lane]
+            i0, jj, kk = d & 0x1ff, (d >> 9) & 0x1ff, (d >> 18) & 0x1ff
+            assert np.array_equal(jj - ks[1], ijk[:, 1]) and np.array_equal(kk - ks[2], ijk[:, 2])
+            assert np.array_equal(s_idx - first[rnd], ijk[:, 0] - i0) and np.all(ijk[:, 0] >= i0)
+            if not shuffle:
+                counts = (nr.value, ns.value)
+            else:
+                assert (nr.value, ns.value) == counts
+    # validation happens on the host as well
+    bad = np.array([[3, 0, 0]], dtype=np.int32)
+    nr, ns = C.c_int32(), C.c_int32()
+    assert lib.ceg_recip_layout(_abi.i32ptr(bad.reshape(-1)), 1, _abi.i32ptr(np.array([2, 2, 2], dtype=np.int32)), C.byref(nr), C.byref(ns), None, None) == -1
+    assert lib.ceg_recip_layout(None, 0, _abi.i32ptr(np.array([2, 2, 2], dtype=np.int32)), C.byref(nr), C.byref(ns), None, None) == 0 and nr.value == 0
+
+
 def test_grid_coordinates_setup_cha():
     """coordinates.jl:32-41 on the CHA fixture (numbers of SURVEY appendix A)."""
     fw = ceg.load_framework_RASPA("CHA_1.4_3b4eeb96", FFNAME)
