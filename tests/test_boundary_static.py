@@ -195,3 +195,26 @@ def test_julia_shim_is_structurally_sound():
             else:
                 opens += 1
     assert opens == ends and opens > 30, (opens, ends)
+
+
+def test_header_is_c99_and_a_plain_c_caller_links(tmp_path):
+    """The boundary is a C ABI: include/ceg_hip.h compiles as strict C99, and examples/grid_vdw.c -- a caller with no C++, torch
+    or HIP on its side -- compiles and links against libceg_hip.so.  Without a device it must refuse to produce numbers."""
+    import shutil, subprocess
+    from ceg_hip import _abi
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        import pytest
+        pytest.skip("no gcc")
+    root = Path(__file__).resolve().parent.parent
+    hdr = tmp_path / "hdr.c"
+    hdr.write_text('#include "ceg_hip.h"\nint main(void) { return 0; }\n')
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", str(root / "include"), "-fsyntax-only", str(hdr)], check=True)
+    libdir = root / "crystalenergygrids.jl_amd" / "csrc"
+    exe = tmp_path / "grid_vdw"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", str(root / "include"), str(root / "examples" / "grid_vdw.c"),
+                    "-o", str(exe), "-L", str(libdir), "-lceg_hip", f"-Wl,-rpath,{libdir}"], check=True)
+    lib = _abi.load_library()
+    if lib.ceg_device_count() == 0:
+        r = subprocess.run([str(exe)], capture_output=True, text=True)
+        assert r.returncode == 3 and "no CPU path" in r.stderr

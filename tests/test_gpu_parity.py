@@ -1325,6 +1325,46 @@ def test_setup_raspa_builds_missing_grids_in_one_pass(hip_lib, oracle, tmp_path)
         ceg.setdir_RASPA(golden)
 
 
+def test_plain_c_caller(hip_lib, tmp_path):
+    """examples/grid_vdw.c (gcc -std=c99, linked against libceg_hip.so) builds a VdW grid through ceg_grid_vdw: the file it writes
+    holds, in channel 0, the minimum-image Lennard-Jones sum of its 32 atoms (numpy, float64) wherever the value is not clamped."""
+    import shutil, subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    root = Path(__file__).resolve().parent.parent
+    libdir = root / "crystalenergygrids.jl_amd" / "csrc"
+    exe, out = tmp_path / "grid_vdw", tmp_path / "out.f32"
+    subprocess.run([gcc, "-std=c99", "-I", str(root / "include"), str(root / "examples" / "grid_vdw.c"), "-o", str(exe),
+                    "-L", str(libdir), "-lceg_hip", f"-Wl,-rpath,{libdir}"], check=True)
+    r = subprocess.run([str(exe), str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    N, a = 23, 26.0
+    grid = np.fromfile(out, dtype=np.float32).reshape(8, N + 1, N + 1, N + 1)
+    basis = np.array([[0.05, 0.05, 0.05], [0.55, 0.55, 0.05], [0.55, 0.05, 0.55], [0.05, 0.55, 0.55]])
+    pos, eps, sig = [], [], []
+    for i in range(2):
+        for j in range(2):
+            for k in range(2):
+                for b in range(4):
+                    pos.append((np.array([i, j, k]) + basis[b]) * a / 2)
+                    eps.append(120.0 if b % 2 == 0 else 80.0)
+                    sig.append(3.4 if b % 2 == 0 else 3.0)
+    pos, eps, sig = np.array(pos), np.array(eps), np.array(sig)
+    ax = np.arange(N + 1) * a / N
+    P = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), axis=-1).reshape(-1, 3)
+    d = P[:, None, :] - pos[None, :, :]
+    d -= a * np.round(d / a)
+    r2 = (d * d).sum(-1)
+    x6 = (sig[None] ** 2 / r2) ** 3
+    e = np.where(r2 < 144.0, 4.0 * eps[None] * x6 * (x6 - 1.0), 0.0).sum(1)
+    lam = 1.0 / (0.01 * 120.27221933)
+    want = (e * lam).reshape(N + 1, N + 1, N + 1)
+    ok = np.abs(want) < 1e5
+    assert ok.sum() > 4000
+    assert np.allclose(grid[0][ok], want[ok], rtol=1e-6, atol=1e-6 * np.abs(want[ok]).max())
+
+
 def test_image_cache_is_shared_and_changes_nothing(hip_lib, monkeypatch):
     """The lattice-image list of a plan is cached on the device and shared between plans that need the same one (the K + 1
     one-shot calls of a setup_RASPA; ceg_image_cache_stats): same framework + same per-atom flags -> a hit, another probe whose
