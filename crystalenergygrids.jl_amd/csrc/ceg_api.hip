@@ -657,7 +657,7 @@ bool build_ew2_table_uncached(double alpha, double r_exact2, double cutoff2, std
     auto B0 = [&](long double s) { const long double r = sqrtl(s); return which == 0 ? erfcl(a * r) / r : (long double)bkA * expl(-a * r); };
     auto Cf = [&](long double s) { return ka * expl(-a * a * s); };
     const int nf = which == 0 ? 2 : 1, stride = which == 0 ? CEG_EW2_STRIDE : CEG_BK2_STRIDE;
-    const int ND = which == 0 ? 7 : CEG_BK2_STRIDE;        // coefficients per polynomial: degree 6 (Ewald pair, 14 doubles) / degree 7
+    const int ND = which == 0 ? 7 : CEG_BK2_ND;            // coefficients per polynomial: degree 6 (Ewald pair, 14 doubles) / degree 7
     const long double PI = 3.14159265358979323846264338327950288L;
     long double node[8];
     for (int k = 0; k < ND; ++k) node[k] = cosl(PI * (k + 0.5L) / (long double)ND);       // u in [-1, 1]

@@ -161,7 +161,11 @@ constexpr int CEG_EW2_NI_MAX = 176;                            // cutoff 12 A fr
 // (3e-13 of the pair energy: up to 77 ULP in stored values where the attractive and repulsive sums of a channel cancel);
 // degree 7 on 32 per octave reaches 2e-15 (fit in long double, checked per plan against CEG_BK2_TOL) with 2/3 of the LDS
 // footprint and half the distinct records per wave.
-constexpr int CEG_BK2_STRIDE = 8;
+constexpr int CEG_BK2_ND = 8;                                  // coefficients per record (degree 7)
+// doubles per record: 80 B, not 64 -- the lanes of a wave read 10-40 CONSECUTIVE intervals, and with a 64-byte stride the records
+// start on only 4 distinct bank groups (16 k mod 64 dwords): every ds_read_b128 of the table was a 4-way conflict
+// (SQ_LDS_BANK_CONFLICT 3.3 x the LDS instruction cycles of the Na kernels); 20 k mod 64 visits all 16 groups
+constexpr int CEG_BK2_STRIDE = 10;
 constexpr int CEG_BK2_LOGM = CEG_EW2_LOGM;
 constexpr int CEG_BK2_SHIFT = 20 - CEG_BK2_LOGM;
 constexpr int CEG_BK2_NI_MAX = CEG_EW2_NI_MAX;
