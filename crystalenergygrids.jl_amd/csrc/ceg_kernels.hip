@@ -874,9 +874,10 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK, NP), culled_waves(M
             //    Anything else is recorded in a per-lane bit mask and redone after the loop with
             //    the reference's literal arithmetic (slow_pairs).
             unsigned long long slow = 0ull;     // wave-uniform: candidates with at least one odd lane
-            auto pair_body = [&](const int q, const Quad A, auto with_vdw_tag, auto interior_tag) __attribute__((always_inline)) {
+            auto pair_body = [&](const int q, auto with_vdw_tag, auto interior_tag) __attribute__((always_inline)) {
                 constexpr bool WITH_VDW = decltype(with_vdw_tag)::value;
                 constexpr bool INTERIOR = decltype(interior_tag)::value;
+                const Quad A = s_rec[q].xyzq;
                 double dx = px - A.x, dy = py - A.y, dz = pz - A.z;
                 const double r2 = dx * dx + dy * dy + dz * dz;
                 // regular: R_EXACT2 <= r2 < min(cutoff2 - band, stale limit), image provably the
@@ -1084,24 +1085,13 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK, NP), culled_waves(M
             if (nkeep == 12345) { av.v += s_rec[0].xyzq.x; ac.v += s_rec[1].xyzq.y; }
             continue;
 #endif
-            // the position of candidate q + 1 is read while candidate q is worked on (slot 64 of the last wave's slice does not exist:
-            // the read then lands in the next shared array and its value is never used)
-            auto run = [&](int qb, int qe, auto with_vdw_tag, auto interior_tag) __attribute__((always_inline)) {
-                if (qb >= qe) return;
-                Quad An = s_rec[qb].xyzq;
-                for (int q = qb; q < qe; ++q) {
-                    const Quad A = An;
-                    An = s_rec[q + 1].xyzq;
-                    pair_body(q, A, with_vdw_tag, interior_tag);
-                }
-            };
             if (MODE != MODE_COULOMB) {
-                run(0, nvi, std::true_type{}, std::true_type{});
-                run(nvi, nv, std::true_type{}, std::false_type{});
+                for (int q = 0; q < nvi; ++q) pair_body(q, std::true_type{}, std::true_type{});
+                for (int q = nvi; q < nv; ++q) pair_body(q, std::true_type{}, std::false_type{});
             }
             if (MODE != MODE_VDW) {
-                run(MODE == MODE_COULOMB ? 0 : nv, nni, std::false_type{}, std::true_type{});
-                run(nni, nreg, std::false_type{}, std::false_type{});
+                for (int q = (MODE == MODE_COULOMB ? 0 : nv); q < nni; ++q) pair_body(q, std::false_type{}, std::true_type{});
+                for (int q = nni; q < nreg; ++q) pair_body(q, std::false_type{}, std::false_type{});
             }
             // third group: the lanes within the cutoff of THIS image go to the exact path (which works from the atom and finds
             // its nearest image itself -- two images of one atom are never both inside the cutoff of a point)
