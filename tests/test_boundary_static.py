@@ -218,3 +218,26 @@ def test_header_is_c99_and_a_plain_c_caller_links(tmp_path):
     if lib.ceg_device_count() == 0:
         r = subprocess.run([str(exe)], capture_output=True, text=True)
         assert r.returncode == 3 and "no CPU path" in r.stderr
+
+
+def test_table_path_kernels_use_no_scratch_and_fit_two_workgroups():
+    """A compile-time guard for the hot path (hipcc cross-compiles without a GPU): every grid-mode k_culled variant of the
+    table paths (EWK = 2 with VDWK 1 or 3, the multi-probe variants) is built with 0 bytes of scratch per lane and no spilled
+    VGPRs, keeps >= 3 waves per SIMD, and two workgroups of the fused variants fit a CU's 160 KiB of LDS.  A silent spill or a
+    lost workgroup is a performance cliff that no numerical test would notice."""
+    import shutil, subprocess, sys
+    import pytest
+    if shutil.which("hipcc") is None and not Path("/opt/rocm/bin/hipcc").exists():
+        pytest.skip("no hipcc")
+    root = Path(__file__).resolve().parent.parent
+    out = subprocess.run([sys.executable, str(root / "scripts" / "resource_usage.py")], capture_output=True, text=True, timeout=900).stdout
+    rows = [l for l in out.splitlines() if l.startswith("k_culled<") and " grid " in l and "EWK=2" in l and ("VDWK=1" in l or "VDWK=3" in l)]
+    assert len(rows) >= 9, out[-2000:]
+    for l in rows:
+        m = re.search(r"VGPR\s+(\d+).*scratch\s+(\d+) B/lane\s+spills S\s+\d+ V\s+(\d+)\s+LDS\s+(\d+) B\s+occupancy (\d+)", l)
+        assert m, l
+        vgpr, scratch, vspill, lds, occ = (int(x) for x in m.groups())
+        assert scratch == 0 and vspill == 0, l
+        assert occ >= 3, l
+        if l.startswith("k_culled<fused"):
+            assert 2 * lds <= 160 * 1024 and occ >= 4, l
