@@ -241,3 +241,28 @@ def test_table_path_kernels_use_no_scratch_and_fit_two_workgroups():
         assert occ >= 3, l
         if l.startswith("k_culled<fused"):
             assert 2 * lds <= 160 * 1024 and occ >= 4, l
+
+
+def test_hot_loop_instruction_budget(tmp_path):
+    """The interior hot loops of the three production kernels, counted in the ISA hipcc emits (scripts/hot_loop_isa.py): the budgets
+    DESIGN section 3 quotes -- fused LJ + Ewald 67 VALU, Coulomb-only 45, LJ-only 36 -- with one instruction of slack, and neither
+    scratch nor global memory accesses inside them."""
+    import subprocess, sys
+    import pytest
+    hipcc = Path("/opt/rocm/bin/hipcc")
+    if not hipcc.exists():
+        pytest.skip("no hipcc")
+    root = Path(__file__).resolve().parent.parent
+    csrc = root / "crystalenergygrids.jl_amd" / "csrc"
+    flags = re.search(r"CXXFLAGS\s*=\s*(.*?)\nSRCS", (csrc / "Makefile").read_text(), re.S).group(1).replace("\\\n", " ").replace("$(ARCH)", "gfx950").split()
+    asm = tmp_path / "kern.s"
+    subprocess.run([str(hipcc), *flags, "-S", "--cuda-device-only", "-o", str(asm), "ceg_kernels.hip"], cwd=csrc, check=True, capture_output=True, timeout=900)
+    # (mode, VDWK, EWK), VALU budget of the interior loop, least FP64 count that identifies it among the kernel's loops
+    for (mode, vdwk, ewk), budget, fp64_min in (((2, 1, 2), 68, 60), ((1, 1, 2), 46, 38), ((0, 1, 1), 37, 30)):
+        out = subprocess.run([sys.executable, str(root / "scripts" / "hot_loop_isa.py"), str(asm), str(mode), str(vdwk), str(ewk)],
+                             capture_output=True, text=True, check=True).stdout
+        loops = re.findall(r"VALU (\d+) \(FP64 (\d+), other (\d+)\), SALU \d+, LDS \d+, scratch (\d+), global (\d+)", out)
+        assert loops, out
+        big = [int(l[0]) for l in loops if int(l[1]) >= fp64_min]
+        assert big and min(big) <= budget, (mode, vdwk, ewk, out)
+        assert all(int(l[3]) == 0 and int(l[4]) == 0 for l in loops), out
