@@ -618,6 +618,29 @@ def test_roofline_workload_properties(hip_lib, oracle):
     compare_grids(full_c[:, i0:i1, j0:j1].cpu().numpy(), ref[:, i0:i1, j0:j1], "R/oracle/coulomb")
 
 
+def test_fused_build_speed_canary(hip_lib):
+    """Not a benchmark (bench.py is): the fused 256^3 x 11 664-atom build took 17.5 ms in round 1 and takes 12.9 - 14.1 ms box by box
+    now; a build that needs more than 20 ms has lost its hot loop (spills, a table that no longer fits, a fallback path)."""
+    import torch
+    w = W.roofline_workload("Ar", 255)
+    nx, ny, nz = w.cset.npoints
+    dev = torch.device("cuda", 0)
+    plan = GridPlan(w.cset, w.probe_vdw, w.probe_coulomb, w.alpha)
+    v = torch.empty((8, nx, ny, nz), dtype=torch.float32, device=dev)
+    c = torch.empty_like(v)
+    s = torch.cuda.current_stream().cuda_stream
+    best = 1e9
+    for _ in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        plan.build_fused(v.data_ptr(), c.data_ptr(), nx * ny * nz, 0, nx, 0, CULLED, s)
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    plan.close()
+    assert best < 20.0, f"fused build {best:.2f} ms"
+
+
 def test_multi_device_oneshot(hip_lib, oracle, monkeypatch):
     """ngpus > 1 in the one-shot entry point (single process, one host thread + plan + slab per device).  On a
     one-GPU box the slabs are oversubscribed onto the one card (CEG_HIP_OVERSUBSCRIBE), which still runs the
