@@ -101,6 +101,54 @@ def test_slab_gather_gloo(tmp_path, world, spacing, oracle):
     assert ncyc in (0, 4 * world)
 
 
+def _layout8_worker(rank, world, port, outdir):
+    for p in (str(ROOT / "crystalenergygrids.jl_amd"), str(ROOT)):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ceg_hip.distributed import PipelinedGather, cyclic_plan
+        nx, ny, nz = 256, 3, 5                      # the x extent of the benchmark grid, tiny planes
+        cyc = cyclic_plan(nx, world, rank, nchunks=8)
+        assert cyc is not None and cyc.m == nx // (8 * world)
+        joint = torch.full((cyc.nchunks, 2, 8, cyc.m, ny, nz), float("nan"), dtype=torch.float32)
+        fa = torch.full((8, nx, ny, nz), float("nan"), dtype=torch.float32)
+        fb = torch.full((8, nx, ny, nz), float("nan"), dtype=torch.float32)
+
+        def value(c, i, j, k):                       # what a correct build leaves at channel c, plane i, row j, column k
+            return (c * 1000.0 + i) + 0.01 * j + 0.0001 * k
+
+        jj, kk = torch.meshgrid(torch.arange(ny, dtype=torch.float32), torch.arange(nz, dtype=torch.float32), indexing="ij")
+
+        def launch(j, ib, ie, blocks):
+            assert ie - ib == cyc.m
+            for c in range(8):
+                for t, i in enumerate(range(ib, ie)):
+                    blocks[0][c, t] = value(c, i, jj, kk)
+                    blocks[1][c, t] = -value(c, i, jj, kk)
+
+        for mode in ("staged", "p2p"):
+            fa.fill_(float("nan")); fb.fill_(float("nan"))
+            pg = PipelinedGather(cyc, [fa, fb], [joint[:, 0], joint[:, 1]], mode=mode, joint=joint if mode == "staged" else None)
+            pg.run(launch)
+            want = torch.stack([torch.stack([value(c, i, jj, kk) for i in range(nx)]) for c in range(8)])
+            assert torch.equal(fa, want) and torch.equal(fb, -want), (rank, mode)
+        open(os.path.join(outdir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_layout_of_the_benchmark(tmp_path):
+    """The data movement of `bench.py --gpus 8` as the driver will launch it (256 x-planes, 8 chunks of 8 x 4 planes, both grids of a
+    chunk in one collective), on 8 gloo ranks with tiny planes: every rank ends with every plane of both grids in its place."""
+    world = 8
+    mp.spawn(_layout8_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
 def test_cyclic_plan_shapes():
     from ceg_hip.distributed import cyclic_plan
     for world in (1, 2, 4, 8):
