@@ -25,21 +25,28 @@ __device__ __forceinline__ double periodic_distance2_literal_m(const double* M, 
     dz = M[2] * f0 + M[5] * f1 + M[8] * f2;
     const double ref2 = dx * dx + dy * dy + dz * dz;
     if (ortho || ref2 <= safemin2) return ref2;
-    // first strictly closer image among +a, -a, +b, -b, +c, -c (src/utils.jl:234-244)
-    const double wx = dx, wy = dy, wz = dz;
+    // first strictly closer image among +a, -a, +b, -b, +c, -c, formed like the reference does (src/utils.jl:234-244):
+    // the fractional component is stepped IN PLACE (+1, -2, +1) and every trial image is the full product mat * f, so a
+    // tie within an ulp of `newnorm2 < ref2` falls on the same side as in the Julia source (and the +1 -2 +1 round trip
+    // leaves in f_i whatever rounding it leaves there for the later axes).
+    double f[3] = {f0, f1, f2};
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
-        const double cx = M[3 * ax], cy = M[3 * ax + 1], cz = M[3 * ax + 2];
-        double ex = wx + cx, ey = wy + cy, ez = wz + cz;     // (f_ax + 1)
-        double n2 = ex * ex + ey * ey + ez * ez;
-        if (n2 < ref2) { dx = ex; dy = ey; dz = ez; return n2; }
-        ex = wx - cx; ey = wy - cy; ez = wz - cz;            // (f_ax - 1)
-        n2 = ex * ex + ey * ey + ez * ez;
-        if (n2 < ref2) { dx = ex; dy = ey; dz = ez; return n2; }
+        f[ax] += 1.0;
+        dx = M[0] * f[0] + M[3] * f[1] + M[6] * f[2];
+        dy = M[1] * f[0] + M[4] * f[1] + M[7] * f[2];
+        dz = M[2] * f[0] + M[5] * f[1] + M[8] * f[2];
+        double n2 = dx * dx + dy * dy + dz * dz;
+        if (n2 < ref2) return n2;
+        f[ax] -= 2.0;
+        dx = M[0] * f[0] + M[3] * f[1] + M[6] * f[2];
+        dy = M[1] * f[0] + M[4] * f[1] + M[7] * f[2];
+        dz = M[2] * f[0] + M[5] * f[1] + M[8] * f[2];
+        n2 = dx * dx + dy * dy + dz * dz;
+        if (n2 < ref2) return n2;
+        f[ax] += 1.0;
     }
-    // fall-through: the reference returns ref2 but leaves buffer at the last trial image
-    // (f_3 - 1), i.e. wrapped - c
-    dx = wx - M[6]; dy = wy - M[7]; dz = wz - M[8];
+    // fall-through: the reference returns ref2 but leaves buffer at the last trial image, mat * (f with f_3 - 1)
     return ref2;
 }
 

@@ -25,8 +25,8 @@ _i64p = C.POINTER(C.c_int64)
 
 def build(force: bool = False) -> Path:
     """Compile the oracle with gcc (recipe: oracle/Makefile)."""
-    src = HERE / "ceg_oracle.c"
-    if force or not LIB.exists() or LIB.stat().st_mtime < src.stat().st_mtime:
+    newest = max((HERE / f).stat().st_mtime for f in ("ceg_oracle.c", "ceg_oracle_mc.c", "Makefile"))
+    if force or not LIB.exists() or LIB.stat().st_mtime < newest:
         subprocess.check_call(["make", "-C", str(HERE), "-B", "libceg_oracle.so"],
                               stdout=subprocess.DEVNULL)
     return LIB
@@ -95,16 +95,20 @@ def _cm(m) -> np.ndarray:
 
 
 class _Probe:
-    """flat view of a ceg_hip ProbeSystem for the C calls"""
+    """INPUT ADAPTER: flat view of a ProbeSystem-like object (positions, atomkinds, charges, mat, invmat, the probe's rule
+    table) for the C calls.  ortho / safemin come from the oracle's own restatement of prepare_periodic_distance_computations
+    (probes.jl:72-73 -> utils.jl:146-155), not from the object."""
 
     def __init__(self, probe):
+        from .hostlogic import prepare_periodic_distance_computations
         self.pos = np.ascontiguousarray(probe.positions, dtype=np.float64)
         self.kinds = np.ascontiguousarray(probe.atomkinds, dtype=np.int64)
         self.q = np.ascontiguousarray(probe.charges, dtype=np.float64)
         self.n = len(self.pos)
         self.mat = _cm(probe.mat)
         self.invmat = _cm(probe.invmat)
-        self.ortho, self.safemin2 = probe.periodic_setup()
+        self.ortho, safemin = prepare_periodic_distance_computations(probe.mat)
+        self.safemin2 = safemin * safemin
         self.cutoff2 = probe.cutoff2
         if probe.probe:
             self.rules, self.offsets = probe.forcefield.rule_table(probe.probe)
@@ -221,9 +225,10 @@ def derivatives_ewald(alpha: float, charge: float, r2: float) -> np.ndarray:
 
 def interpolate_points(g, points, nthreads=0) -> np.ndarray:
     """interpolate_grid (grids.jl:212-273) of an EnergyGrid (values in K) at many points, literal
-    COEFF*X evaluation; the COEFF matrix comes from ceg_hip.constants.tricubic_coeff()."""
+    COEFF*X evaluation; the COEFF matrix is the oracle's own (oracle/hostlogic.py, pinned to the reference's literal
+    src/constants.jl:24-89 through tests/golden/coeff.json).  ``g``: any object with the EnergyGrid fields (input adapter)."""
     import math
-    from ceg_hip.constants import tricubic_coeff
+    from .hostlogic import tricubic_coeff
     cs = g.csetup
     grid = np.ascontiguousarray(g.grid, dtype=np.float32)
     dims = np.ascontiguousarray(cs.dims, dtype=np.int32)
@@ -244,16 +249,18 @@ def interpolate_points(g, points, nthreads=0) -> np.ndarray:
 
 def reciprocal_energies(ef, molecule, positions, nthreads=0) -> np.ndarray:
     """compute_ewald (ewald.jl:555-577) of one rigid molecule placed at positions[n, natoms, 3]: literal
-    restatement with the reference's power tables and summation order."""
-    from ceg_hip.ewald import ewald_context_constants, kindices_array
-    kind = kindices_array(ef)
+    restatement with the reference's power tables and summation order.  ``ef``: an EwaldFramework-like object (input adapter:
+    attribute access only); the two context constants come from the oracle's own restatement (oracle/hostlogic.py)."""
+    from .hostlogic import adapt_ewald_framework, ewald_context_constants
+    kind = np.ascontiguousarray(np.array(ef.kspace.kindices, dtype=np.int32).reshape(-1, 5))
     ks = np.asarray(ef.kspace.ks, dtype=np.int32)
     kf = np.ascontiguousarray(ef.kfactors, dtype=np.float64)
     re = np.ascontiguousarray(ef.StoreRigidChargeFramework.real, dtype=np.float64)
     im = np.ascontiguousarray(ef.StoreRigidChargeFramework.imag, dtype=np.float64)
     q = np.ascontiguousarray(molecule.atomic_charge, dtype=np.float64)
     pos = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, len(q), 3)
-    enc, static = ewald_context_constants(ef, ((molecule,),))
+    enc, static = ewald_context_constants(adapt_ewald_framework(ef),
+                                          [(q, np.asarray(molecule.position, dtype=np.float64).reshape(-1, 3), 1)])
     out = np.empty(len(pos), dtype=np.float64)
     lib().oracle_reciprocal_energies(kind.ctypes.data_as(_i32p), len(kind), ks.ctypes.data_as(_i32p), _d(kf), _d(re), _d(im),
                                      len(kf), _d(_cm(ef.invmat)), _d(pos.reshape(-1)), _d(q), len(q), len(pos), enc, static,
@@ -263,8 +270,8 @@ def reciprocal_energies(ef, molecule, positions, nthreads=0) -> np.ndarray:
 
 def single_contribution_vdw(mc, idx, trial, nthreads=0) -> np.ndarray:
     """single_contribution_vdw_noneighbour (energy.jl:407-427) of molecule ``idx`` = (kind, molecule),
-    0-based, of a ceg_hip.montecarlo.MonteCarloSetup at trial[n, natoms, 3]."""
-    from ceg_hip.constants import COULOMBIC_CONVERSION_FACTOR
+    0-based, of a MonteCarloSetup-like object (input adapter) at trial[n, natoms, 3]."""
+    from .hostlogic import COULOMBIC_CONVERSION_FACTOR
     rules, offsets = mc.ff.pair_table()
     pos, kinds, mol = [], [], []
     for m, (i, j, ids, p) in enumerate(mc.molecules()):
@@ -305,7 +312,7 @@ def block_from_grid(g, threshold=5e6) -> np.ndarray:
 
 def block_spheres(csetup, centers, radius2, nthreads=0) -> np.ndarray:
     """The scan of parse_blockfile (coordinates.jl:139-152) -> bool[nx, ny, nz]."""
-    from ceg_hip.utils import prepare_periodic_distance_computations
+    from .hostlogic import prepare_periodic_distance_computations
     dims = np.ascontiguousarray(csetup.dims, dtype=np.int32)
     ortho, safemin = prepare_periodic_distance_computations(csetup.cell.mat)
     c = np.ascontiguousarray(centers, dtype=np.float64).reshape(-1, 3)

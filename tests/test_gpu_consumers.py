@@ -187,13 +187,18 @@ def test_mc_replay_1000_moves(hip_lib, tmp_path):
     """BASELINE config 5 as the reference runs it (montecarlo.jl:563-628, simulation.jl:727-781): one trial per Markov step.
     A fixed sequence of 1000 translation / rotation moves with an energy-independent acceptance pattern is replayed on
     the device-resident state (ceg_mc_trial: ONE launch per step, ceg_mc_accept: update_mc! on the device, nothing uploaded
-    between moves) and on the host mirror ceg_hip.montecarlo; every movement_energy (before, after; four terms) must agree
-    to 1e-9, and so must the final positions and total structure factor."""
+    between moves) and on the ORACLE's state (oracle/montecarlo.OracleMonteCarlo: movement_energy composed of the C restatements
+    oracle_interpolate_grid + oracle_single_contribution_vdw + power-table structure factors + the rest sum of ewald.jl:718-737,
+    nothing of the product package in it); every movement_energy (before, after; four terms) must agree to 1e-9, and so must
+    the final positions and total structure factor.  The host mirror ceg_hip.montecarlo is checked as a second assert."""
     from ceg_hip.energy import DeviceMonteCarlo
+    from oracle.montecarlo import OracleMonteCarlo
     try:
         M, mc = _mc_setup(tmp_path)
         M.baseline_energy(mc)                                   # host: per-molecule structure factors (mc.sums)
         dev = DeviceMonteCarlo(mc)
+        omc = OracleMonteCarlo.from_setup(mc)
+        omc.compute_ewald()
         mols = [(i, j) for i, kind in enumerate(mc.positions) for j in range(len(kind))]
         rng = np.random.default_rng(2024)
         worst = 0.0
@@ -210,22 +215,25 @@ def test_mc_replay_1000_moves(hip_lib, tmp_path):
                 new = c + (new - c) @ _rotation(rng).T
             got = dev.trial(idx, new[None])
             before, after = M.movement_energy(mc, idx), M.movement_energy(mc, idx, new)
-            for row, ref in ((got[0], before), (got[1], after)):
-                r = np.array([ref.framework_vdw, ref.framework_direct, ref.inter, ref.reciprocal])
+            for row, r, mirror in ((got[0], omc.movement_energy(idx), before), (got[1], omc.movement_energy(idx, new), after)):
                 ok = np.isfinite(r) & (np.abs(r) < 1e90)
                 assert np.array_equal(row[~ok] >= 1e90, r[~ok] >= 1e90) or not (~ok).any(), (step, row, r)
                 err = np.abs(row[ok] - r[ok]) / (1e-9 * np.abs(r[ok]) + 1e-7)
                 worst = max(worst, float(err.max()) if ok.any() else 0.0)
                 assert (err <= 1.0).all(), (step, idx, row, r)
+                m = np.array([mirror.framework_vdw, mirror.framework_direct, mirror.inter, mirror.reciprocal])      # second assert
+                assert np.all(np.abs(row[ok] - m[ok]) <= 1e-9 * np.abs(m[ok]) + 1e-7), (step, idx, row, m)
             if step % 3 != 0:                                   # energy-independent acceptance pattern
                 dev.accept(idx, new)
+                omc.update(idx, new)
                 M.update_mc(mc, idx, new)
                 naccept += 1
         assert naccept > 600
         pos, sf = dev.state()
-        ref_pos = np.concatenate([p for _i, _j, _ids, p in mc.molecules()])
-        assert np.array_equal(pos, ref_pos)                     # positions are copied, not recomputed
-        scale = np.abs(mc.sums[:, 0]).max()
+        assert np.array_equal(pos, omc.flat_positions())        # positions are copied, not recomputed
+        osf = omc.total_structure_factor()
+        scale = np.abs(osf).max()
+        assert np.abs(sf - osf).max() <= 1e-9 * scale
         assert np.abs(sf - mc.sums[:, 0]).max() <= 1e-9 * scale
         # the same through a batch: 64 placements of one CO2 in one launch == the step-by-step rows
         idx = mols[2]
@@ -233,8 +241,7 @@ def test_mc_replay_1000_moves(hip_lib, tmp_path):
         batch = cur[None] + rng.uniform(-1.0, 1.0, (64, 1, 3))
         rows = dev.trial(idx, batch)
         for t in (0, 17, 63):
-            ref = M.movement_energy(mc, idx, batch[t])
-            r = np.array([ref.framework_vdw, ref.framework_direct, ref.inter, ref.reciprocal])
+            r = omc.movement_energy(idx, batch[t])
             ok = np.abs(r) < 1e90
             assert np.all(np.abs(rows[1 + t][ok] - r[ok]) <= 1e-9 * np.abs(r[ok]) + 1e-7)
         # baseline_energy of the final configuration from the device state == the host mirror's
@@ -249,22 +256,28 @@ def test_mc_replay_1000_moves(hip_lib, tmp_path):
 
 def test_mc_insertions_and_removals(hip_lib, tmp_path):
     """GCMC swaps on the device-resident state (ceg_mc_trial_insert / ceg_mc_insert / ceg_mc_remove = movement_energy with
-    ij < 0, add_one_system!, remove_one_system!; ewald.jl:704-728,775-810) interleaved with displacements, against the host
-    mirror: insertion energies, the energies of every later move (they see the inserted / miss the removed molecules in the
-    pair sum and in the total structure factor), final positions and structure factor."""
+    ij < 0, add_one_system!, remove_one_system!; ewald.jl:704-728,775-810) interleaved with displacements, against the ORACLE's
+    state (oracle/montecarlo.OracleMonteCarlo; the host mirror as a second assert): insertion energies, the energies of every
+    later move (they see the inserted / miss the removed molecules in the pair sum and in the total structure factor), final
+    positions and structure factor."""
     from ceg_hip.energy import DeviceMonteCarlo
+    from oracle.montecarlo import OracleMonteCarlo
     try:
         M, mc = _mc_setup(tmp_path)
         M.baseline_energy(mc)
         dev = DeviceMonteCarlo(mc)
+        omc = OracleMonteCarlo.from_setup(mc)
+        omc.compute_ewald()
         rng = np.random.default_rng(77)
         base = mc.positions[1][0] - mc.positions[1][0][1]              # CO2 geometry about its carbon
         na = np.zeros((1, 3))
 
-        def check(row, ref, what):
-            r = np.array([ref.framework_vdw, ref.framework_direct, ref.inter, ref.reciprocal])
+        def check(row, r, ref, what):
             ok = np.abs(r) < 1e90
+            assert np.array_equal(row[~ok] >= 1e90, r[~ok] >= 1e90), (what, row, r)
             assert np.all(np.abs(row[ok] - r[ok]) <= 1e-9 * np.abs(r[ok]) + 1e-7), (what, row, r)
+            m = np.array([ref.framework_vdw, ref.framework_direct, ref.inter, ref.reciprocal])                      # second assert: the mirror
+            assert np.all(np.abs(row[ok] - m[ok]) <= 1e-9 * np.abs(m[ok]) + 1e-7), (what, row, m)
 
         nins = nrem = 0
         for step in range(240):
@@ -275,15 +288,15 @@ def test_mc_insertions_and_removals(hip_lib, tmp_path):
                 trials = (mc.mat @ rng.uniform(0, 1, (5, 3)).T).T[:, None, :] + shape[None]
                 rows = dev.trial_insert(kind, trials)
                 for t in (0, 4):
-                    check(rows[t], M.insertion_energy(mc, kind, trials[t]), ("insert", step, t))
+                    check(rows[t], omc.insertion_energy(kind, trials[t]), M.insertion_energy(mc, kind, trials[t]), ("insert", step, t))
                 dev.insert(kind, trials[2])
-                M.add_molecule(mc, kind, trials[2])
+                assert omc.add(kind, trials[2]) == M.add_molecule(mc, kind, trials[2])
                 nins += 1
             elif op == 2 and len(mc.positions[kind]) > 1:            # deletion: energy of the molecule where it is, then remove
                 j = int(rng.integers(len(mc.positions[kind])))
                 row = dev.trial((kind, j), np.empty((0, len(mc.ffidx[kind]), 3)))[0]
-                check(row, M.movement_energy(mc, (kind, j)), ("delete", step))
-                assert dev.remove((kind, j)) == M.remove_molecule(mc, (kind, j))     # the last molecule of the kind takes index j
+                check(row, omc.movement_energy((kind, j)), M.movement_energy(mc, (kind, j)), ("delete", step))
+                assert dev.remove((kind, j)) == omc.remove((kind, j)) == M.remove_molecule(mc, (kind, j))     # the last molecule of the kind takes index j
                 nrem += 1
             else:                                                    # displacement
                 if not mc.positions[kind]:
@@ -292,15 +305,17 @@ def test_mc_insertions_and_removals(hip_lib, tmp_path):
                 cur = mc.positions[kind][j]
                 new = cur + rng.uniform(-0.4, 0.4, 3)
                 got = dev.trial((kind, j), new[None])
-                check(got[0], M.movement_energy(mc, (kind, j)), ("before", step))
-                check(got[1], M.movement_energy(mc, (kind, j), new), ("after", step))
+                check(got[0], omc.movement_energy((kind, j)), M.movement_energy(mc, (kind, j)), ("before", step))
+                check(got[1], omc.movement_energy((kind, j), new), M.movement_energy(mc, (kind, j), new), ("after", step))
                 if step % 3:
                     dev.accept((kind, j), new)
+                    omc.update((kind, j), new)
                     M.update_mc(mc, (kind, j), new)
         assert nins == 60 and nrem > 30
         pos, sf = dev.state()
-        ref_pos = np.concatenate([p for _i, _j, _ids, p in mc.molecules()])
-        assert np.array_equal(pos, ref_pos)
+        assert np.array_equal(pos, omc.flat_positions())
+        osf = omc.total_structure_factor()
+        assert np.abs(sf - osf).max() <= 1e-9 * np.abs(osf).max()
         assert np.abs(sf - mc.sums[:, 0]).max() <= 1e-9 * np.abs(mc.sums[:, 0]).max()
         dev.close()
     finally:
@@ -618,8 +633,15 @@ def test_incremental_ewald_context_testset(hip_lib, monkeypatch):
         _abi.check(lib, lib.ceg_mc_get_state(h, None, _abi.dptr(re), _abi.dptr(im)))
         return re + 1j * im
 
+    from oracle import hostlogic as H
+    oef = H.adapt_ewald_framework(mc.ewald)
+
+    def mol_sf(i, p):        # the oracle's power-table structure factor of one molecule (ewald.jl:352-366,660-684)
+        re, im = H.molecule_sums(oef, p, [mc.charges[ix] for ix in mc.ffidx[i]])
+        return re + 1j * im
+
     def expected_sf():
-        return sum(M._molecule_sf(mc, mc.ffidx[i], p) for i, p in state)
+        return sum(mol_sf(i, p) for i, p in state)
 
     def check():
         ref = expected_sf()
@@ -638,6 +660,6 @@ def test_incremental_ewald_context_testset(hip_lib, monkeypatch):
     assert remove(3) == 3 and add(1, pos3) == 3; check()                      # :105-107
     assert add(2, co2_2) == 4; check()                                        # :112
     # the same species listed in another order give the same energy (:113-120): the structure factor is a plain sum
-    other = sum(M._molecule_sf(mc, mc.ffidx[i], p) for i, p in ((1, co2_2), (1, pco2), (0, pos3), (0, pos2)))
+    other = sum(mol_sf(i, p) for i, p in ((1, co2_2), (1, pco2), (0, pos3), (0, pos2)))
     assert np.abs(total_sf() - other).max() <= 1e-10 * max(1.0, np.abs(other).max())
     dev.close()
