@@ -135,6 +135,60 @@ __device__ __forceinline__ double interp_point(const InterpGeom& g, const float*
     return (g.is_vdw && blocked) ? 1e100 : ret;
 }
 
+// The same interpolant with ONE corner per lane (the wave-per-placement Monte-Carlo kernel: 8 lanes per (atom, grid), their partial
+// sums added by the caller with three lane shuffles).  corner = ax << 2 | ay << 1 | az.  Returns the corner's share of the 64-term sum;
+// `blocked` is set when THIS corner's value exceeds 5e6 (the caller ORs the eight).  Trilinear grids ("no derivatives", a hand-made
+// EnergyGrid only) are evaluated whole by the lane of corner 0.
+__device__ __forceinline__ double interp_corner(const InterpGeom& g, const float* __restrict__ grid, double px, double py, double pz, int corner,
+                                                bool& blocked)
+{
+    blocked = false;
+    if (g.trilinear) return corner == 0 ? interp_point(g, grid, px, py, pz) : 0.0;
+    double sh[3];
+    {
+#pragma clang fp contract(off)
+        const double* I = g.invmat;
+        const double* M = g.mat;
+        double a0 = (I[0] * px + I[3] * py) + I[6] * pz;
+        double a1 = (I[1] * px + I[4] * py) + I[7] * pz;
+        double a2 = (I[2] * px + I[5] * py) + I[8] * pz;
+        a0 -= floor(a0); a1 -= floor(a1); a2 -= floor(a2);
+        const double q0 = (M[0] * a0 + M[3] * a1) + M[6] * a2;
+        const double q1 = (M[1] * a0 + M[4] * a1) + M[7] * a2;
+        const double q2 = (M[2] * a0 + M[5] * a1) + M[8] * a2;
+        sh[0] = (q0 - g.shift[0]) * (double)g.dims[0] / g.size[0] + 1.0;
+        sh[1] = (q1 - g.shift[1]) * (double)g.dims[1] / g.size[1] + 1.0;
+        sh[2] = (q2 - g.shift[2]) * (double)g.dims[2] / g.size[2] + 1.0;
+    }
+    const int ext[3] = {g.dims[0] + 1, g.dims[1] + 1, g.dims[2] + 1};
+    const int sel[3] = {(corner >> 2) & 1, (corner >> 1) & 1, corner & 1};
+    int node[3];
+    double w0[3], w1[3];                       // Hermite weights of this corner along each axis: value, slope
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double f = floor(sh[a]);
+        int i0 = (int)f;
+        const double t = sh[a] - f;
+        i0 = i0 < 1 ? 1 : (i0 > ext[a] ? ext[a] : i0);
+        const int i1 = i0 + (i0 != ext[a] ? 1 : 0);
+        node[a] = (sel[a] ? i1 : i0) - 1;
+        const double t2 = t * t, t3 = t2 * t;
+        w0[a] = sel[a] ? (-2.0 * t3 + 3.0 * t2) : (2.0 * t3 - 3.0 * t2 + 1.0);
+        w1[a] = sel[a] ? (t3 - t2) : (t3 - 2.0 * t2 + t);
+    }
+    const int64_t n = ((int64_t)node[0] * ext[1] + node[1]) * ext[2] + node[2];
+    const float4* g4 = reinterpret_cast<const float4*>(grid);
+    const float4 a = g4[2 * n], b = g4[2 * n + 1];
+    blocked = a.x > 5e6f;
+    // channels: value, dx, dy, dz, dxy, dxz, dyz, dxyz
+    const double x0 = w0[0], x1 = w1[0], y0 = w0[1], y1 = w1[1], z0 = w0[2], z1 = w1[2];
+    double ret = (x0 * y0) * (z0 * (double)a.x + z1 * (double)a.w);        // value, dz
+    ret += (x1 * y0) * (z0 * (double)a.y + z1 * (double)b.y);              // dx, dxz
+    ret += (x0 * y1) * (z0 * (double)a.z + z1 * (double)b.z);              // dy, dyz
+    ret += (x1 * y1) * (z0 * (double)b.x + z1 * (double)b.w);              // dxy, dxyz
+    return ret;
+}
+
 // ------------------------------------------------------------------ f3: pair rule energies
 // (rule::InteractionRule)(r2) -- src/interactions.jl:392-406 (r2 forms) and :367-390 (r forms)
 __device__ __forceinline__ double rule_energy(const DevRule& R, double r2, double coulombic)

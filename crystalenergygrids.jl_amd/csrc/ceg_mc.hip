@@ -23,11 +23,13 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <utility>
 #include <vector>
 
 #include "../../include/ceg_hip.h"
 #include "ceg_consumers.h"
+#include "ceg_rows.h"
 
 using ceg::DevRule;
 using ceg_consumers::InterpGeom;
@@ -79,6 +81,11 @@ struct McView {
     double hfrac[3];                           // cutoff / perpendicular width: fractional half-extent of the cutoff sphere
     double4* cells;                            // [nb0*nb1*nb2][cell_cap]
     int32_t* cell_count;                       // [nb0*nb1*nb2]
+    // the k-vectors as rows cut into segments and dealt to 64 lanes in rounds (ceg_rows.h)
+    int32_t nrounds, ns;
+    int32_t fastwrap, _pad1;                   // every perpendicular width > 2 cutoff: a pair at the wrap boundary is beyond the cutoff (see k_mcw_pairs)
+    const int32_t* desc;                       // [nrounds * 64]
+    const int32_t* qof;                        // [ns * 64] k-vector of (slot, lane), -1 in the padding slots
 };
 
 // what an update does to the cells, worked out on the host mirror of the cell lists: cells[dst[i]] = atoms[src[i]] once the
@@ -109,7 +116,9 @@ __device__ __forceinline__ void unpack(double w, int& kind, int& mol)
 
 // e^{2 pi i m f} tables of `m_atoms` atoms at s_pos (setup_Eik / move_one_system!, src/ewald.jl:109-146,352-366),
 // by sine / cosine of the exact angle (ceg_math.h sincos_2pi); entry t of atom a at tab[a * stride + t]: t in [0, kx] -> x, then y (m = -ky..ky), then z
-__device__ __forceinline__ void fill_tables(const McView& v, const double* s_pos, int m_atoms, double2* tab, int stride, int tid, int nthreads)
+// s_q != nullptr: the z entries carry the atom's charge as a factor (what the row-wise walk of ceg_rows.h expects)
+__device__ __forceinline__ void fill_tables(const McView& v, const double* s_pos, int m_atoms, double2* tab, int stride, int tid, int nthreads,
+                                            const double* s_q = nullptr)
 {
     const int kx = v.ks[0], ky = v.ks[1], kz = v.ks[2];
     const int nxp = kx + 1, nyp = 2 * ky + 1;
@@ -125,7 +134,51 @@ __device__ __forceinline__ void fill_tables(const McView& v, const double* s_pos
         const double ff = f - rint(f);
         double s, c;
         ceg::sincos_2pi((double)mm * ff, s, c);
-        tab[e] = make_double2(c, s);
+        const double w = (s_q && t >= nxp + nyp) ? s_q[a] : 1.0;
+        tab[e] = make_double2(w * c, w * s);
+    }
+}
+
+// the same tables filled by ONE wave (k_mcw_ewald): entry t per lane, the atoms in an inner loop -- no division by the stride, the axis
+// decoded once per entry
+__device__ __forceinline__ void fill_tables_wave(const McView& v, const double* s_pos, int m_atoms, double2* tab, int stride, int lane, const double* s_q)
+{
+    const int kx = v.ks[0], ky = v.ks[1], kz = v.ks[2];
+    const int nxp = kx + 1, nyp = 2 * ky + 1;
+    const double* I = v.ew_invmat;
+    for (int t = lane; t < stride; t += 64) {
+        const int ax = t < nxp ? 0 : (t < nxp + nyp ? 1 : 2);
+        const int mm = ax == 0 ? t : (ax == 1 ? t - nxp - ky : t - nxp - nyp - kz);
+        const double i0 = I[ax], i1 = I[ax + 3], i2 = I[ax + 6];
+        for (int a = 0; a < m_atoms; ++a) {
+            const double f = i0 * s_pos[3 * a] + i1 * s_pos[3 * a + 1] + i2 * s_pos[3 * a + 2];
+            const double ff = f - rint(f);
+            double s, c;
+            ceg::sincos_2pi((double)mm * ff, s, c);
+            const double w = ax == 2 ? s_q[a] : 1.0;
+            tab[a * stride + t] = make_double2(w * c, w * s);
+        }
+    }
+}
+
+// The structure factor of the molecule whose tables (charge on z) are `tab`, k-vector by k-vector in the row-wise order of ceg_rows.h:
+// wave `wave` of `nwaves` takes the rounds wave, wave + nwaves, ...; sink(q, re, im) for every real k-vector.
+template <class Sink>
+__device__ __forceinline__ void rows_structure_factor(const McView& v, const double2* tab, int stride, int m_atoms, int wave, int nwaves, int lane, Sink&& sink)
+{
+    const int nxp = v.ks[0] + 1, nyp = 2 * v.ks[1] + 1;
+    int slot = 0;
+    for (int r = 0; r < v.nrounds; ++r) {
+        const int d = v.desc[r * 64 + lane];
+        const int L = __builtin_amdgcn_readfirstlane(d >> 27);
+        if (r % nwaves == wave) {
+            const int at = slot * 64 + lane;
+            ceg_rows::round_dispatch(L, m_atoms, tab, stride, nxp, nyp, d & 0x1ff, (d >> 9) & 0x1ff, (d >> 18) & 0x1ff, [&](int sidx, double sr, double si) {
+                const int q = v.qof[at + sidx * 64];
+                if (q >= 0) sink(q, sr, si);
+            });
+        }
+        slot += L;
     }
 }
 
@@ -338,6 +391,366 @@ __global__ __launch_bounds__(MC_THREADS, MC_TRIAL_WAVES) void k_mc_trial(McView 
     }
 }
 
+// ---- the same rows for LARGE batches: one WAVE per placement, one kernel per term (round 4).
+// k_mc_trial gives every placement a workgroup of four waves that meet at five barriers and read the k-space constants (56 B per
+// k-vector) from L2 for every placement: right for the latency of a batch-1 call, 0.064 of the FP64 peak at batch 65 536.  From
+// `wave_kernel_min_rows` rows on a batch goes through three launches instead, each with the registers its term needs and nothing
+// else (fused into one kernel the three terms took 225 VGPRs -- 400 B of scratch at four waves per SIMD):
+//   k_mcw_frame  framework_interactions: one grid CORNER per lane (16 lanes per atom: VdW grid + Coulomb grid), three shuffles per sum;
+//   k_mcw_ewald  single_contribution_ewald: the workgroup stages kf Re(rest), kf Im(rest), kf once in the [slot][lane] planes of
+//                ceg_rows.h (rest = framework + sums[:,1] - sums[:,ij+1], ewald.jl:722-728), every wave then walks its own
+//                placements: tables by sincos_2pi with the charge on z, row-wise k-vector walk (8 FMAs per atom and k-vector, no LDS
+//                access), one wave reduction -- no workgroup barrier after the staging;
+//   k_mcw_pairs  single_contribution_vdw: the rows of the pair table that belong to the kinds of THIS molecule staged in LDS, lanes
+//                stride over the guest atoms (or over the reachable neighbour cells).
+// Row r of `out` (4 doubles) receives columns 0-1 from the first, 3 from the second, 2 from the third.
+struct McFastPair {                // an entry whose rules are at most one Lennard-Jones and one CoulombEwaldDirect term (+ NoInteraction)
+    double c4eps, sigma2, qq, alpha, shift;      // 4 eps, sigma^2, coulombic q1 q2, alpha, sum of the shifts
+    int32_t cls, _pad;                           // 1: this record is the whole entry; 0: walk the rules
+};
+struct McCompact {                 // the pair-table rows of one molecule's kinds: entry (kind1, a) -> rules [off[kind1 * m + a], off[.. + 1])
+    const DevRule* rules;
+    const int32_t* off;
+    const McFastPair* fast;        // [nkinds * m]
+    int32_t nrules, in_lds;
+};
+
+// the libm-grade rule energies behind a call: inlined, their exp / erfc / pow temporaries would set the register count of the whole
+// kernel (k_pairs: 168 VGPRs) while they serve the pairs closer than 0.5 A only
+__device__ __attribute__((noinline)) double rule_energy_call(const DevRule* R, double r2, double coulombic) { return rule_energy(*R, r2, coulombic); }
+
+// positions of row `row` into pos[3 m] (LDS of the wave): row 0 of a displacement batch is the molecule where it is now
+template <bool INSERT>
+__device__ __forceinline__ void mcw_load_row(const McView& v, int first, int m, const double* __restrict__ trial, int64_t row, int lane, double* pos)
+{
+    if (lane < 3 * m) {
+        if (!INSERT && row == 0) {
+            const double4 A = v.atoms[first + lane / 3];
+            pos[lane] = (lane % 3 == 0) ? A.x : ((lane % 3 == 1) ? A.y : A.z);
+        } else {
+            pos[lane] = trial[(size_t)(INSERT ? row : row - 1) * m * 3 + lane];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+constexpr int MCW_WAVES = 4;       // waves per workgroup of the frame and pairs kernels (nothing large is staged there)
+
+template <bool INSERT>
+__global__ __launch_bounds__(64 * MCW_WAVES) void k_mcw_frame(McView v, int32_t molecule, McMolecule nm, const double* __restrict__ trial, int64_t nrows,
+                                                             double* __restrict__ out, int per_wave)
+{
+    __shared__ double s_pos[MCW_WAVES][MC_MAX_ATOMS * 3];
+    __shared__ double s_q[MC_MAX_ATOMS];
+    __shared__ int32_t s_kind[MC_MAX_ATOMS];
+    __shared__ McGrid s_grid[MC_MAX_ATOMS];        // geometry + pointer of every atom's VdW grid: read per lane from global memory they were a
+                                                   // dependent 230-byte fetch in front of every interpolation
+    static_assert(sizeof(McGrid) % 8 == 0, "McGrid is copied in 8-byte words");
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int first = INSERT ? 0 : v.mol[molecule].x, m = INSERT ? nm.m : v.mol[molecule].y;
+    if (tid < m) {
+        int kind, mol;
+        if (INSERT) kind = nm.kinds[tid];
+        else unpack(v.atoms[first + tid].w, kind, mol);
+        s_kind[tid] = kind;
+        s_q[tid] = v.kind_charge[kind];
+    }
+    __syncthreads();
+    {
+        constexpr int W = (int)(sizeof(McGrid) / 8);
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(s_grid);
+        for (int t = tid; t < m * W; t += 64 * MCW_WAVES)
+            dst[t] = reinterpret_cast<const unsigned long long*>(v.vdw + s_kind[t / W])[t % W];
+    }
+    __syncthreads();
+    const int64_t p0 = ((int64_t)blockIdx.x * MCW_WAVES + wave) * per_wave;
+    const int64_t p1 = p0 + per_wave < nrows ? p0 + per_wave : nrows;
+    double* pos = s_pos[wave];
+    // the coordinates of a placement are fetched one placement ahead
+    auto fetch = [&](int64_t row) -> double {
+        if (lane >= 3 * m || row >= p1) return 0.0;
+        if (!INSERT && row == 0) {
+            const double4 A = v.atoms[first + lane / 3];
+            return (lane % 3 == 0) ? A.x : ((lane % 3 == 1) ? A.y : A.z);
+        }
+        return trial[(size_t)(INSERT ? row : row - 1) * m * 3 + lane];
+    };
+    double next = fetch(p0);
+    for (int64_t row = p0; row < p1; ++row) {
+        if (lane < 3 * m) pos[lane] = next;
+        __builtin_amdgcn_wave_barrier();
+        next = fetch(row + 1);
+        double fv = 0.0, fd = 0.0;
+        // montecarlo.jl:490-504: lane 16a + 8g + corner, g = 0 the VdW grid of atom a, g = 1 the Coulomb grid
+        for (int base = 0; base < 16 * m; base += 64) {
+            const int l = base + lane;
+            const int a = l >> 4, gsel = (l >> 3) & 1, corner = l & 7;
+            double part = 0.0;
+            bool blocked = false, have = false, isvdw = false;
+            if (l < 16 * m) {
+                const double px = pos[3 * a], py = pos[3 * a + 1], pz = pos[3 * a + 2];
+                if (gsel == 0) {
+                    const McGrid* G = s_grid + a;
+                    if (G->grid) { part = ceg_consumers::interp_corner(G->g, G->grid, px, py, pz, corner, blocked); have = true; isvdw = G->g.is_vdw != 0; }
+                } else if (v.coulomb.grid) {
+                    part = ceg_consumers::interp_corner(v.coulomb.g, v.coulomb.grid, px, py, pz, corner, blocked);
+                    have = true;
+                    isvdw = v.coulomb.g.is_vdw != 0;
+                }
+            }
+            int blk = blocked ? 1 : 0;
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                part += __shfl_xor(part, o);
+                blk |= __shfl_xor(blk, o);
+            }
+            if (have && corner == 0) {
+                const double val = (isvdw && blk) ? 1e100 : part;     // grids.jl:245-248
+                if (gsel == 0) fv += val;
+                else fd += (val == 1e100) ? val : s_q[a] * val;        // montecarlo.jl:500
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            fv += __shfl_xor(fv, o);
+            fd += __shfl_xor(fd, o);
+        }
+        if (lane == 0) {
+            out[4 * (size_t)row] = fv;
+            out[4 * (size_t)row + 1] = fd;
+        }
+        __builtin_amdgcn_wave_barrier();                           // pos is rewritten for the next placement
+    }
+}
+
+template <bool INSERT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 4) void k_mcw_ewald(McView v, int32_t molecule, McMolecule nm, const double* __restrict__ trial, int64_t nrows,
+                                                              double* __restrict__ out, int stride, int per_wave)
+{
+    // dynamic LDS: [3 ns 64] doubles (planes A, B, kf) | [nrounds 64] int32 (padded to 16 B) | [WAVES][m][stride] double2 tables
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    __shared__ double s_pos[WAVES][MC_MAX_ATOMS * 3];
+    __shared__ double s_q[MC_MAX_ATOMS];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int first = INSERT ? 0 : v.mol[molecule].x, m = INSERT ? nm.m : v.mol[molecule].y;
+    const size_t plane = (size_t)v.ns * 64;
+    double* cA = reinterpret_cast<double*>(s_raw);
+    double* cB = cA + plane;
+    double* ckf = cB + plane;
+    int32_t* s_desc = reinterpret_cast<int32_t*>(ckf + plane);
+    const size_t ndesc = ((size_t)v.nrounds * 64 + 3) & ~(size_t)3;
+    double2* tab = reinterpret_cast<double2*>(s_desc + ndesc) + (size_t)wave * m * stride;
+    if (tid < m) {
+        int kind, mol;
+        if (INSERT) kind = nm.kinds[tid];
+        else unpack(v.atoms[first + tid].w, kind, mol);
+        s_q[tid] = v.kind_charge[kind];
+    }
+    {   // staged once per workgroup
+        const double2* mine = v.sf_mol + (size_t)(INSERT ? 0 : molecule) * v.nk;
+        for (size_t t = tid; t < plane; t += 64 * WAVES) {
+            const int q = v.qof[t];
+            double a = 0.0, b = 0.0, k = 0.0;
+            if (q >= 0) {
+                const double2 f = v.sf_fw[q], tot = v.sf_tot[q];
+                const double2 old = INSERT ? make_double2(0.0, 0.0) : mine[q];
+                k = v.kf[q];
+                a = k * (f.x + (tot.x - old.x));          // rest = framework + (sums[:,1] - sums[:,ij+1])
+                b = k * (f.y + (tot.y - old.y));
+            }
+            cA[t] = a; cB[t] = b; ckf[t] = k;
+        }
+        for (int t = tid; t < v.nrounds * 64; t += 64 * WAVES) s_desc[t] = v.desc[t];
+    }
+    __syncthreads();
+    const int nxp = v.ks[0] + 1, nyp = 2 * v.ks[1] + 1;
+    const int64_t p0 = ((int64_t)blockIdx.x * WAVES + wave) * per_wave;
+    const int64_t p1 = p0 + per_wave < nrows ? p0 + per_wave : nrows;
+    double* pos = s_pos[wave];
+    for (int64_t row = p0; row < p1; ++row) {
+        double rs = 0.0, ss = 0.0;
+        if (!INSERT && row == 0) {
+            // positions === nothing (ewald.jl:731): the stored sums[:, ij+1] of the molecule
+            const double2* mine = v.sf_mol + (size_t)molecule * v.nk;
+            for (int q = lane; q < v.nk; q += 64) {
+                const double2 old = mine[q], f = v.sf_fw[q], t = v.sf_tot[q];
+                const double rr = f.x + (t.x - old.x), ri = f.y + (t.y - old.y);
+                const double kf = v.kf[q];
+                rs += kf * (rr * old.x + ri * old.y);
+                ss += kf * (old.x * old.x + old.y * old.y);
+            }
+        } else {
+            mcw_load_row<INSERT>(v, first, m, trial, row, lane, pos);
+            fill_tables_wave(v, pos, m, tab, stride, lane, s_q);
+            __builtin_amdgcn_wave_barrier();
+            int slot = 0;
+            for (int r = 0; r < v.nrounds; ++r) {
+                const int d = s_desc[r * 64 + lane];
+                const int L = __builtin_amdgcn_readfirstlane(d >> 27);
+                const size_t at = (size_t)slot * 64 + lane;
+                ceg_rows::round_dispatch(L, m, tab, stride, nxp, nyp, d & 0x1ff, (d >> 9) & 0x1ff, (d >> 18) & 0x1ff, [&](int sidx, double sr, double si) {
+                    const size_t idx = at + (size_t)sidx * 64;
+                    rs += cA[idx] * sr + cB[idx] * si;
+                    ss += ckf[idx] * (sr * sr + si * si);
+                });
+                slot += L;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            rs += __shfl_xor(rs, o);
+            ss += __shfl_xor(ss, o);
+        }
+        if (lane == 0) out[4 * (size_t)row + 3] = 2.0 * rs + ss;
+        __builtin_amdgcn_wave_barrier();                           // pos / tab are rewritten for the next placement
+    }
+}
+
+template <bool FAST, bool INSERT, bool CELLS>
+__global__ __launch_bounds__(64 * MCW_WAVES, (FAST && CELLS) ? 3 : 4) void k_mcw_pairs(McView v, McCompact ct, int32_t molecule, McMolecule nm, const double* __restrict__ trial,
+                                                                 int64_t nrows, double* __restrict__ out, int per_wave)
+{
+    // dynamic LDS (ct.in_lds): the compact pair table: fast records, rules, offsets
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    __shared__ double s_pos[MCW_WAVES][MC_MAX_ATOMS * 3];
+    __shared__ int s_first[CELLS ? MCW_WAVES : 1][64], s_cell[CELLS ? MCW_WAVES : 1][64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int first = INSERT ? 0 : v.mol[molecule].x, m = INSERT ? nm.m : v.mol[molecule].y;
+    const DevRule* rules = ct.rules;
+    const int32_t* offset = ct.off;
+    const McFastPair* fastp = ct.fast;
+    if (ct.in_lds) {
+        McFastPair* s_fast = reinterpret_cast<McFastPair*>(s_raw);
+        DevRule* s_rules = reinterpret_cast<DevRule*>(s_fast + (size_t)v.nkinds * m);
+        int32_t* s_off = reinterpret_cast<int32_t*>(s_rules + (ct.nrules > 0 ? ct.nrules : 1));
+        for (int t = tid; t < v.nkinds * m; t += 64 * MCW_WAVES) s_fast[t] = ct.fast[t];
+        for (int t = tid; t < ct.nrules; t += 64 * MCW_WAVES) s_rules[t] = ct.rules[t];
+        for (int t = tid; t < v.nkinds * m + 1; t += 64 * MCW_WAVES) s_off[t] = ct.off[t];
+        rules = s_rules;
+        offset = s_off;
+        fastp = s_fast;
+    }
+    __syncthreads();
+    // unsafe_periodic_distance2! (utils.jl:294-302) measures the ONE image with fractional difference in [-1/2, 1/2).  With every
+    // perpendicular width above 2 cutoff a pair whose fractional difference is within rounding of +-1/2 lies beyond the cutoff under
+    // either image, so the wrap may be done as f - rint(f) with fused multiply-adds (30 instructions instead of 50); only a pair
+    // within 1e-9 of the cutoff itself (where the truncated potentials jump) is measured again with the reference's operation order.
+    const bool fastwrap = FAST && v.fastwrap != 0;
+    const double band = 1e-9 * v.cutoff2;
+    const int64_t p0 = ((int64_t)blockIdx.x * MCW_WAVES + wave) * per_wave;
+    const int64_t p1 = p0 + per_wave < nrows ? p0 + per_wave : nrows;
+    double* pos = s_pos[wave];
+    const double* M = v.mat;
+    const double* I = v.invmat;
+    for (int64_t row = p0; row < p1; ++row) {
+        mcw_load_row<INSERT>(v, first, m, trial, row, lane, pos);
+        double inter = 0.0;
+        auto pairs_with = [&](const double4 A) __attribute__((always_inline)) {
+            int kind1, mol;
+            unpack(A.w, kind1, mol);
+            if (mol < 0 || (!INSERT && mol == molecule)) return;            // energy.jl:419 (and free slots)
+            for (int a = 0; a < m; ++a) {
+                const double dx = pos[3 * a] - A.x, dy = pos[3 * a + 1] - A.y, dz = pos[3 * a + 2] - A.z;
+                auto literal = [&]() -> double {
+#pragma clang fp contract(off)
+                    double f0 = I[0] * dx + I[3] * dy + I[6] * dz;
+                    double f1 = I[1] * dx + I[4] * dy + I[7] * dz;
+                    double f2 = I[2] * dx + I[5] * dy + I[8] * dz;
+                    f0 = ((f0 + 0.5) - floor(f0 + 0.5)) - 0.5;
+                    f1 = ((f1 + 0.5) - floor(f1 + 0.5)) - 0.5;
+                    f2 = ((f2 + 0.5) - floor(f2 + 0.5)) - 0.5;
+                    const double vx = M[0] * f0 + M[3] * f1 + M[6] * f2;
+                    const double vy = M[1] * f0 + M[4] * f1 + M[7] * f2;
+                    const double vz = M[2] * f0 + M[5] * f1 + M[8] * f2;
+                    return vx * vx + vy * vy + vz * vz;
+                };
+                double r2;
+                if (fastwrap) {
+                    double f0 = __builtin_fma(I[6], dz, __builtin_fma(I[3], dy, I[0] * dx));
+                    double f1 = __builtin_fma(I[7], dz, __builtin_fma(I[4], dy, I[1] * dx));
+                    double f2 = __builtin_fma(I[8], dz, __builtin_fma(I[5], dy, I[2] * dx));
+                    f0 -= __builtin_rint(f0);
+                    f1 -= __builtin_rint(f1);
+                    f2 -= __builtin_rint(f2);
+                    const double vx = __builtin_fma(M[6], f2, __builtin_fma(M[3], f1, M[0] * f0));
+                    const double vy = __builtin_fma(M[7], f2, __builtin_fma(M[4], f1, M[1] * f0));
+                    const double vz = __builtin_fma(M[8], f2, __builtin_fma(M[5], f1, M[2] * f0));
+                    r2 = __builtin_fma(vz, vz, __builtin_fma(vy, vy, vx * vx));
+                    if (fabs(r2 - v.cutoff2) <= band) r2 = literal();       // the cutoff decision is the reference's
+                } else {
+                    r2 = literal();
+                }
+                if (!(r2 < v.cutoff2)) continue;                            // :422
+                const int t = kind1 * m + a;
+                if (FAST && r2 >= 0.25) {
+                    double r, rinv;
+                    ceg::fast_sqrt_rsqrt(r2, r, rinv);
+                    const McFastPair P = fastp[t];
+                    if (P.cls) {
+                        const double q2 = P.sigma2 * (rinv * rinv);
+                        const double x6 = q2 * q2 * q2;
+                        double e = __builtin_fma(P.c4eps * x6, x6 - 1.0, -P.shift);
+                        if (P.qq != 0.0) {
+                            const double x = P.alpha * r;
+                            e = __builtin_fma(P.qq * rinv, ceg::fast_exp_neg(-(x * x)) * ceg::erfcx_poly(x), e);
+                        }
+                        inter += e;
+                    } else {
+                        for (int q = offset[t]; q < offset[t + 1]; ++q) inter += rule_energy_fast(rules[q], r2, r, rinv, v.coulombic);
+                    }
+                } else {
+                    for (int q = offset[t]; q < offset[t + 1]; ++q) inter += rule_energy_call(&rules[q], r2, v.coulombic);
+                }
+            }
+        };
+        if (!CELLS) {
+            for (int l = lane; l < v.natoms; l += 64) pairs_with(v.atoms[l]);
+        } else {
+            // only the cells the cutoff spheres of the molecule's atoms can reach (ceg_consumers.h); every lane works the range out
+            int bin0[3], nbin[3];
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) ceg_consumers::cell_range(I, pos, m, ax, v.nb[ax], v.hfrac[ax], bin0[ax], nbin[ax]);
+            const int n1 = nbin[1], n2 = nbin[2];
+            const int ncell = nbin[0] * n1 * n2;
+            for (int base = 0; base < ncell; base += 64) {
+                const int e = base + lane;
+                int cnt = 0, cell = 0;
+                if (e < ncell) {
+                    const int j2 = e % n2, j1 = (e / n2) % n1, j0 = e / (n2 * n1);
+                    int c0 = bin0[0] + j0, c1 = bin0[1] + j1, c2 = bin0[2] + j2;
+                    if (c0 >= v.nb[0]) c0 -= v.nb[0];
+                    if (c1 >= v.nb[1]) c1 -= v.nb[1];
+                    if (c2 >= v.nb[2]) c2 -= v.nb[2];
+                    cell = (c0 * v.nb[1] + c1) * v.nb[2] + c2;
+                    cnt = v.cell_count[cell];
+                }
+                int incl = cnt;                                            // inclusive scan over the wave
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int up = __shfl_up(incl, o);
+                    if (lane >= o) incl += up;
+                }
+                const int total = __shfl(incl, 63);
+                s_first[CELLS ? wave : 0][lane] = incl - cnt;
+                s_cell[CELLS ? wave : 0][lane] = cell;
+                __builtin_amdgcn_wave_barrier();
+                for (int l = lane; l < total; l += 64) {
+                    int j = 0;                                             // last cell whose first entry is <= l
+#pragma unroll
+                    for (int step = 32; step > 0; step >>= 1)
+                        if (s_first[CELLS ? wave : 0][j + step] <= l) j += step;
+                    pairs_with(v.cells[(size_t)s_cell[CELLS ? wave : 0][j] * v.cell_cap + (l - s_first[CELLS ? wave : 0][j])]);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) inter += __shfl_xor(inter, o);
+        if (lane == 0) out[4 * (size_t)row + 2] = inter;
+        __builtin_amdgcn_wave_barrier();                           // pos is rewritten for the next placement
+    }
+}
+
 // update_mc! for a displacement (montecarlo.jl:615-628): positions; sums[:,1] += new - sums[:,ij+1]; sums[:,ij+1] = new
 __global__ __launch_bounds__(MC_THREADS) void k_mc_accept(McView v, int32_t molecule, McPositions np, McCellOps ops, int stride)
 {
@@ -359,18 +772,17 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_accept(McView v, int32_t mole
     if (v.use_cells) apply_cell_ops(v, ops, tid);
     if (v.nk == 0) return;
     double2* tab = reinterpret_cast<double2*>(s_raw);
-    fill_tables(v, s_pos, m, tab, stride, tid, MC_THREADS);
+    fill_tables(v, s_pos, m, tab, stride, tid, MC_THREADS, s_q);
     __syncthreads();
     double2* mine = v.sf_mol + (size_t)molecule * v.nk;
-    for (int64_t q = tid; q < v.nk; q += MC_THREADS) {
-        const double2 S = molecule_sf(v, tab, stride, s_q, m, q);
+    rows_structure_factor(v, tab, stride, m, tid >> 6, MC_THREADS / 64, tid & 63, [&](int q, double sr, double si) {
         const double2 old = mine[q];
         double2 t = v.sf_tot[q];
-        t.x += S.x - old.x;
-        t.y += S.y - old.y;
+        t.x += sr - old.x;
+        t.y += si - old.y;
         v.sf_tot[q] = t;
-        mine[q] = S;
-    }
+        mine[q] = make_double2(sr, si);
+    });
 }
 
 // sums[:, ij+1] of every molecule from its current positions (one workgroup per molecule)
@@ -390,10 +802,11 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_sf_molecules(McView v, int st
     }
     __syncthreads();
     double2* tab = reinterpret_cast<double2*>(s_raw);
-    fill_tables(v, s_pos, m, tab, stride, tid, MC_THREADS);
+    fill_tables(v, s_pos, m, tab, stride, tid, MC_THREADS, s_q);
     __syncthreads();
     double2* mine = v.sf_mol + (size_t)molecule * v.nk;
-    for (int64_t q = tid; q < v.nk; q += MC_THREADS) mine[q] = molecule_sf(v, tab, stride, s_q, m, q);
+    rows_structure_factor(v, tab, stride, m, tid >> 6, MC_THREADS / 64, tid & 63,
+                          [&](int q, double sr, double si) { mine[q] = make_double2(sr, si); });
 }
 
 // sums[:, 1] = sum over the molecules, in molecule order
@@ -428,17 +841,16 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_insert(McView v, int32_t mole
     if (v.use_cells) apply_cell_ops(v, ops, tid);
     if (v.nk == 0) return;
     double2* tab = reinterpret_cast<double2*>(s_raw);
-    fill_tables(v, s_pos, m, tab, stride, tid, MC_THREADS);
+    fill_tables(v, s_pos, m, tab, stride, tid, MC_THREADS, s_q);
     __syncthreads();
     double2* mine = v.sf_mol + (size_t)molecule * v.nk;
-    for (int64_t q = tid; q < v.nk; q += MC_THREADS) {
-        const double2 S = molecule_sf(v, tab, stride, s_q, m, q);
+    rows_structure_factor(v, tab, stride, m, tid >> 6, MC_THREADS / 64, tid & 63, [&](int q, double sr, double si) {
         double2 t = v.sf_tot[q];
-        t.x += S.x;
-        t.y += S.y;
+        t.x += sr;
+        t.y += si;
         v.sf_tot[q] = t;
-        mine[q] = S;
-    }
+        mine[q] = make_double2(sr, si);
+    });
 }
 
 // remove_one_system! (ewald.jl:794-810, :404-413): sums[:,1] -= sums[:,ij+1]; the LAST molecule takes index `molecule`
@@ -618,6 +1030,13 @@ struct ceg_mc {
     double4* d_cells = nullptr;
     int32_t* d_cell_count = nullptr;
     int stride = 0;
+    // row-wise k-vector layout (ceg_rows.h) and, per distinct molecule (tuple of atom kinds), the pair-table rows of its kinds
+    int32_t *d_desc = nullptr, *d_qof = nullptr;
+    std::vector<DevRule> h_rules;
+    std::vector<int32_t> h_offset;
+    std::vector<int32_t> h_kind;                 // kind per atom slot (host copy)
+    struct Compact { DevRule* d_rules = nullptr; int32_t* d_off = nullptr; void* d_fast = nullptr; int32_t nrules = 0; };
+    std::map<std::vector<int32_t>, Compact> compact;
     // pinned, device-mapped staging for small batches; device scratch for large ones
     double *h_in = nullptr, *h_out = nullptr, *dm_in = nullptr, *dm_out = nullptr;
     double *d_in = nullptr, *d_out = nullptr;
@@ -722,6 +1141,15 @@ extern "C" int ceg_mc_create(ceg_mc_t** handle, int32_t device, ceg_interp_t* co
               upload(&h->d_ijk, kvec_ijk, (size_t)(3 * nk)) && upload(&h->d_kf, kfactors, (size_t)nk) &&
               upload(&h->d_fw, fw.data(), (size_t)nk) && upload(&h->d_tot, fw.data(), (size_t)nk);
     ok = ok && hipMemset(h->d_tot, 0, sizeof(double2) * (size_t)(nk > 0 ? nk : 1)) == hipSuccess;
+    {
+        const ceg_rows::Layout lay = ceg_rows::choose_layout(kvec_ijk, nk, nk > 0 ? ks : v.ks);
+        std::vector<int32_t> qof((size_t)std::max(lay.ns, 1) * 64, -1);
+        for (int64_t q = 0; q < nk; ++q) qof[(size_t)lay.slot_of[(size_t)q]] = (int32_t)q;
+        v.nrounds = lay.nrounds; v.ns = lay.ns;
+        ok = ok && upload(&h->d_desc, lay.desc.data(), lay.desc.size()) && upload(&h->d_qof, qof.data(), qof.size());
+    }
+    h->h_rules.assign(dr.begin(), dr.begin() + (nr > 0 ? nr : 0));
+    h->h_offset.assign(rule_offset, rule_offset + nt + 1);
     ok = ok && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&h->h_in, MC_MAPPED_BYTES, hipHostMallocMapped) == hipSuccess &&
          hipHostMalloc((void**)&h->h_out, MC_MAPPED_BYTES, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
@@ -737,6 +1165,7 @@ extern "C" int ceg_mc_create(ceg_mc_t** handle, int32_t device, ceg_interp_t* co
     }
     v.vdw = h->d_vdw; v.kind_charge = h->d_charge; v.rules = h->d_rules; v.rule_offset = h->d_offset;
     v.ijk = h->d_ijk; v.kf = h->d_kf; v.sf_fw = h->d_fw; v.sf_tot = h->d_tot;
+    v.desc = h->d_desc; v.qof = h->d_qof;
     {
         CellMirror& cm = h->cm;
         cm.bins = ceg_consumers::choose_cell_bins(invmat, cutoff);
@@ -744,6 +1173,7 @@ extern "C" int ceg_mc_create(ceg_mc_t** handle, int32_t device, ceg_interp_t* co
         for (int a = 0; a < 9; ++a) cm.invmat[a] = invmat[a];
         cm.on = cm.bins.on != 0;
         v.use_cells = cm.on ? 1 : 0;
+        v.fastwrap = (cm.bins.hfrac[0] < 0.5 * (1.0 - 1e-6) && cm.bins.hfrac[1] < 0.5 * (1.0 - 1e-6) && cm.bins.hfrac[2] < 0.5 * (1.0 - 1e-6)) ? 1 : 0;
         if (cm.on) {
             cm.members.assign((size_t)cm.ncells(), {});
             if (int rc = rebuild_cells(h)) { ceg_mc_destroy(h); return rc; }
@@ -766,6 +1196,13 @@ extern "C" int ceg_mc_destroy(ceg_mc_t* h)
         if (h->h_out) (void)hipHostFree(h->h_out);
         if (h->h_flag) (void)hipHostFree(h->h_flag);
         if (h->d_done) (void)hipFree(h->d_done);
+        if (h->d_desc) (void)hipFree(h->d_desc);
+        if (h->d_qof) (void)hipFree(h->d_qof);
+        for (auto& kv : h->compact) {
+            if (kv.second.d_rules) (void)hipFree(kv.second.d_rules);
+            if (kv.second.d_off) (void)hipFree(kv.second.d_off);
+            if (kv.second.d_fast) (void)hipFree(kv.second.d_fast);
+        }
     }
     delete h;
     return CEG_OK;
@@ -850,6 +1287,121 @@ int rebuild_cells(ceg_mc* h)
 
 size_t tables_bytes(const ceg_mc* h, int m) { return sizeof(double2) * (size_t)m * (size_t)h->stride; }
 
+// the pair-table rows of the kinds of one molecule: entry (kind1, a) -> the rules of (kind1, kinds[a]); built once per distinct
+// molecule and kept on the device (a handful per run: one per species)
+const ceg_mc::Compact* compact_table(ceg_mc* h, const int32_t* kinds, int m)
+{
+    std::vector<int32_t> key(kinds, kinds + m);
+    auto it = h->compact.find(key);
+    if (it != h->compact.end()) return &it->second;
+    const int nkinds = h->v.nkinds;
+    std::vector<int32_t> off((size_t)nkinds * m + 1, 0);
+    std::vector<DevRule> rules;
+    std::vector<McFastPair> fast((size_t)nkinds * m);
+    for (int k1 = 0; k1 < nkinds; ++k1)
+        for (int a = 0; a < m; ++a) {
+            const size_t t = (size_t)k1 * nkinds + kinds[a];
+            // at most one Lennard-Jones and one CoulombEwaldDirect term (and NoInteraction): the whole entry is one branch-free record
+            // (v - shift summed in another order than the rule loop: inside the 1e-9 of the pair sum, like the rest of the fast path)
+            McFastPair P{0.0, 0.0, 0.0, 0.0, 0.0, 1, 0};
+            int nlj = 0, nced = 0;
+            for (int32_t q = h->h_offset[t]; q < h->h_offset[t + 1]; ++q) {
+                const DevRule& R = h->h_rules[(size_t)q];
+                rules.push_back(R);
+                if (R.kind == CEG_LENNARDJONES && nlj == 0) { P.c4eps = 4.0 * R.p0; P.sigma2 = R.p1 * R.p1; P.shift += R.shift; ++nlj; }
+                else if (R.kind == CEG_COULOMB_EWALD_DIRECT && nced == 0) { P.alpha = R.p0; P.qq = h->v.coulombic * R.p1 * R.p2; P.shift += R.shift; ++nced; }
+                else if (R.kind == CEG_NOINTERACTION) P.shift += R.shift;
+                else P.cls = 0;
+            }
+            fast[(size_t)k1 * m + a] = P;
+            off[(size_t)k1 * m + a + 1] = (int32_t)rules.size();
+        }
+    ceg_mc::Compact c;
+    c.nrules = (int32_t)rules.size();
+    McFastPair* d_fast = nullptr;
+    if (!upload(&c.d_rules, rules.data(), rules.size()) || !upload(&c.d_off, off.data(), off.size()) || !upload(&d_fast, fast.data(), fast.size())) {
+        if (c.d_rules) (void)hipFree(c.d_rules);
+        if (c.d_off) (void)hipFree(c.d_off);
+        if (d_fast) (void)hipFree(d_fast);
+        return nullptr;
+    }
+    c.d_fast = d_fast;
+    return &h->compact.emplace(std::move(key), c).first->second;
+}
+
+// rows from which a batch goes to the wave-per-placement kernels (CEG_HIP_MC_WAVE_MIN overrides; 0 = always, a huge value = never)
+int64_t wave_kernel_min_rows()
+{
+    if (const char* e = std::getenv("CEG_HIP_MC_WAVE_MIN")) return std::atoll(e);
+    return 2048;        // measured cross-over (64 CO2 in CHA, 1368 k-vectors): 1024 rows 56 vs 60 us, 2048 rows 80 vs 74 us, 65 536 rows 1520 vs 690 us
+}
+
+// placements per wave: amortise what a workgroup stages, but keep every CU busy (>= ~2048 workgroups when the batch allows it)
+int rows_per_wave(int64_t rows, int waves, int most)
+{
+    int per_wave = most;
+    while (per_wave > 1 && rows / ((int64_t)per_wave * waves) < 2048) per_wave >>= 1;
+    return per_wave;
+}
+
+// large batch: one wave per placement, one launch per term (k_mcw_frame, k_mcw_ewald, k_mcw_pairs)
+int launch_wave_kernels(ceg_mc* h, bool insert, int32_t molecule, const McMolecule& nm, int m, const double* d_in, int64_t rows, double* d_out)
+{
+    const McView& v = h->v;
+    const int32_t* kinds = insert ? nm.kinds : h->h_kind.data() + h->h_mol[molecule].x;
+    const ceg_mc::Compact* ctab = compact_table(h, kinds, m);
+    if (!ctab) return merr(CEG_ERR_HIP, "could not upload the pair-table rows of the molecule");
+    {   // framework_interactions
+        const int per_wave = rows_per_wave(rows, MCW_WAVES, 4);
+        const int64_t nb = (rows + (int64_t)MCW_WAVES * per_wave - 1) / ((int64_t)MCW_WAVES * per_wave);
+        if (insert) hipLaunchKernelGGL(k_mcw_frame<true>, dim3((unsigned)nb), dim3(64 * MCW_WAVES), 0, h->stream, v, molecule, nm, d_in, rows, d_out, per_wave);
+        else hipLaunchKernelGGL(k_mcw_frame<false>, dim3((unsigned)nb), dim3(64 * MCW_WAVES), 0, h->stream, v, molecule, nm, d_in, rows, d_out, per_wave);
+    }
+    if (v.nk > 0) {   // single_contribution_ewald
+        const size_t c_bytes = sizeof(double) * 3 * (size_t)v.ns * 64 + sizeof(int32_t) * ((((size_t)v.nrounds * 64) + 3) & ~(size_t)3);
+        int waves = 8;
+        while (waves > 1 && c_bytes + (size_t)waves * tables_bytes(h, m) > 72 * 1024) waves >>= 1;
+        const size_t lds = c_bytes + (size_t)waves * tables_bytes(h, m);
+        if (lds > 150 * 1024) return merr(CEG_ERR_UNSUPPORTED, "k-space tables do not fit in LDS");
+        const int per_wave = rows_per_wave(rows, waves, 8);
+        const int64_t nb = (rows + (int64_t)waves * per_wave - 1) / ((int64_t)waves * per_wave);
+#define CEG_MCW_E(I, W) hipLaunchKernelGGL((k_mcw_ewald<I, W>), dim3((unsigned)nb), dim3(64 * W), lds, h->stream, v, molecule, nm, d_in, rows, d_out, h->stride, per_wave)
+#define CEG_MCW_EW(I)                        \
+    do {                                     \
+        if (waves == 8) CEG_MCW_E(I, 8);     \
+        else if (waves == 4) CEG_MCW_E(I, 4); \
+        else if (waves == 2) CEG_MCW_E(I, 2); \
+        else CEG_MCW_E(I, 1);                \
+    } while (0)
+        if (insert) CEG_MCW_EW(true);
+        else CEG_MCW_EW(false);
+#undef CEG_MCW_EW
+#undef CEG_MCW_E
+    } else {
+        // no Ewald summation: column 3 is zero
+        if (hipMemset2DAsync(d_out + 3, 4 * sizeof(double), 0, sizeof(double), (size_t)rows, h->stream) != hipSuccess) return merr(CEG_ERR_HIP, "memset failed");
+    }
+    {   // single_contribution_vdw
+        const size_t ct_full = sizeof(McFastPair) * (size_t)v.nkinds * m + sizeof(DevRule) * (size_t)std::max(ctab->nrules, 1) +
+                               sizeof(int32_t) * ((size_t)v.nkinds * m + 1);
+        McCompact ct{ctab->d_rules, ctab->d_off, static_cast<const McFastPair*>(ctab->d_fast), ctab->nrules, ct_full <= 32 * 1024 ? 1 : 0};
+        const size_t lds = ct.in_lds ? ct_full : 0;
+        const int per_wave = rows_per_wave(rows, MCW_WAVES, 4);
+        const int64_t nb = (rows + (int64_t)MCW_WAVES * per_wave - 1) / ((int64_t)MCW_WAVES * per_wave);
+#define CEG_MCW_P(F, I, CL) hipLaunchKernelGGL((k_mcw_pairs<F, I, CL>), dim3((unsigned)nb), dim3(64 * MCW_WAVES), lds, h->stream, v, ct, molecule, nm, d_in, rows, d_out, per_wave)
+#define CEG_MCW_PICK(CL)                                                                      \
+    do {                                                                                      \
+        if (insert) { if (v.fast) CEG_MCW_P(true, true, CL); else CEG_MCW_P(false, true, CL); }   \
+        else { if (v.fast) CEG_MCW_P(true, false, CL); else CEG_MCW_P(false, false, CL); }        \
+    } while (0)
+        if (v.use_cells) CEG_MCW_PICK(true);
+        else CEG_MCW_PICK(false);
+#undef CEG_MCW_PICK
+#undef CEG_MCW_P
+    }
+    return hipGetLastError() == hipSuccess ? CEG_OK : merr(CEG_ERR_HIP, "trial kernel launch failed");
+}
+
 // launch the trial kernel for n placements (INSERT: of a molecule that is not in the system) and bring the rows back
 int run_trial(ceg_mc* h, bool insert, int32_t molecule, const McMolecule& nm, int m, const double* trial, int64_t n, double* out)
 {
@@ -883,6 +1435,13 @@ int run_trial(ceg_mc* h, bool insert, int32_t molecule, const McMolecule& nm, in
         if (hipMemcpyAsync(h->d_in, trial, in_bytes, hipMemcpyHostToDevice, h->stream) != hipSuccess) return merr(CEG_ERR_HIP, "H2D failed");
         d_in = h->d_in;
         d_out = h->d_out;
+    }
+    if (rows >= wave_kernel_min_rows()) {
+        if (int rc = launch_wave_kernels(h, insert, molecule, nm, m, d_in, rows, d_out)) return rc;
+        if (!mapped && hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return merr(CEG_ERR_HIP, "D2H failed");
+        if (hipStreamSynchronize(h->stream) != hipSuccess) return merr(CEG_ERR_HIP, "trial kernel failed");
+        if (mapped) memcpy(out, h->h_out, out_bytes);
+        return CEG_OK;
     }
     McView v = h->v;
     size_t table_bytes = v.table_in_lds ? sizeof(DevRule) * (size_t)(v.nrules > 0 ? v.nrules : 1) + sizeof(int32_t) * ((size_t)v.nkinds * v.nkinds + 1) : 0;
@@ -971,6 +1530,7 @@ extern "C" int ceg_mc_set_guests(ceg_mc_t* h, const double* positions, const int
     if (ok && nmol > 0) ok = hipMemcpy(h->d_molidx, idx.data(), sizeof(int2) * (size_t)nmol, hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) return merr(CEG_ERR_HIP, "could not upload the guest atoms");
     h->h_mol.assign(idx.begin(), idx.begin() + nmol);
+    h->h_kind.assign(kinds, kinds + natoms);
     h->free_runs.assign(MC_MAX_ATOMS + 1, {});
     McView& v = h->v;
     v.natoms = (int32_t)natoms; v.nmol = nmol;
@@ -1070,6 +1630,8 @@ extern "C" int ceg_mc_insert(ceg_mc_t* h, const int32_t* kinds, int32_t m, const
     for (int t = 0; t < 3 * m; ++t) np.xyz[t] = positions[t];
     h->v.nmol += 1;
     h->h_mol.push_back(make_int2(first, m));
+    if ((int64_t)h->h_kind.size() < (int64_t)first + m) h->h_kind.resize((size_t)first + m, 0);
+    for (int a = 0; a < m; ++a) h->h_kind[(size_t)first + a] = nm.kinds[a];
     McCellOps ops{};
     bool rebuild = false;
     if (h->cm.on) {

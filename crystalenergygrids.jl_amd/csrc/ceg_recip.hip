@@ -25,6 +25,7 @@
 
 #include "../../include/ceg_hip.h"
 #include "ceg_math.h"
+#include "ceg_rows.h"
 
 extern "C" void ceg_set_last_error_(const char* msg);
 
@@ -34,7 +35,8 @@ constexpr int MAX_ATOMS = 16;       // atoms per molecule held in LDS
 constexpr int MAX_TAB = 400;        // (kx+1) + (2ky+1) + (2kz+1) per atom
 constexpr int MAX_WAVES = 8;        // placements in flight per workgroup (the constants in LDS are shared: two workgroups = 4 waves per SIMD);
                                     // fewer (4, 2, 1) when the tables of a large molecule / k-space would not fit
-constexpr int SEG = 10;             // k-vectors per segment (structure-factor accumulators a lane holds); the switch in k_recip lists 1..SEG
+using ceg_rows::Layout;
+using ceg_rows::choose_layout;
 
 struct RecipGeom {
     double invmat[9];
@@ -43,39 +45,6 @@ struct RecipGeom {
     double q[MAX_ATOMS];
     double energy_net_charges, static_contribution;
 };
-
-// One round of k_recip for segments of LEN k-vectors: the structure factor of the molecule at (i0 + s, j, k), s < LEN, then the two
-// energy sums with the constants of the round's slots (at[s * 64] of each plane).
-template <int LEN>
-__device__ __forceinline__ void recip_round(const RecipGeom& g, const double2* tab, int tab_stride, int nxp, int nyp, int i0, int jj, int kk,
-                                            const double* cA, const double* cB, const double* ckf, size_t at, double& fa, double& aa)
-{
-    double sr[LEN], si[LEN];
-#pragma unroll
-    for (int s = 0; s < LEN; ++s) sr[s] = si[s] = 0.0;
-    for (int a = 0; a < g.natoms; ++a) {
-        const double2* ta = tab + a * tab_stride;
-        const double2 ey = ta[nxp + jj], ez = ta[nxp + nyp + kk], e1 = ta[nxp > 1 ? 1 : 0];
-        double2 ex = ta[i0];
-        const double cr = ey.x * ez.x - ey.y * ez.y, ci = ey.x * ez.y + ey.y * ez.x;      // c*Eiky*Eikz: the z table carries the charge
-#pragma unroll
-        for (int s = 0; s < LEN; ++s) {
-            sr[s] += ex.x * cr - ex.y * ci;
-            si[s] += ex.x * ci + ex.y * cr;
-            if (s + 1 < LEN) {
-                const double nx = ex.x * e1.x - ex.y * e1.y;
-                ex.y = ex.x * e1.y + ex.y * e1.x;
-                ex.x = nx;
-            }
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < LEN; ++s) {
-        const size_t idx = at + (size_t)s * 64;
-        fa += cA[idx] * sr[s] + cB[idx] * si[s];
-        aa += ckf[idx] * (sr[s] * sr[s] + si[s] * si[s]);
-    }
-}
 
 // g_desc[r * 64 + lane]: segment of `lane` in round r: i0 | (j + ky) << 9 | (k + kz) << 18 | L_r << 27 (nine bits each: MAX_TAB < 512; L_r = longest segment of the
 // round, the same in every lane).  g_c: three planes [ns * 64] of the constants A = kf Re S_f, B = kf Im S_f, kf by (slot, lane):
@@ -143,18 +112,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_recip(RecipGeom g, const int32_t
             const int d = desc[r * 64 + lane];
             const int L = __builtin_amdgcn_readfirstlane(d >> 27);
             const int i0 = d & 0x1ff, jj = (d >> 9) & 0x1ff, kk = (d >> 18) & 0x1ff;
-            switch (L) {        // one branch-free body per round length: the loads of a round are then scheduled ahead of its arithmetic
-            case 1: recip_round<1>(g, tab, tab_stride, nxp, nyp, i0, jj, kk, cA, cB, ckf, (size_t)slot * 64 + lane, fa, aa); break;
-            case 2: recip_round<2>(g, tab, tab_stride, nxp, nyp, i0, jj, kk, cA, cB, ckf, (size_t)slot * 64 + lane, fa, aa); break;
-            case 3: recip_round<3>(g, tab, tab_stride, nxp, nyp, i0, jj, kk, cA, cB, ckf, (size_t)slot * 64 + lane, fa, aa); break;
-            case 4: recip_round<4>(g, tab, tab_stride, nxp, nyp, i0, jj, kk, cA, cB, ckf, (size_t)slot * 64 + lane, fa, aa); break;
-            case 5: recip_round<5>(g, tab, tab_stride, nxp, nyp, i0, jj, kk, cA, cB, ckf, (size_t)slot * 64 + lane, fa, aa); break;
-            case 6: recip_round<6>(g, tab, tab_stride, nxp, nyp, i0, jj, kk, cA, cB, ckf, (size_t)slot * 64 + lane, fa, aa); break;
-            case 7: recip_round<7>(g, tab, tab_stride, nxp, nyp, i0, jj, kk, cA, cB, ckf, (size_t)slot * 64 + lane, fa, aa); break;
-            case 8: recip_round<8>(g, tab, tab_stride, nxp, nyp, i0, jj, kk, cA, cB, ckf, (size_t)slot * 64 + lane, fa, aa); break;
-            case 9: recip_round<9>(g, tab, tab_stride, nxp, nyp, i0, jj, kk, cA, cB, ckf, (size_t)slot * 64 + lane, fa, aa); break;
-            default: recip_round<SEG>(g, tab, tab_stride, nxp, nyp, i0, jj, kk, cA, cB, ckf, (size_t)slot * 64 + lane, fa, aa); break;
-            }
+            const size_t at = (size_t)slot * 64 + lane;
+            ceg_rows::round_dispatch(L, g.natoms, tab, tab_stride, nxp, nyp, i0, jj, kk, [&](int s, double sr, double si) {
+                const size_t idx = at + (size_t)s * 64;
+                fa += cA[idx] * sr + cB[idx] * si;
+                aa += ckf[idx] * (sr * sr + si * si);
+            });
             slot += L;
         }
 #pragma unroll
@@ -190,68 +153,6 @@ struct ceg_recip {
 
 namespace {
 
-// Regroup the flat k-vector list: rows of consecutive i at fixed (j, k), cut into segments of <= seg k-vectors of nearly equal length,
-// sorted by length (longest first) and dealt to the lanes in rounds of 64 -- the segments of one round have nearly the same length,
-// so a round that runs to its longest segment wastes little.  Returns the padded slot count.
-struct Layout {
-    int nrounds = 0, ns = 0;
-    std::vector<int32_t> desc;
-    std::vector<int64_t> slot_of;
-};
-Layout build_layout(const int32_t* ijk, int64_t nk, const int32_t ks[3], int seg)
-{
-    std::map<std::pair<int, int>, std::vector<std::pair<int, int64_t>>> rows;        // (j, k) -> (i, q)
-    for (int64_t q = 0; q < nk; ++q) rows[{ijk[3 * q + 1], ijk[3 * q + 2]}].push_back({ijk[3 * q], q});
-    struct Seg { int j, k, i0, len; std::vector<int64_t> q; };
-    std::vector<Seg> segs;
-    for (auto& kv : rows) {
-        auto& v = kv.second;
-        std::sort(v.begin(), v.end());
-        size_t b = 0;
-        while (b < v.size()) {
-            size_t e = b + 1;
-            while (e < v.size() && v[e].first == v[e - 1].first + 1) ++e;          // run of consecutive i (a repeated i starts a new run)
-            const int len = (int)(e - b), parts = (len + seg - 1) / seg;
-            size_t at = b;
-            for (int part = 0; part < parts; ++part) {
-                const int l = len / parts + (part < len % parts ? 1 : 0);
-                Seg s{kv.first.first, kv.first.second, v[at].first, l, {}};
-                for (int t = 0; t < l; ++t) s.q.push_back(v[at + t].second);
-                segs.push_back(std::move(s));
-                at += l;
-            }
-            b = e;
-        }
-    }
-    std::stable_sort(segs.begin(), segs.end(), [](const Seg& a, const Seg& b) { return a.len > b.len; });
-    Layout out;
-    out.nrounds = (int)((segs.size() + 63) / 64);
-    out.desc.assign((size_t)out.nrounds * 64, 0);
-    out.slot_of.assign((size_t)nk, 0);
-    int slot = 0;
-    for (int r = 0; r < out.nrounds; ++r) {
-        const int L = segs[(size_t)r * 64].len;
-        for (int l = 0; l < 64; ++l) {
-            const size_t si = (size_t)r * 64 + l;
-            const int lane = (r & 1) ? 63 - l : l;
-            int32_t d = (ks[1] << 9) | (ks[2] << 18);                              // padding: j = k = i0 = 0, all constants zero
-            if (si < segs.size()) {
-                const Seg& s = segs[si];
-                d = s.i0 | ((s.j + ks[1]) << 9) | ((s.k + ks[2]) << 18);
-                for (int t = 0; t < s.len; ++t) out.slot_of[(size_t)s.q[t]] = (int64_t)(slot + t) * 64 + lane;
-            }
-            out.desc[(size_t)r * 64 + lane] = d | (L << 27);
-        }
-        slot += L;
-    }
-    out.ns = slot;
-    return out;
-}
-
-// cost model of a layout for the choice of the segment length: per round and atom one Ey Ez q product + table reads (~14 FP64
-// instructions' worth), per slot 8 FMAs per atom + 5 for the energy; two atoms assumed
-double layout_cost(const Layout& l) { return 2.0 * 14.0 * l.nrounds + (2.0 * 8.0 + 5.0) * l.ns; }
-
 int upload_constants(ceg_recip* h, const double* sf_re, const double* sf_im)
 {
     const size_t plane = (size_t)h->ns * 64;
@@ -267,20 +168,6 @@ int upload_constants(ceg_recip* h, const double* sf_re, const double* sf_im)
 }
 
 }  // namespace
-
-// the layout choice of ceg_recip_create, host side only
-static Layout choose_layout(const int32_t* kvec_ijk, int64_t nk, const int32_t ks[3])
-{
-    Layout best;
-    if (nk > 0) {
-        best = build_layout(kvec_ijk, nk, ks, SEG);
-        for (int seg = SEG - 1; seg >= 3; --seg) {                 // shorter segments can fill the last round better
-            Layout l = build_layout(kvec_ijk, nk, ks, seg);
-            if (layout_cost(l) < layout_cost(best)) best = std::move(l);
-        }
-    }
-    return best;
-}
 
 static int check_kspace(const int32_t* kvec_ijk, int64_t nk, const int32_t ks[3])
 {

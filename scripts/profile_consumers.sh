@@ -4,7 +4,8 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/consumers
 mkdir -p $out
-for name in interp recip pairs mc; do
+names=${@:-interp recip pairs mc}
+for name in $names; do
   script=tests/perf/time_$name.py
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${name}_trace -- python $script > $out/${name}_run.log 2>&1 || echo "$name: trace run failed"
   for ctr in FETCH_SIZE WRITE_SIZE; do

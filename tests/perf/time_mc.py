@@ -46,9 +46,25 @@ def bench(nbatch, reps):
     dt = (time.perf_counter() - t) / reps
     return dt, e
 
+if os.environ.get("CEG_TIME_MC_ONLY_BIG"):          # profiling runs: the large batch alone
+    dt = bench(65536, 20)[0]
+    print(f"GPU  batch  65536: {dt * 1e6:9.1f} us per call")
+    dev.close()
+    sys.exit(0)
 for nbatch, reps in ((1, 2000), (16, 1000), (1024, 200), (65536, 10)):
     dt, e = bench(nbatch, reps)
     print(f"GPU  batch {nbatch:6d}: {dt * 1e6:9.1f} us per call (trial launch + every second call an accept) = {dt * 1e6 / nbatch:9.3f} us per trial placement")
+
+# where the wave-per-placement kernels (three launches: k_mcw_frame / k_mcw_ewald / k_mcw_pairs) take over from the
+# workgroup-per-placement kernel (one launch: k_mc_trial): both forced on the same batches
+print("# batch: workgroup-per-placement kernel | wave-per-placement kernels (us per call)")
+for nbatch, reps in ((64, 400), (128, 400), (256, 400), (512, 300), (1024, 200), (2048, 100), (4096, 100), (16384, 30), (65536, 10)):
+    os.environ["CEG_HIP_MC_WAVE_MIN"] = "1000000000"
+    t_group = bench(nbatch, reps)[0]
+    os.environ["CEG_HIP_MC_WAVE_MIN"] = "0"
+    t_wave = bench(nbatch, reps)[0]
+    del os.environ["CEG_HIP_MC_WAVE_MIN"]
+    print(f"GPU  batch {nbatch:6d}: {t_group * 1e6:9.1f} | {t_wave * 1e6:9.1f}")
 
 # roofline.  Algorithmic work of ONE placement of a 3-atom CO2 among 64 CO2 (192 guest atoms), 1368 k-vectors:
 # interpolation 3 atoms x 2 grids x 256 B gathered = 1.5 KB and ~1500 flops; pair sum 3 x 189 tests x 47 + in-cutoff rules ~ 30 kflop;
@@ -58,8 +74,11 @@ for nbatch, reps in ((1, 2000), (16, 1000), (1024, 200), (65536, 10)):
 # cost keeps falling up to batches of ~10^4 placements (the figure to read is the large-batch one).
 dt_big = bench(65536, 10)[0]
 fl = 65537 * (3 * 1368 * 16.0 + 1368 * 10.0 + 3 * 51 * 40.0 + 3 * 189 * 47.0 + 60 * 72.0 + 1500.0)
-print(f"roofline k_mc_trial, batch 65536: ~{fl / 65537 / 1e3:.0f} kflop/placement -> {fl / dt_big / 1e12:.2f} TFLOP/s = {fl / dt_big / 78.6e12:.3f} of the FP64 "
-      f"vector peak; batch 1: latency bound (2 workgroups on 256 CUs)")
+print(f"roofline movement_energy, batch 65536, PER CALL (host arrays in and out: 4.7 MB H2D + 2.1 MB D2H + three launches inside the call): "
+      f"~{fl / 65537 / 1e3:.0f} kflop/placement -> {fl / dt_big / 1e12:.2f} TFLOP/s = {fl / dt_big / 78.6e12:.3f} of the FP64 vector peak; "
+      f"batch 1: latency bound (2 workgroups on 256 CUs)")
+print(f"roofline movement_energy, batch 65536, KERNELS (inputs resident): the same {fl / 1e9:.2f} Gflop / (sum of the average durations of k_mcw_frame + "
+      f"k_mcw_ewald + k_mcw_pairs in a run of the large batch alone: scripts/profile_mc_big.sh) / 78.6 TFLOP/s")
 
 # CPU: the oracle's three sums for the same molecule, one thread, amortised over 2000 placements (no per-call overhead)
 idx = mols[7 % len(mols)]

@@ -322,6 +322,80 @@ def test_mc_insertions_and_removals(hip_lib, tmp_path):
         ceg.setdir_RASPA(Path(__file__).parent / "golden" / "raspa")
 
 
+def test_mc_large_batches_take_the_wave_kernels(hip_lib, tmp_path, monkeypatch):
+    """From 2048 rows on a trial batch runs as three wave-per-placement launches (k_mcw_frame / k_mcw_ewald / k_mcw_pairs: one grid
+    corner per lane, k-space constants staged once per workgroup + row-wise k-vector walk, the pair-table rows of the molecule's
+    kinds in LDS) instead of one workgroup per placement.  Displacement batches (row 0 = the molecule where it is, with its STORED
+    structure factor) and insertion batches of both species, after some accepted moves and an insertion, sampled against the ORACLE's
+    movement_energy (1e-9) and, row for row, against the workgroup-per-placement kernel forced on the same batch (1e-10)."""
+    from ceg_hip.energy import DeviceMonteCarlo
+    from oracle.montecarlo import OracleMonteCarlo
+    try:
+        M, mc = _mc_setup(tmp_path)
+        M.baseline_energy(mc)
+        dev = DeviceMonteCarlo(mc)
+        omc = OracleMonteCarlo.from_setup(mc)
+        omc.compute_ewald()
+        rng = np.random.default_rng(404)
+        base = mc.positions[1][0] - mc.positions[1][0][1]
+        # move things first: accepted displacements and one insertion, so that sums[:, 1] and sums[:, ij+1] are device-updated values
+        for step in range(12):
+            kind = step % 2
+            j = int(rng.integers(len(mc.positions[kind])))
+            new = mc.positions[kind][j] + rng.uniform(-0.6, 0.6, 3)
+            dev.accept((kind, j), new); omc.update((kind, j), new); M.update_mc(mc, (kind, j), new)
+        extra = mc.mat @ np.array([0.41, 0.13, 0.77]) + base @ _rotation(rng).T
+        dev.insert(1, extra); omc.add(1, extra); M.add_molecule(mc, 1, extra)
+
+        def check_rows(rows, refs, what):
+            for t, r in refs.items():
+                ok = np.abs(r) < 1e90
+                assert np.array_equal(rows[t][~ok] >= 1e90, r[~ok] >= 1e90), (what, t, rows[t], r)
+                assert np.all(np.abs(rows[t][ok] - r[ok]) <= 1e-9 * np.abs(r[ok]) + 1e-7), (what, t, rows[t], r)
+
+        def both_paths(call):
+            monkeypatch.setenv("CEG_HIP_MC_WAVE_MIN", "0")
+            wave = call()
+            monkeypatch.setenv("CEG_HIP_MC_WAVE_MIN", "1000000000")
+            group = call()
+            monkeypatch.delenv("CEG_HIP_MC_WAVE_MIN")
+            assert np.array_equal(np.abs(wave) >= 1e90, np.abs(group) >= 1e90)
+            for c in range(4):            # same terms in another order: 1e-10 of the value, floored at 1e-13 of the column's upper quartile
+                ok = (np.abs(group[:, c]) < 1e90) & np.isfinite(group[:, c])
+                scale = float(np.percentile(np.abs(group[ok, c]), 75)) if ok.any() else 0.0
+                err = np.abs(wave[ok, c] - group[ok, c])
+                assert (err <= 1e-10 * np.abs(group[ok, c]) + 1e-13 * scale + 1e-300).all(), (c, float(err.max()), scale)
+            return wave
+
+        n = 3000
+        for kind, j in ((1, 2), (0, 0)):
+            cur = mc.positions[kind][j]
+            trial = cur[None] + rng.uniform(-1.2, 1.2, (n, 1, 3))
+            trial[1::5] = (rng.uniform(-0.5, 1.5, (len(trial[1::5]), 3)) @ mc.mat.T)[:, None, :] + (cur - cur[len(cur) // 2])[None]   # anywhere, also outside the cell
+            if len(cur) > 1:
+                for t in range(0, n, 3):
+                    c = trial[t][1]
+                    trial[t] = c + (trial[t] - c) @ _rotation(rng).T
+            rows = both_paths(lambda: dev.trial((kind, j), trial))
+            assert rows.shape == (n + 1, 4)
+            refs = {0: omc.movement_energy((kind, j))}
+            for t in (0, 1, 6, 511, 512, 1777, n - 1):
+                refs[1 + t] = omc.movement_energy((kind, j), trial[t])
+            check_rows(rows, refs, ("displacement", kind))
+            assert (np.abs(rows[:, 0]) >= 1e90).any() and (np.abs(rows[:, 0]) < 1e90).sum() > n // 4      # blocked and open placements
+            # the default routing: this batch is large enough for the wave kernels, a 64-row one is not -- same numbers either way
+            np.testing.assert_allclose(dev.trial((kind, j), trial[:63])[:, 2:], rows[:64, 2:], rtol=1e-10, atol=1e-7)
+        for kind in (0, 1):
+            shape = np.zeros((1, 3)) if kind == 0 else base
+            trial = (rng.uniform(0, 1, (n, 3)) @ mc.mat.T)[:, None, :] + shape[None]
+            rows = both_paths(lambda: dev.trial_insert(kind, trial))
+            assert rows.shape == (n, 4)
+            check_rows(rows, {t: omc.insertion_energy(kind, trial[t]) for t in (0, 5, 640, n - 1)}, ("insertion", kind))
+        dev.close()
+    finally:
+        ceg.setdir_RASPA(Path(__file__).parent / "golden" / "raspa")
+
+
 def test_mc_handle_refuses_work_after_a_failed_update(hip_lib, tmp_path, monkeypatch):
     """accept / insert / remove change the host mirror before the launch is known to have succeeded; when one of them fails
     after that point (injected: CEG_HIP_MC_INJECT_FAILURE) the handle must refuse every later call -- instead of answering from
