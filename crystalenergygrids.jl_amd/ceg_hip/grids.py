@@ -255,11 +255,17 @@ def create_grid_coulomb(file, framework, forcefield: ForceField, spacing: float,
 def build_multi_arrays(probes, coulomb_probe: Optional[ProbeSystem], alpha: float, cset: GridCoordinatesSetup, ngpus: int = 1,
                        pinned: bool = False):
     """All the grids of one setup from one pass over one lattice-image list (``ceg_grids_multi``): the VdW grid of every probe
-    in ``probes`` (ProbeSystems of the same framework, Lennard-Jones-only: 1..4 of them) and, with ``coulomb_probe``, the
-    Coulomb grid.  -> (list of float32[8, nx, ny, nz], float32[8, nx, ny, nz] or None)."""
+    in ``probes`` (1..4 ProbeSystems of the same framework, of any rule class ``create_grid_vdw`` takes: the library lets the
+    Lennard-Jones-only ones share accumulating loops and launches a Buckingham cation alone or fused with the Coulomb grid) and, with
+    ``coulomb_probe``, the Coulomb grid.  -> (list of float32[8, nx, ny, nz], float32[8, nx, ny, nz] or None)."""
     lib = _abi.load_library()
     probes = list(probes)
     ref = probes[0]
+    for pr in probes[1:] + ([coulomb_probe] if coulomb_probe is not None else []):
+        # one framework, one supercell, one cutoff: the probes differ in their rule tables only (ADVICE r3)
+        if (pr.positions.shape != ref.positions.shape or not np.array_equal(pr.positions, ref.positions) or not np.array_equal(pr.mat, ref.mat)
+                or not np.array_equal(pr.atomkinds, ref.atomkinds) or pr.cutoff2 != ref.cutoff2):
+            raise ValueError("the probes of a multi-probe build must share framework positions, atom kinds, cell and cutoff")
     tables = []
     for pr in probes:
         pr.forcefield.check_vdw_grid(pr.probe, np.unique(pr.atomkinds))
@@ -294,22 +300,43 @@ def create_grids_multi(vdw_files, coulomb_file, framework, forcefield: ForceFiel
     """``create_grid_vdw`` (grids.jl:137-157) for every atom of ``atoms`` and -- with ``coulomb_file`` -- ``create_grid_coulomb``
     (grids.jl:159-185) of one framework in ONE pass: the files are byte-identical in format to the ones the two functions write
     (same header / payload / trailer writer), the payloads come from ``ceg_grids_multi``.  This is the call pattern of
-    setup_RASPA (raspa.jl:497-520) collapsed into one call.  Several atoms share the pass only when each is Lennard-Jones-only against the
-    framework (the library says so otherwise: the caller builds those with ``create_grid_vdw``); a single atom of any rule class
-    shares it with the Coulomb grid."""
+    setup_RASPA (raspa.jl:497-520) collapsed into one call.  The atoms may be of any rule class (Na + the C and O of CO2: round 4).
+
+    Every file is written to a temporary name in its directory and renamed onto the target only after ALL of them are complete:
+    the reference's cache looks no further than ``isfile`` (raspa.jl:426), so a truncated file at the cache path would be
+    "retrieved" by every later setup_RASPA.  On any failure the temporaries are removed and no target is touched."""
     atoms = list(atoms)
     assert len(vdw_files) == len(atoms) and 1 <= len(atoms) <= 4
     cset, num_unitcell = _setup_grid_common(framework, spacing, forcefield.cutoff)
     probes = [ProbeSystem.build(framework, forcefield, a) for a in atoms]
-    pc, alpha, prec = None, 0.0, None
+    pc, alpha, prec, num_unitcell_c = None, 0.0, None, num_unitcell
     if coulomb_file is not None:
-        ewald = _ewald if isinstance(_ewald, EwaldFramework) else initialize_ewald(framework, num_unitcell)
+        _cset_c, num_unitcell_c = _setup_grid_common(framework, spacing, 12.0)        # create_grid_coulomb: 12 A whatever the force field says (grids.jl:160)
+        ewald = _ewald if isinstance(_ewald, EwaldFramework) else initialize_ewald(framework, num_unitcell_c)
         pc, alpha, prec = ProbeSystem.build(framework, forcefield), ewald.alpha, ewald.precision
     vgrids, cgrid = build_multi_arrays(probes, pc, alpha, cset, ngpus)
-    for f, g in zip(vdw_files, vgrids):
-        write_grid_file(f, cset, num_unitcell, g)
+    jobs = [(f, num_unitcell, g, None) for f, g in zip(vdw_files, vgrids)]
     if coulomb_file is not None:
-        write_grid_file(coulomb_file, cset, num_unitcell, cgrid, ewald_precision=prec)
+        jobs.append((coulomb_file, num_unitcell_c, cgrid, prec))
+    tmps = []
+    try:
+        for n, (f, nuc, g, pr) in enumerate(jobs):
+            tmp = f"{os.fspath(f)}.tmp.{os.getpid()}.{n}"
+            tmps.append(tmp)
+            if os.environ.get("CEG_HIP_INJECT_WRITE_FAILURE") == str(n):             # test hook: the n-th file fails half way
+                with open(tmp, "wb") as fh:
+                    fh.write(b"truncated")
+                raise OSError(f"injected failure while writing {tmp}")
+            write_grid_file(tmp, cset, nuc, g, ewald_precision=pr)
+        for tmp, (f, *_rest) in zip(tmps, jobs):
+            os.replace(tmp, f)
+    except BaseException:
+        for tmp in tmps:
+            try:
+                os.unlink(tmp)
+            except OSError:
+                pass
+        raise
     return vgrids, cgrid
 
 

@@ -118,9 +118,9 @@ class MultiGridPlan:
     (``ceg_plan_create_multi``): what ``setup_RASPA`` needs for a molecule -- one ``create_grid_vdw`` per distinct
     guest atom and one ``create_grid_coulomb`` (raspa.jl:497-520) -- from one lattice-image list in one pass.
 
-    ``probes``: ProbeSystems of the same framework (same positions / kinds / cutoff), one per probe atom, every one
-    Lennard-Jones-only against the kinds present when there are several (``_abi.CegError`` with code -5 otherwise: build that probe
-    alone); ONE probe may have any rule class and then shares the fused single-probe pass with the Coulomb grid."""
+    ``probes``: ProbeSystems of the same framework (same positions / kinds / cutoff), one per probe atom, of any rule class
+    ``ceg_plan_create`` takes (round 4): the Lennard-Jones-only probes share accumulating loops, a probe of another class (a
+    Buckingham cation) is launched alone or fused with the Coulomb grid -- all from the one image list."""
     MAX_PROBES = 4
 
     def __init__(self, cset: GridCoordinatesSetup, probes, coulomb: Optional[ProbeSystem] = None, alpha: float = 0.0,

@@ -132,19 +132,15 @@ def setup_RASPA(framework, pff, molecule, ffname_molecule: Optional[str] = None,
     # The reference builds the missing grids one after the other (raspa.jl:497-520: one retrieve_or_create_grid for the
     # Coulomb grid, one per distinct atom of the molecule).  Here every grid that has to be CREATED is collected first and
     # built by one multi-probe call -- one lattice-image list, one pass over the framework (grids.create_grids_multi) --;
-    # retrieve_or_create_grid then finds the files and only parses them.  Lennard-Jones-only atoms go in groups of four; an atom
-    # with another rule class (a Buckingham cation) cannot share accumulating loops with other atoms but still shares its pass
-    # with the Coulomb grid when no Lennard-Jones group takes that; anything the library refuses falls through to the one-by-one path.
+    # retrieve_or_create_grid then finds the files and only parses them.  The atoms go in groups of four whatever their rule
+    # class (round 4: Na + the C and O of CO2 in one call; the library lets the Lennard-Jones-only probes share accumulating loops and
+    # launches a Buckingham cation alone or fused with the Coulomb grid); anything the library refuses falls through to the one-by-one path.
     written = set()                                               # files the multi-probe calls below have just created
     if multi and not isinstance(framework, np.ndarray) and not math.isinf(cutoff) and cutoff == 12.0:
         todo = [i for i, atom in enumerate(rev_atomdict)
                 if vdws[i] and forcefield.needsvdwgrid(atom) and (new or not os.path.isfile(vdws[i]))]
-        missing = [i for i in todo if forcefield.lj_only_probe(rev_atomdict[i], syst_framework)]
-        others = [i for i in todo if i not in missing]
         want_c = bool(needcoulomb and coulomb_grid_path and (new or not os.path.isfile(coulomb_grid_path)))
-        groups = [missing[lo:lo + 4] for lo in range(0, len(missing), 4)]
-        if want_c and not groups and others:
-            groups = [others[:1]]                                 # one probe of any class + the Coulomb grid: the fused single-probe kernel
+        groups = [todo[lo:lo + 4] for lo in range(0, len(todo), 4)]
         for n, part in enumerate(groups):
             with_c = want_c and n == 0
             if len(part) + int(with_c) < 2:

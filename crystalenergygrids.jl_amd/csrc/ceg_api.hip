@@ -115,6 +115,13 @@ struct ceg_plan {
         int32_t* d_offset = nullptr;
         FastVdw* d_fast = nullptr;
         PlanConst* d_pc = nullptr;
+        // the probe's own hot-loop class (round 4: probes of several classes in one plan): 1 Lennard-Jones-only -- shares launches
+        // with other such probes --, 3 one tabulated Buckingham class, 2 / 0 as in an ordinary plan: single-probe launches
+        int vdwk = 0;
+        bool single_buck = false;
+        double bk[4] = {0, 0, 0, 0};
+        double* d_bk2 = nullptr;
+        int32_t* d_imgkind = nullptr;   // per image: kind | "the kind has a rule with THIS probe" (the shared list carries the union)
     };
     int nprobes = 0;             // 0: ordinary plan
     std::vector<ProbeTab> probes;
@@ -769,8 +776,26 @@ int check_common(const double* pos, int64_t natoms, const double* mat, const dou
 
 }  // namespace
 
+// out[i] = kind of image i | META_HASVDW iff has[kind] (the flag bit is bit 25: what build_images sets for the union of the probes)
+__global__ void k_probe_image_flags(const int32_t* __restrict__ kind_union, const int32_t* __restrict__ has, int32_t nkinds, int32_t* __restrict__ out, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t kw = kind_union[i];
+    if (kw < 0) { out[i] = kw; return; }
+    const int32_t k = kw & ((1 << 24) - 1);
+    out[i] = k | ((k < nkinds && has[k]) ? (1 << 25) : 0);
+}
+
+static int probe_image_flags(const int32_t* d_union, const int32_t* d_has, int32_t nkinds, int32_t* d_out, int64_t n)
+{
+    if (n <= 0) return CEG_OK;
+    hipLaunchKernelGGL(k_probe_image_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, d_union, d_has, nkinds, d_out, n);
+    return hipGetLastError() == hipSuccess ? CEG_OK : fail(CEG_ERR_HIP, "image-flag kernel launch failed");
+}
+
 // nprobes == 0: the ordinary plan of ceg_plan_create (rules / rule_offset may be NULL: Coulomb only);
-// nprobes >= 1: a multi-probe plan, mrules / moffset [nprobes], every probe Lennard-Jones-only for the kinds present
+// nprobes >= 1: a multi-probe plan, mrules / moffset [nprobes], probes of any rule class ceg_plan_create takes
 static int create_impl(ceg_plan_t** plan, int32_t device,
                        const double* pos, const int64_t* atomkind, const double* charge,
                        int64_t natoms,
@@ -848,21 +873,28 @@ static int create_impl(ceg_plan_t** plan, int32_t device,
             p->nprobes = nprobes;
             p->probes.resize(nprobes);
             std::vector<int32_t> any(nkinds, 0);
+            double r_exact2 = CEG_R_EXACT2;
             for (int q = 0; q < nprobes; ++q) {
                 if (q > 0)
                     if (int rc = convert_rules(p, mrules[q], moffset[q], nkinds)) { delete p; return rc; }
-                // several probes share accumulating loops written for Lennard-Jones; ONE probe of any rule class (a Buckingham
-                // cation) runs the single-probe kernels and still shares its pass with the Coulomb grid
-                if (nprobes > 1 && (p->vdwk != 1 || p->r_exact2 != CEG_R_EXACT2)) {
-                    delete p;
-                    return fail(CEG_ERR_UNSUPPORTED, "multi-probe plans of several probes take Lennard-Jones-only probes (probe %d has another "
-                                                     "rule class against a framework kind that is present): build that grid with a plan of its own", q);
-                }
+                // Probes of any rule class share the plan (round 4: the grids of Na + CO2, src/raspa.jl:497-520, from one image list).
+                // The Lennard-Jones-only ones share accumulating loops (ceg_plan_build_multi); a probe of another class -- a
+                // Buckingham cation -- runs the single-probe kernels of its class from the same list, alone or fused with the Coulomb grid.
                 ceg_plan::ProbeTab& t = p->probes[q];
                 t.rules = p->h_rules; t.offset = p->h_offset; t.fast = p->h_fast;
+                t.vdwk = p->vdwk; t.single_buck = p->single_buck;
+                for (int c = 0; c < 4; ++c) t.bk[c] = p->bk[c];
+                r_exact2 = std::max(r_exact2, p->r_exact2);          // ONE exact-path radius for the plan: the largest any probe asks for
                 for (int32_t k = 0; k < nkinds; ++k) any[k] |= (t.offset[k + 1] > t.offset[k]) ? 1 : 0;
             }
+            p->r_exact2 = r_exact2;
+            if (!(r_exact2 < p->g.cutoff2)) {
+                delete p;
+                return fail(CEG_ERR_UNSUPPORTED, "a hard sphere of one of the probes reaches the cutoff: build that grid with a plan of its own");
+            }
             p->h_rules = p->probes[0].rules; p->h_fast = p->probes[0].fast;
+            p->vdwk = p->probes[0].vdwk; p->single_buck = p->probes[0].single_buck;
+            for (int c = 0; c < 4; ++c) p->bk[c] = p->probes[0].bk[c];
             p->h_offset_union.assign(nkinds + 1, 0);
             for (int32_t k = 0; k < nkinds; ++k) p->h_offset_union[k + 1] = p->h_offset_union[k] + any[k];
             p->h_offset = p->probes[0].offset;
@@ -920,12 +952,17 @@ static int create_impl(ceg_plan_t** plan, int32_t device,
         rc = upload(&p->d_fast, p->h_fast.data(), p->h_fast.size());
         hc.fastvdw = p->d_fast;
         p->fast_ewald = false;
-        if (!rc && ((p->has_charge && std::isfinite(alpha) && alpha > 0) || p->vdwk == 2)) {
+        bool any_vdwk2 = p->vdwk == 2;
+        for (const auto& t : p->probes) any_vdwk2 = any_vdwk2 || t.vdwk == 2;
+        if (!rc && ((p->has_charge && std::isfinite(alpha) && alpha > 0) || any_vdwk2)) {
             std::vector<double> tab, e2;
             double inv_h = 0, mx0 = 0;
             const bool want_ewald = p->has_charge && std::isfinite(alpha) && alpha > 0;
             const bool ok = build_ewald_tables(want_ewald ? alpha : 0.25, cutoff2, tab, e2, &inv_h, &mx0);
             if (!ok && p->vdwk == 2) p->vdwk = 0;       // no exp table: Buckingham stays on the generic path
+            if (!ok)
+                for (auto& t : p->probes)
+                    if (t.vdwk == 2) t.vdwk = 0;
             if (ok) {
                 rc = upload(&p->d_erfcx, tab.data(), tab.size());
                 if (!rc) rc = upload(&p->d_exp2, e2.data(), e2.size());
@@ -949,22 +986,24 @@ static int create_impl(ceg_plan_t** plan, int32_t device,
                 }
             }
         }
-        if (!rc && p->vdwk == 2 && p->single_buck && !std::getenv("CEG_HIP_NO_BK2")) {
+        // the r^2-indexed table of ONE Buckingham class (VDWK = 3): G0/C, the hot loop accumulates the channels divided by C, 6C, -48C,
+        // 480C (ceg_kernels.hip); `target` receives the table and its scalar constants
+        auto setup_bk2 = [&](int& vdwk, bool single_buck, const double bk[4], double** d_tab, PlanConst& target) {
+            if (rc || vdwk != 2 || !single_buck || std::getenv("CEG_HIP_NO_BK2")) return;
             std::vector<double> tb;
             int32_t base = 0, ni = 0;
-            // the table holds G0/C: the hot loop accumulates the channels divided by C, 6C, -48C, 480C (ceg_kernels.hip)
-            if (build_bk2_table(p->bk[0] / p->bk[2], p->bk[1], 1.0, p->r_exact2, cutoff2, tb, &base, &ni)) {
-                rc = upload(&p->d_bk2, tb.data(), tb.size());
-                hc.bk2_tab = p->d_bk2;
-                hc.bk2_ni = ni;
-                hc.bk2_base = base;
-                const double B = p->bk[1], C = p->bk[2];
-                hc.bk_B = B; hc.bk_C = C; hc.bk_invC = 1.0 / C; hc.bk_nshift = -p->bk[3] / C;
-                hc.bk_c1 = -B / 6.0; hc.bk_c2 = -B / 48.0; hc.bk_c3 = B * B / 3.0; hc.bk_c4 = -B / 160.0;
-                hc.bk_s1 = 1.0 / (6.0 * C); hc.bk_s2 = -1.0 / (48.0 * C); hc.bk_s3 = 1.0 / (480.0 * C);
-                if (!rc) p->vdwk = 3;
-            }
-        }
+            if (!build_bk2_table(bk[0] / bk[2], bk[1], 1.0, p->r_exact2, cutoff2, tb, &base, &ni)) return;
+            rc = upload(d_tab, tb.data(), tb.size());
+            target.bk2_tab = *d_tab;
+            target.bk2_ni = ni;
+            target.bk2_base = base;
+            const double B = bk[1], C = bk[2];
+            target.bk_B = B; target.bk_C = C; target.bk_invC = 1.0 / C; target.bk_nshift = -bk[3] / C;
+            target.bk_c1 = -B / 6.0; target.bk_c2 = -B / 48.0; target.bk_c3 = B * B / 3.0; target.bk_c4 = -B / 160.0;
+            target.bk_s1 = 1.0 / (6.0 * C); target.bk_s2 = -1.0 / (48.0 * C); target.bk_s3 = 1.0 / (480.0 * C);
+            if (!rc) vdwk = 3;
+        };
+        if (p->nprobes == 0) setup_bk2(p->vdwk, p->single_buck, p->bk, &p->d_bk2, hc);
         if (!rc && p->nprobes > 0) {
             // (without the r^2-indexed Ewald tables -- alpha * cutoff > 5, or a fit that misses its tolerance -- the Coulomb grid is
             //  built by its own launch with the erfcx / libm-grade arithmetic and only the VdW grids share a pass: ceg_plan_build_multi)
@@ -978,10 +1017,33 @@ static int create_impl(ceg_plan_t** plan, int32_t device,
                 hc.fastm[q] = t.d_fast;
             }
             for (int q = 0; q < p->nprobes && !rc; ++q) {        // the block with probe q in the single-probe slots
+                ceg_plan::ProbeTab& t = p->probes[q];
                 PlanConst hq = hc;
                 hq.rt = hc.rtm[q];
                 hq.fastvdw = hc.fastm[q];
-                rc = upload(&p->probes[q].d_pc, &hq, 1);
+                setup_bk2(t.vdwk, t.single_buck, t.bk, &t.d_bk2, hq);
+                // per image: does ITS kind have a rule with this probe?  The shared list carries the union of the probes (what the
+                // launches of several Lennard-Jones probes stage by); a single-probe launch drops / declasses the images that are
+                // inactive for its probe -- the tabulated Buckingham class carries no per-candidate parameters that could be zero.
+                if (!rc && p->nprobes > 1) {
+                    std::vector<int32_t> has((size_t)p->nkinds);
+                    for (int32_t k = 0; k < p->nkinds; ++k) has[k] = t.offset[k + 1] > t.offset[k] ? 1 : 0;
+                    int32_t* d_has = nullptr;
+                    rc = upload(&d_has, has.data(), has.size());
+                    if (!rc) {
+                        void* raw = nullptr;
+                        const int64_t n = p->ib.nimages;
+                        if (cached_malloc(&raw, sizeof(int32_t) * (size_t)std::max<int64_t>(n, 1)) != hipSuccess) rc = fail(CEG_ERR_HIP, "hipMalloc failed");
+                        else {
+                            t.d_imgkind = (int32_t*)raw;
+                            rc = probe_image_flags(p->d_imgkind, d_has, p->nkinds, t.d_imgkind, n);
+                        }
+                    }
+                    if (d_has) { (void)hipDeviceSynchronize(); cached_free(d_has); }
+                    hq.ib.kind = t.d_imgkind;
+                }
+                if (!rc) rc = upload(&t.d_pc, &hq, 1);
+                if (q == 0) { p->vdwk = t.vdwk; }
             }
             hc.rt = hc.rtm[0];
             hc.fastvdw = hc.fastm[0];
@@ -1036,7 +1098,7 @@ extern "C" int ceg_plan_destroy(ceg_plan_t* p)
                       (void*)p->d_exp2, (void*)p->d_fast, (void*)p->d_ew2, (void*)p->d_bk2})
         cached_free(ptr);
     for (auto& t : p->probes)
-        for (void* ptr : {(void*)t.d_rules, (void*)t.d_offset, (void*)t.d_fast, (void*)t.d_pc}) cached_free(ptr);
+        for (void* ptr : {(void*)t.d_rules, (void*)t.d_offset, (void*)t.d_fast, (void*)t.d_pc, (void*)t.d_bk2, (void*)t.d_imgkind}) cached_free(ptr);
     delete p;
     return CEG_OK;
 }
@@ -1179,11 +1241,11 @@ extern "C" int ceg_plan_build_multi(ceg_plan_t* p, double lambda_vdw, double thr
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSuccess;
     const int ewk = p->ew2 ? 2 : (p->fast_ewald ? 1 : 0);        // real-space Ewald arithmetic available to this plan
-    auto single = [&](int mode, int q) {          // one probe (q >= 0) and / or the Coulomb grid: the single-probe kernels
+    auto single = [&](int mode, int q) {          // one probe (q >= 0) and / or the Coulomb grid: the single-probe kernels of the probe's class
         Output o = base;
         o.vdw = q >= 0 ? d_out_vdw[q] : nullptr;
         o.coulomb = mode != MODE_VDW ? d_out_coulomb : nullptr;
-        return launch_culled(mode, q >= 0 ? p->probes[q].d_pc : p->d_pc, p->g, p->nprobes == 1 ? p->vdwk : 1, ewk, o, Points{nullptr, 0}, st);
+        return launch_culled(mode, q >= 0 ? p->probes[q].d_pc : p->d_pc, p->g, q >= 0 ? p->probes[q].vdwk : 1, ewk, o, Points{nullptr, 0}, st);
     };
     auto multi = [&](int mode, const int* idx, int np) {
         Output o = base;
@@ -1191,22 +1253,35 @@ extern "C" int ceg_plan_build_multi(ceg_plan_t* p, double lambda_vdw, double thr
         o.coulomb = mode == MODE_FUSED ? d_out_coulomb : nullptr;
         return launch_culled_multi(mode, np, p->d_pc, p->g, o, st);
     };
-    size_t at = 0;
+    // the Lennard-Jones-only probes can share accumulating loops; a probe of another class launches alone (or fused with the Coulomb grid)
+    std::vector<int> lj, other;
+    for (int q : req) (p->probes[q].vdwk == 1 ? lj : other).push_back(q);
     if (d_out_coulomb) {
         int fused_np = CEG_MAX_PROBES_FUSED;          // probes that share the Coulomb launch (CEG_HIP_MULTI_FUSED_NP = 0 | 1 | 2: measurement aid)
         if (const char* env = std::getenv("CEG_HIP_MULTI_FUSED_NP")) fused_np = std::max(0, std::min(CEG_MAX_PROBES_FUSED, atoi(env)));
-        fused_np = std::min<int>(fused_np, (int)req.size());
         if (!p->ew2 && p->nprobes > 1) fused_np = 0;  // the fused multi-probe variants are built on the r^2-indexed tables
-        if (fused_np >= 2) e = multi(MODE_FUSED, &req[0], 2);
-        else if (fused_np == 1) e = single(MODE_FUSED, req[0]);
-        else e = single(MODE_COULOMB, -1);
-        at = (size_t)std::min(fused_np, 2);
+        // what rides with the Coulomb grid, by what it saves on the roofline workload (profiles/r04_multi_probe_timing.txt): two
+        // Lennard-Jones probes (25.3 -> 18.1 ms), else one probe of another class (18.2 -> 15.5 ms), else one Lennard-Jones probe
+        if (fused_np >= 2 && lj.size() >= 2) {
+            e = multi(MODE_FUSED, &lj[0], 2);
+            lj.erase(lj.begin(), lj.begin() + 2);
+        } else if (fused_np >= 1 && !other.empty()) {
+            e = single(MODE_FUSED, other[0]);
+            other.erase(other.begin());
+        } else if (fused_np >= 1 && !lj.empty()) {
+            e = single(MODE_FUSED, lj[0]);
+            lj.erase(lj.begin());
+        } else {
+            e = single(MODE_COULOMB, -1);
+        }
     }
-    while (e == hipSuccess && at < req.size()) {
-        const int n = (int)std::min<size_t>(CEG_MAX_PROBES, req.size() - at);
-        e = n == 1 ? single(MODE_VDW, req[at]) : multi(MODE_VDW, &req[at], n);
+    size_t at = 0;
+    while (e == hipSuccess && at < lj.size()) {
+        const int n = (int)std::min<size_t>(CEG_MAX_PROBES, lj.size() - at);
+        e = n == 1 ? single(MODE_VDW, lj[at]) : multi(MODE_VDW, &lj[at], n);
         at += (size_t)n;
     }
+    for (size_t t = 0; e == hipSuccess && t < other.size(); ++t) e = single(MODE_VDW, other[t]);
     if (e != hipSuccess) return fail(CEG_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     return CEG_OK;
 }

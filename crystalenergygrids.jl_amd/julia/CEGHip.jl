@@ -185,9 +185,12 @@ end
 # ------------------------------------------------------------------ all the grids of a setup in one pass
 # setup_RASPA (src/raspa.jl:497-520) calls retrieve_or_create_grid once for the Coulomb grid and once per distinct atom of the
 # molecule; each call that has to CREATE its grid runs a full pass over the framework.  ceg_grids_multi (include/ceg_hip.h)
-# builds the VdW grids of up to 4 Lennard-Jones probes and the Coulomb grid from one lattice-image list in one pass.
+# builds the VdW grids of up to 4 probes OF ANY RULE CLASS (round 4: Na + the C and O of CO2) and the Coulomb grid from one
+# lattice-image list: the Lennard-Jones-only probes share accumulating loops, a Buckingham cation is launched alone or fused with the
+# Coulomb grid.  (These multi-probe paths -- create_grids_multi, prebuild_grids!, result_array, interp_handle_from_file -- have never been
+# executed: no Julia in the build image; tests/test_boundary_static.py checks ccall names and arities only.)
 
-"True when `atom` meets every kind present in `probe` with at most one Lennard-Jones rule (what ceg_grids_multi accepts)."
+"True when `atom` meets every kind present in `probe` with at most one Lennard-Jones rule (such probes share accumulating loops; informational)."
 function lj_only(ff::ForceField, probe::Int, kinds)
     for k in unique(kinds)
         real = [r for r in _rules(ff.interactions[k, probe]) if r.kind !== FF.NoInteraction && r.kind !== FF.CoulombEwaldDirect]
@@ -236,33 +239,48 @@ end
 """
     create_grids_multi(vdw_files, coulomb_file, framework, forcefield, spacing, atoms, _ewald=nothing)
 
-`create_grid_vdw` (src/grids.jl:137-157) for every atom of `atoms` (2 to 4 Lennard-Jones-only ones, or 1 of any rule class) and, unless
-`coulomb_file === nothing`, `create_grid_coulomb` (:159-185) in one GPU pass; the files are written by the reference's own lines.
+`create_grid_vdw` (src/grids.jl:137-157) for every atom of `atoms` (1 to 4, of any rule class) and, unless
+`coulomb_file === nothing`, `create_grid_coulomb` (:159-185) in one GPU pass; the files are written by the reference's own lines --
+each to a temporary name in its directory, renamed onto the target only when ALL are complete (the cache of src/raspa.jl:426 looks no
+further than `isfile`: a truncated file at a cache path would be "retrieved" ever after); on failure the temporaries are removed.
 """
 function create_grids_multi(vdw_files, coulomb_file, framework::AbstractSystem{3}, forcefield::ForceField, spacing::TÅ, atoms::Vector{Symbol}, _ewald=nothing)
     cset, num_unitcell = CEG._setup_grid_common(framework, spacing, forcefield.cutoff)
     newgrid() = result_array(cset)
     probes = [ProbeSystem(framework, forcefield, atom) for atom in atoms]
     vgrids = [newgrid() for _ in atoms]
-    if coulomb_file === nothing
-        fill_grids_multi!(vgrids, nothing, probes, nothing, nothing, cset)
-    else
-        ewald = _ewald isa EwaldFramework ? _ewald : CEG.initialize_ewald(framework, num_unitcell)
-        cgrid = newgrid()
-        fill_grids_multi!(vgrids, cgrid, probes, ProbeSystem(framework, forcefield), ewald, cset)
-        open(coulomb_file, "w") do f
-            CEG._create_grid_common(f, cset, num_unitcell)
-            write(f, ewald.precision)
-            write(f, cgrid)
-            write(f, NoUnits.(cset.cell.mat./u"Å"))
+    tmps = String[]
+    targets = String[]
+    try
+        if coulomb_file === nothing
+            fill_grids_multi!(vgrids, nothing, probes, nothing, nothing, cset)
+        else
+            _, num_unitcell_c = CEG._setup_grid_common(framework, spacing, 12.0u"Å")       # src/grids.jl:160: 12 Å whatever the force field says
+            ewald = _ewald isa EwaldFramework ? _ewald : CEG.initialize_ewald(framework, num_unitcell_c)
+            cgrid = newgrid()
+            fill_grids_multi!(vgrids, cgrid, probes, ProbeSystem(framework, forcefield), ewald, cset)
+            tmp = string(coulomb_file, ".tmp.", getpid(), ".c")
+            push!(tmps, tmp); push!(targets, String(coulomb_file))
+            open(tmp, "w") do f
+                CEG._create_grid_common(f, cset, num_unitcell_c)
+                write(f, ewald.precision)
+                write(f, cgrid)
+                write(f, NoUnits.(cset.cell.mat./u"Å"))
+            end
         end
-    end
-    for (file, grid) in zip(vdw_files, vgrids)
-        open(file, "w") do f
-            CEG._create_grid_common(f, cset, num_unitcell)
-            write(f, grid)
-            write(f, NoUnits.(cset.cell.mat./u"Å"))
+        for (n, (file, grid)) in enumerate(zip(vdw_files, vgrids))
+            tmp = string(file, ".tmp.", getpid(), ".", n)
+            push!(tmps, tmp); push!(targets, String(file))
+            open(tmp, "w") do f
+                CEG._create_grid_common(f, cset, num_unitcell)
+                write(f, grid)
+                write(f, NoUnits.(cset.cell.mat./u"Å"))
+            end
         end
+        foreach(((t, f),) -> mv(t, f; force=true), zip(tmps, targets))
+    catch
+        foreach(t -> rm(t; force=true), tmps)
+        rethrow()
     end
     nothing
 end
@@ -272,8 +290,7 @@ end
 
 Call with the arguments of `setup_RASPA` (src/raspa.jl:472-531) right before it: every grid that `setup_RASPA` would have to
 create -- same paths (`grid_locations`, :403-419), same conditions (`retrieve_or_create_grid`, :420-439) -- is created here by
-`create_grids_multi`, four probes at a time; `setup_RASPA` then only retrieves.  An atom that is not Lennard-Jones-only
-(a Buckingham cation) shares its pass with the Coulomb grid when no Lennard-Jones group does, and is left to `create_grid_vdw` otherwise.
+`create_grids_multi`, four probes at a time whatever their rule classes; `setup_RASPA` then only retrieves.
 """
 function prebuild_grids!(framework, pff, syst_mol; gridstep=0.15u"Å", supercell=nothing, new=false, cutoff=12.0u"Å")
     (framework isa AbstractMatrix || isinf(cutoff) || cutoff != 12.0u"Å") && return nothing
@@ -283,14 +300,9 @@ function prebuild_grids!(framework, pff, syst_mol; gridstep=0.15u"Å", supercell
     atoms = unique(syst_mol[:,:atomic_symbol])
     coulomb_grid_path, vdws = CEG.grid_locations(framework, pff, forcefield, atoms, gridstep, supercell)
     needcoulomb = any(!iszero(syst_mol[i,:atomic_charge])::Bool for i in 1:length(syst_mol))
-    kinds = ProbeSystem(syst_framework, forcefield).atomkinds
     todo = [i for (i, atom) in enumerate(atoms) if CEG.needsvdwgrid(forcefield, atom) && (new || !isfile(vdws[i]))]
-    islj(i) = lj_only(forcefield, forcefield.sdict[Symbol(CEG.get_atom_name(atoms[i]))], kinds)   # sdict keys as in src/probes.jl:23,59
-    lj = filter(islj, todo)
     want_c = needcoulomb && (new || !isfile(coulomb_grid_path))
-    groups = [lj[lo:min(lo+3, length(lj))] for lo in 1:4:length(lj)]
-    # one atom of another rule class (a Buckingham cation) still shares its pass with the Coulomb grid (fused single-probe kernel)
-    isempty(groups) && want_c && any(!islj, todo) && (groups = [[first(filter(!islj, todo))]])
+    groups = [todo[lo:min(lo+3, length(todo))] for lo in 1:4:length(todo)]
     for (n, part) in enumerate(groups)
         with_c = want_c && n == 1
         length(part) + with_c < 2 && continue

@@ -261,16 +261,19 @@ CEG_API int ceg_plan_build_fused(ceg_plan_t* plan,
  *
  *   nprobes       1 .. 4 (CEG_MAX_PROBES)
  *   rules[q], rule_offset[q]   the flattened column ff.interactions[:, probe_q] as for ceg_plan_create (same nkinds for all).
- *                 With nprobes > 1 every probe must be Lennard-Jones-only against the framework kinds that are present (at most
- *                 one LJ rule per kind; NoInteraction / CoulombEwaldDirect count as none) -- CEG_ERR_UNSUPPORTED otherwise.  A
- *                 plan of ONE probe takes any rule class ceg_plan_create takes (a Buckingham / hard-sphere cation): its VdW
- *                 grid and the Coulomb grid then come out of one pass of the fused single-probe kernel.  charge may be NULL
- *                 (VdW grids only).
+ *                 Every probe may be of any rule class ceg_plan_create takes (round 4: Na + the C and O of CO2 are one plan).  The
+ *                 probes that are Lennard-Jones-only against the framework kinds that are present (at most one LJ rule per kind;
+ *                 NoInteraction / CoulombEwaldDirect count as none) share accumulating loops -- two of them with the Coulomb grid,
+ *                 up to four in a VdW launch --; a probe of another class (a Buckingham / hard-sphere cation) is launched alone with
+ *                 the kernel of its class, or fused with the Coulomb grid when no Lennard-Jones pair takes that place: all from the
+ *                 plan's one image list, bins and function tables.  The exact-path radius of the plan is the largest any probe
+ *                 asks for (hard spheres); CEG_ERR_UNSUPPORTED only if that reaches the cutoff.  charge may be NULL (VdW grids only).
  *   d_out_vdw     [nprobes] device pointers, NULL entries are skipped; d_out_coulomb may be NULL.  Layout, channel_stride,
  *                 i_begin / i_end / i_origin, lambda / threshold and the asynchronous stream semantics as ceg_plan_build_*.
  *
  * Every grid is bit-identical to the one the same call produces when it is asked for that grid alone (identical per-pair
- * arithmetic and summation order, whatever the grouping into launches); against a single-probe plan of ceg_plan_create the
+ * arithmetic whatever the grouping into launches; candidates that contribute exact zeros may be staged in one launch and
+ * dropped in another, which leaves the FP64 sums unchanged); against a single-probe plan of ceg_plan_create the
  * values agree to the last bits of the FP64 sums (a VdW-only single-probe plan lists fewer images, which reorders the sums).
  * The ordinary ceg_plan_build_vdw / _coulomb / _fused calls work on a multi-probe plan too and use probe 0.
  */
@@ -285,7 +288,7 @@ CEG_API int ceg_plan_create_multi(ceg_plan_t** plan, int32_t device,
 CEG_API int ceg_plan_num_probes(const ceg_plan_t* plan);    /* 0 for an ordinary plan */
 /* One-shot form (what the Julia binding calls once per setup_RASPA): host arrays out, grids_vdw [nprobes] (NULL entries skipped),
  * grid_coulomb may be NULL; the x-slabs are spread over `ngpus` devices and every device pipelines compute / D2H / host copy as
- * ceg_grid_vdw does.  Several probes of which one is not Lennard-Jones-only -> CEG_ERR_UNSUPPORTED and nothing is written. */
+ * ceg_grid_vdw does.  Probes of any rule class, as for ceg_plan_create_multi. */
 CEG_API int ceg_grids_multi(const double* pos, const int64_t* atomkind, const double* charge, int64_t natoms,
                     const double mat[9], const double invmat[9], int32_t ortho, double safemin2, double cutoff2,
                     int32_t nprobes, const ceg_rule_t* const* rules, const int32_t* const* rule_offset, int32_t nkinds, double alpha,

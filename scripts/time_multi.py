@@ -1,7 +1,8 @@
 """Kernel times of the multi-probe build (ceg_plan_build_multi) against the separate builds it replaces:
     python scripts/time_multi.py [reps]
 CO2 (C_co2 + O_co2 + Coulomb) in the CHA fixture at 0.15 A (the reference's default spacing) and on the roofline workload
-(11 664 atoms x 256^3); three and four probes on the latter."""
+(11 664 atoms x 256^3); three and four probes on the latter; round 4: probes of SEVERAL rule classes in one plan -- Na
+(Buckingham + hard sphere) + the C and O of CO2 in CIT-7 (the setup of runtests.jl:240-258) and on the roofline workload, CO2 + Ar in CHA."""
 import os, sys
 here = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [os.path.join(here, '..', 'crystalenergygrids.jl_amd'), os.path.join(here, '..')]
@@ -69,3 +70,9 @@ case("roofline workload", ("C_co2", "O_co2", "N_n2"), lambda a: W.roofline_workl
 case("roofline workload", ("C_co2", "O_co2", "N_n2", "Ar"), lambda a: W.roofline_workload(a, 255))
 # one probe of another rule class (Na: Buckingham + hard sphere): a one-probe plan shares the fused single-probe pass with the Coulomb grid
 case("roofline workload", ("Na",), lambda a: W.roofline_workload(a, 255))
+# round 4: mixed rule classes in one plan / one call (with CEG_HIP_MULTI_FUSED_NP = 2: Lennard-Jones pair fused with the Coulomb grid + the
+# cation alone; 1: cation fused with the Coulomb grid + the Lennard-Jones pair in one VdW launch; 0: Coulomb alone + VdW launches)
+case("CIT-7 fixture @ 0.15 A, Na + CO2 (runtests.jl:240-258)", ("Na", "C_co2", "O_co2"), lambda a: W.fixture_workload("CIT-7", a, 0.15))
+case("roofline workload, Na + CO2", ("Na", "C_co2", "O_co2"), lambda a: W.roofline_workload(a, 255))
+case("CHA fixture @ 0.15 A, CO2 + Ar", ("C_co2", "O_co2", "Ar"), lambda a: W.fixture_workload("CHA_1.4_3b4eeb96", a, 0.15))
+case("roofline workload, CO2 + Ar", ("C_co2", "O_co2", "Ar"), lambda a: W.roofline_workload(a, 255))

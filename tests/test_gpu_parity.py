@@ -1197,12 +1197,18 @@ def _probe_set(fwname, atoms, spacing=None, dims=None, tile=None):
     ("CHA_1.4_3b4eeb96", ("C_co2", "O_co2"), 0.45),                       # CO2 in CHA: the reference's own test molecule (2 VdW + Coulomb)
     ("CHA_1.4_3b4eeb96_Na_11812", ("Ar", "C_co2", "O_co2", "N_n2"), 0.7),  # four probes; Na cations in the framework: a second LJ kind
     ("CIT-7", ("O_co2", "Ar", "C_co2"), 0.4),                             # triclinic 2x3x3 supercell, three probes
+    ("CIT-7", ("Na", "C_co2", "O_co2"), 0.4),                             # MIXED classes (round 4): the Na + CO2 setup of runtests.jl:240-258 --
+                                                                          # a tabulated Buckingham cation beside two Lennard-Jones probes
+    ("CHA_1.4_3b4eeb96", ("C_co2", "O_co2", "Ar"), 0.45),                 # CO2 + Ar in CHA: three Lennard-Jones probes + Coulomb in one call
+    ("CHA_1.4_3b4eeb96", ("Ar", "Na", "O_co2", "Na"), 0.7),               # the Buckingham probe neither first nor alone (and listed twice)
 ])
 def test_multi_probe_build(hip_lib, oracle, fwname, atoms, spacing):
     """ceg_plan_create_multi / ceg_plan_build_multi: the K VdW grids + the Coulomb grid of one framework from one image list in one
     call (raspa.jl:497-520 asks for them one by one).  (1) every grid within the suite's tolerance of the oracle; (2) every grid
     BIT-identical to the one the same plan produces when asked for that grid alone, and to any other grouping of the request into
-    launches (fused pair + VdW rest, VdW only, one by one); (3) slabs with i_origin, skipped outputs."""
+    launches (fused pair + VdW rest, VdW only, one by one); (3) slabs with i_origin, skipped outputs.  Probes of several rule
+    classes share the plan (round 4): the Lennard-Jones-only ones share accumulating loops, a Buckingham cation is launched with
+    the kernel of its class, alone or fused with the Coulomb grid."""
     import torch
     from ceg_hip.plan import MultiGridPlan
     w, probes = _probe_set(fwname, atoms, spacing)
@@ -1261,12 +1267,31 @@ def test_multi_probe_build(hip_lib, oracle, fwname, atoms, spacing):
     plan.close()
 
 
-def test_multi_probe_plan_rejects_non_lj_probes(hip_lib):
-    from ceg_hip.plan import MultiGridPlan
-    w, probes = _probe_set("CHA_1.4_3b4eeb96", ("Ar", "Na"), 0.7)
-    with pytest.raises(_abi.CegError) as ei:
-        MultiGridPlan(w.cset, probes, w.probe_coulomb, w.alpha)
-    assert ei.value.code == -5 and "Lennard-Jones" in str(ei.value)
+def test_mixed_class_probes_through_the_one_shot_call(hip_lib, oracle):
+    """ceg_grids_multi (the one-shot C entry point the Julia shim binds) with probes of several rule classes -- refused until round 3
+    (CEG_ERR_UNSUPPORTED), one call now: Na (Buckingham + hard sphere) + C_co2 + O_co2 + Coulomb in CIT-7, the reference's own
+    Na + CO2 setup (runtests.jl:240-258, raspa.jl:497-520); every grid against the oracle with no floor on channel 0, and
+    bit-identical on 1 and 3 (oversubscribed) slabs."""
+    atoms = ("Na", "C_co2", "O_co2")
+    w, probes = _probe_set("CIT-7", atoms, 0.5)
+    vg, cg = G.build_multi_arrays(probes, w.probe_coulomb, w.alpha, w.cset)
+    lam, thr = G.vdw_scaling()
+    for a, pr, g in zip(atoms, probes, vg):
+        compare_grids(g, oracle.grid_vdw(pr, w.cset, lam, thr)[0], f"one-shot mixed / {a}", floor0=0.0)
+    lam, thr = G.coulomb_scaling()
+    compare_grids(cg, oracle.grid_coulomb(w.probe_coulomb, w.alpha, w.cset, lam, thr)[0], "one-shot mixed / coulomb", floor0=0.0)
+    assert (vg[0][0] == np.float32(2e7)).any()                       # the hard sphere of Na clamps
+    os.environ["CEG_HIP_OVERSUBSCRIBE"] = "1"
+    try:
+        v3, c3 = G.build_multi_arrays(probes, w.probe_coulomb, w.alpha, w.cset, ngpus=3)
+    finally:
+        os.environ.pop("CEG_HIP_OVERSUBSCRIBE", None)
+    for a, b in zip(vg + [cg], v3 + [c3]):
+        assert np.array_equal(a.view(np.int32), b.view(np.int32))
+    # probes that do not share a framework are refused on the host side
+    other = W.fixture_workload("CHA_1.4_3b4eeb96", "Ar", 0.7)
+    with pytest.raises(ValueError):
+        G.build_multi_arrays([probes[0], other.probe_vdw], None, 0.0, w.cset)
 
 
 def test_one_probe_of_any_rule_class_shares_the_pass_with_the_coulomb_grid(hip_lib, oracle):
@@ -1340,6 +1365,20 @@ def test_setup_raspa_builds_missing_grids_in_one_pass(hip_lib, oracle, tmp_path)
         finally:
             SR.create_grids_multi = real
         assert len(calls) == 1 and len(calls[0]) == 1, calls
+        # the multi path never leaves a truncated file at a cache path: the second of the two files fails half way ->
+        # neither target is touched, no temporary stays behind, and the next call builds both
+        from ceg_hip.raspa import getdir_RASPA
+        raspa = Path(getdir_RASPA())
+        before = {p: p.read_bytes() for p in (raspa / "grids").rglob("*") if p.is_file()}
+        assert len(before) >= 2
+        os.environ["CEG_HIP_INJECT_WRITE_FAILURE"] = "1"
+        try:
+            with pytest.raises(OSError):
+                ceg.setup_RASPA("CIT-7", "BoulfelfelSholl2021", "Na", gridstep=0.6, new=True)
+        finally:
+            os.environ.pop("CEG_HIP_INJECT_WRITE_FAILURE", None)
+        after = {p: p.read_bytes() for p in (raspa / "grids").rglob("*") if p.is_file()}
+        assert after == before, sorted(str(x) for x in set(after) ^ set(before))
         na1 = ceg.setup_RASPA("CIT-7", "BoulfelfelSholl2021", "Na", gridstep=0.6, new=True, multi=False)
         assert na.grids[0].grid.shape[0] == 8 and np.isfinite(ceg.energy_point(na, np.array([[3.1, 4.2, 5.3]]))[0])
         compare_grids(np.ascontiguousarray(na.grids[0].grid), np.ascontiguousarray(na1.grids[0].grid), "Na VdW: shared pass vs one by one", sentinel=1.9e7 * ceg.GRID_TO_KELVIN, floor0=0.0)
