@@ -1346,7 +1346,7 @@ inline void slab(int nx, int n, int d, int* begin, int* end)
 }
 
 // ---- pinned staging buffers, kept across calls (page-locking costs more than the copy it serves)
-struct PinnedBuf { void* ptr; size_t bytes; bool busy; };
+struct PinnedBuf { void* ptr; size_t bytes; bool busy; bool user = false; };     // user: handed to a caller by ceg_host_grid_alloc
 std::mutex g_pinned_mutex;
 std::vector<PinnedBuf> g_pinned;
 
@@ -1437,7 +1437,7 @@ void pinned_release(void* ptr)
 {
     std::lock_guard<std::mutex> lock(g_pinned_mutex);
     for (auto& p : g_pinned)
-        if (p.ptr == ptr) p.busy = false;
+        if (p.ptr == ptr) { p.busy = false; p.user = false; }
 }
 
 // copy `nseg` segments in parallel; first touch of a fresh destination is page-fault bound, and the
@@ -2040,13 +2040,34 @@ extern "C" int ceg_grids_multi(const double* pos, const int64_t* atomkind, const
 // plus a second pass by host threads (first touch of fresh pages).  A caller that lets the LIBRARY allocate the result gets
 // page-locked memory (kept in the per-process cache, so the page-locking is paid once) and the pipelines copy every chunk straight
 // to its place: the call is then bounded by the D2H alone.
+// Page-locked result arrays in callers' hands are bounded (CEG_HIP_PINNED_LIMIT_MB, default 4096): a garbage-collected caller (the
+// Julia shim wraps them as Arrays and returns them with a finalizer) cannot pin host memory without limit while its collector has not
+// run yet -- beyond the limit the call fails with CEG_ERR_UNSUPPORTED and the shim falls back to an ordinary array.
 extern "C" float* ceg_host_grid_alloc(const int32_t dims[3])
 {
     if (!dims || dims[0] < 1 || dims[1] < 1 || dims[2] < 1) { (void)fail(CEG_ERR_INVALID, "bad dims"); return nullptr; }
     if (ceg_device_count() <= 0) { (void)fail(CEG_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)"); return nullptr; }
     const size_t bytes = sizeof(float) * 8 * (size_t)(dims[0] + 1) * (size_t)(dims[1] + 1) * (size_t)(dims[2] + 1);
+    size_t limit = (size_t)4096 << 20;
+    if (const char* e = std::getenv("CEG_HIP_PINNED_LIMIT_MB")) limit = (size_t)std::max(0ll, atoll(e)) << 20;
+    {
+        std::lock_guard<std::mutex> lock(g_pinned_mutex);
+        size_t out = 0;
+        for (const auto& p : g_pinned)
+            if (p.busy && p.user) out += p.bytes;
+        if (out + bytes > limit) {
+            (void)fail(CEG_ERR_UNSUPPORTED, "page-locked result arrays in use (%zu MB) + this one (%zu MB) exceed CEG_HIP_PINNED_LIMIT_MB = %zu: "
+                                            "free some (ceg_host_grid_free) or use an ordinary array", out >> 20, bytes >> 20, limit >> 20);
+            return nullptr;
+        }
+    }
     void* p = pinned_acquire(bytes);
-    if (!p) (void)fail(CEG_ERR_HIP, "page-locked allocation of %zu bytes failed", bytes);
+    if (!p) { (void)fail(CEG_ERR_HIP, "page-locked allocation of %zu bytes failed", bytes); return nullptr; }
+    {
+        std::lock_guard<std::mutex> lock(g_pinned_mutex);
+        for (auto& q : g_pinned)
+            if (q.ptr == p) q.user = true;
+    }
     return static_cast<float*>(p);
 }
 

@@ -132,21 +132,35 @@ function fill_grid_coulomb!(grid::Array{Cfloat,4}, probe::ProbeSystem, ewald::Ew
     grid
 end
 
-# Result arrays.  ENV["CEG_HIP_PINNED_RESULT"] = "1": the grid array is page-locked memory of the library (ceg_host_grid_alloc) wrapped as
-# an Array -- the build then copies every chunk D2H straight to its place (256^3 VdW grid: 10.5 instead of 13.6 ms) -- and goes back to the
-# library's cache when the Array is finalized.  Off by default: the memory stays page-locked until Julia's GC collects the Array.
-pinned_results() = get(ENV, "CEG_HIP_PINNED_RESULT", "0") == "1"
+# Result arrays.  By default (round 4) the grid array is page-locked memory of the library (ceg_host_grid_alloc) wrapped as an Array: the
+# build then copies every chunk D2H straight to its place (256^3 VdW grid: 10.5 instead of 13.4 ms, the driver-run figures are in
+# BENCH_r04.json `oneshot`).  The Array goes back to the library's cache when it is finalized, or at once through `release!(grid)` when the
+# caller is done with it (the reference's own caller, retrieve_or_create_grid, src/raspa.jl:420-439, drops the returned array and parses
+# the file it has just written).  The page-locked memory in Julia's hands is BOUNDED by the library (CEG_HIP_PINNED_LIMIT_MB, default
+# 4096 MB): beyond it ceg_host_grid_alloc refuses and an ordinary Array is used, so a collector that has not run yet cannot pin host
+# memory without limit.  ENV["CEG_HIP_PINNED_RESULT"] = "0" turns the page-locked arrays off.
+pinned_results() = get(ENV, "CEG_HIP_PINNED_RESULT", "1") != "0"
+
+_free_pinned(g) = (ccall((:ceg_host_grid_free, LIB[]), Cint, (Ptr{Cfloat},), pointer(g)); nothing)
 
 function result_array(cset::GridCoordinatesSetup)
     dims = (cset.dims[3]+1, cset.dims[2]+1, cset.dims[1]+1, 8)
     pinned_results() || return Array{Cfloat,4}(undef, dims...)
     d = Int32[cset.dims...]
     ptr = GC.@preserve d ccall((:ceg_host_grid_alloc, LIB[]), Ptr{Cfloat}, (Ptr{Int32},), d)
-    ptr == C_NULL && error("libceg_hip: " * unsafe_string(ccall((:ceg_last_error, LIB[]), Cstring, ())))
+    ptr == C_NULL && return Array{Cfloat,4}(undef, dims...)      # over the limit (or no page-locked memory): the ordinary route
     grid = unsafe_wrap(Array, ptr, dims; own=false)
-    finalizer(g -> ccall((:ceg_host_grid_free, LIB[]), Cint, (Ptr{Cfloat},), pointer(g)), grid)
+    finalizer(_free_pinned, grid)
     grid
 end
+
+"""
+    release!(grid)
+
+Hand the page-locked memory behind a grid returned by `create_grid_vdw` / `create_grid_coulomb` back to the library NOW instead of at
+the next garbage collection.  `grid` must not be used afterwards.  A no-op for ordinary arrays.
+"""
+release!(grid::Array{Cfloat,4}) = (finalize(grid); nothing)     # runs (and retires) the finalizer registered by result_array
 
 # The two methods below are the reference's (src/grids.jl:137-185) with the `@threads` loop nest
 # replaced by one call; every other line is unchanged.
@@ -258,7 +272,8 @@ function create_grids_multi(vdw_files, coulomb_file, framework::AbstractSystem{3
             _, num_unitcell_c = CEG._setup_grid_common(framework, spacing, 12.0u"Å")       # src/grids.jl:160: 12 Å whatever the force field says
             ewald = _ewald isa EwaldFramework ? _ewald : CEG.initialize_ewald(framework, num_unitcell_c)
             cgrid = newgrid()
-            fill_grids_multi!(vgrids, cgrid, probes, ProbeSystem(framework, forcefield), ewald, cset)
+            push!(vgrids, cgrid)           # (released with the others below; only the first length(atoms) entries are VdW grids)
+            fill_grids_multi!(vgrids[1:length(atoms)], cgrid, probes, ProbeSystem(framework, forcefield), ewald, cset)
             tmp = string(coulomb_file, ".tmp.", getpid(), ".c")
             push!(tmps, tmp); push!(targets, String(coulomb_file))
             open(tmp, "w") do f
@@ -268,7 +283,7 @@ function create_grids_multi(vdw_files, coulomb_file, framework::AbstractSystem{3
                 write(f, NoUnits.(cset.cell.mat./u"Å"))
             end
         end
-        for (n, (file, grid)) in enumerate(zip(vdw_files, vgrids))
+        for (n, (file, grid)) in enumerate(zip(vdw_files, vgrids[1:length(atoms)]))
             tmp = string(file, ".tmp.", getpid(), ".", n)
             push!(tmps, tmp); push!(targets, String(file))
             open(tmp, "w") do f
@@ -281,6 +296,8 @@ function create_grids_multi(vdw_files, coulomb_file, framework::AbstractSystem{3
     catch
         foreach(t -> rm(t; force=true), tmps)
         rethrow()
+    finally
+        foreach(release!, vgrids)          # nothing is returned: the page-locked arrays go back to the library at once
     end
     nothing
 end

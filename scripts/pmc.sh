@@ -77,9 +77,8 @@ if all(v is not None for v in f64) and "lane_util" in summ:
 root = os.environ.get("GRAFT_REPO_ROOT", ".")
 h = hashlib.sha256()
 csrc = os.path.join(root, "crystalenergygrids.jl_amd", "csrc")
-for fn in sorted(os.listdir(csrc)):
-    if fn.endswith((".hip", ".h")) or fn == "Makefile":
-        h.update(fn.encode()); h.update(open(os.path.join(csrc, fn), "rb").read())
+for fn in ("Makefile", "ceg_api.hip", "ceg_internal.h", "ceg_kernels.hip", "ceg_math.h", "ceg_minimage.h"):     # = bench.py GRID_KERNEL_SOURCES
+    h.update(fn.encode()); h.update(open(os.path.join(csrc, fn), "rb").read())
 summ["csrc_sha256"] = h.hexdigest()
 summ["host"] = socket.gethostname()
 summ["timed_launches_per_pass"] = steps

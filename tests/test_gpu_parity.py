@@ -1636,3 +1636,16 @@ def test_page_locked_result_arrays(hip_lib, monkeypatch):
     assert hip_lib.ceg_host_grid_free(foreign.ctypes.data_as(_abi.c_float_p)) == -1 and hip_lib.ceg_host_grid_free(None) == 0
     bad = np.array([0, 3, 3], dtype=np.int32)
     assert not hip_lib.ceg_host_grid_alloc(_abi.i32ptr(bad))
+    # the page-locked memory in callers' hands is bounded (CEG_HIP_PINNED_LIMIT_MB): what makes it a safe default for a garbage-collected
+    # caller (julia/CEGHip.jl result_array falls back to an ordinary Array when the library refuses)
+    del vg, cg
+    gc.collect()
+    monkeypatch.setenv("CEG_HIP_PINNED_LIMIT_MB", "48")                  # one 34 MB array fits, two do not
+    first = G.alloc_host_grid(w.cset)
+    with pytest.raises(_abi.CegError) as ei:
+        G.alloc_host_grid(w.cset)
+    assert "CEG_HIP_PINNED_LIMIT_MB" in str(ei.value)
+    del first
+    gc.collect()
+    second = G.alloc_host_grid(w.cset)                                   # freed arrays do not count
+    del second
