@@ -265,6 +265,79 @@ __device__ __forceinline__ double rule_energy_fast(const DevRule& R, double r2, 
 }
 
 
+// ---- the pair distance of unsafe_periodic_distance2! (src/utils.jl:294-302) for the consumer kernels.
+// The reference measures the ONE image whose fractional difference lies in [-1/2, 1/2): invmat*d, wrap, mat*f, norm -- 47 flops as
+// separate instructions when its operation order is kept (no contraction), of which the hot loop of k_pairs spent 91 % on non-FMA
+// instructions (profiles/r03_consumers_pairs.txt).  With every perpendicular cell width above 2 cutoff (`fastwrap`, decided on the
+// host: what the reference demands of an MC cell, montecarlo.jl "perpendicular length lower than 24.0") a pair whose fractional
+// difference is within rounding of +-1/2 lies beyond the cutoff under EITHER image, so the wrap may be done as f - rint(f) with fused
+// multiply-adds; only a pair within 1e-9 of the cutoff itself -- where the truncated potentials jump -- is measured again with the
+// reference's operation order.  TRI: mat and invmat are upper triangular (a along x, b in the xy plane: the convention of every cell the
+// reference builds, utils.jl:140-144), six of the eighteen products vanish.
+__device__ __forceinline__ double pair_distance2_literal(const double* M, const double* I, double dx, double dy, double dz)
+{
+#pragma clang fp contract(off)
+    double f0 = I[0] * dx + I[3] * dy + I[6] * dz;
+    double f1 = I[1] * dx + I[4] * dy + I[7] * dz;
+    double f2 = I[2] * dx + I[5] * dy + I[8] * dz;
+    f0 = ((f0 + 0.5) - floor(f0 + 0.5)) - 0.5;
+    f1 = ((f1 + 0.5) - floor(f1 + 0.5)) - 0.5;
+    f2 = ((f2 + 0.5) - floor(f2 + 0.5)) - 0.5;
+    const double vx = M[0] * f0 + M[3] * f1 + M[6] * f2;
+    const double vy = M[1] * f0 + M[4] * f1 + M[7] * f2;
+    const double vz = M[2] * f0 + M[5] * f1 + M[8] * f2;
+    return vx * vx + vy * vy + vz * vz;
+}
+
+// the same behind a call, matrices read from memory (`geom` = mat[9], invmat[9] in device memory): what the fast form falls back to
+// for the rare pair in the cutoff band -- inlined, the literal form kept all eighteen matrix elements live in scalar registers across
+// the hot loop, and the kernels ran out of them (v_readlane reloads of spilled SGPRs: 16 VALU instructions per pair test in k_pairs)
+__device__ __attribute__((noinline)) double pair_distance2_literal_call(const double* __restrict__ geom, double dx, double dy, double dz)
+{
+    return pair_distance2_literal(geom, geom + 9, dx, dy, dz);
+}
+
+template <bool TRI>
+__device__ __forceinline__ double pair_distance2_fast(const double* M, const double* I, const double* __restrict__ geom, double dx, double dy, double dz,
+                                                      double cutoff2, double band)
+{
+    double f0, f1, f2;
+    if (TRI) {
+        f2 = I[8] * dz;
+        f1 = __builtin_fma(I[7], dz, I[4] * dy);
+        f0 = __builtin_fma(I[6], dz, __builtin_fma(I[3], dy, I[0] * dx));
+    } else {
+        f0 = __builtin_fma(I[6], dz, __builtin_fma(I[3], dy, I[0] * dx));
+        f1 = __builtin_fma(I[7], dz, __builtin_fma(I[4], dy, I[1] * dx));
+        f2 = __builtin_fma(I[8], dz, __builtin_fma(I[5], dy, I[2] * dx));
+    }
+    f0 -= __builtin_rint(f0);
+    f1 -= __builtin_rint(f1);
+    f2 -= __builtin_rint(f2);
+    double vx, vy, vz;
+    if (TRI) {
+        vx = __builtin_fma(M[6], f2, __builtin_fma(M[3], f1, M[0] * f0));
+        vy = __builtin_fma(M[7], f2, M[4] * f1);
+        vz = M[8] * f2;
+    } else {
+        vx = __builtin_fma(M[6], f2, __builtin_fma(M[3], f1, M[0] * f0));
+        vy = __builtin_fma(M[7], f2, __builtin_fma(M[4], f1, M[1] * f0));
+        vz = __builtin_fma(M[8], f2, __builtin_fma(M[5], f1, M[2] * f0));
+    }
+    double r2 = __builtin_fma(vz, vz, __builtin_fma(vy, vy, vx * vx));
+    if (fabs(r2 - cutoff2) <= band) r2 = pair_distance2_literal_call(geom, dx, dy, dz);       // the cutoff decision is the reference's
+    return r2;
+}
+
+// host side: 0 literal, 1 fast wrap, 2 fast wrap with upper-triangular matrices
+inline int wrap_mode(const double mat[9], const double invmat[9], const double hfrac[3])
+{
+    for (int i = 0; i < 3; ++i)
+        if (!(hfrac[i] < 0.5 * (1.0 - 1e-6))) return 0;
+    const bool tri = mat[1] == 0.0 && mat[2] == 0.0 && mat[5] == 0.0 && invmat[1] == 0.0 && invmat[2] == 0.0 && invmat[5] == 0.0;
+    return tri ? 2 : 1;
+}
+
 // ---- neighbour cells of the guest atoms (what the reference gets from CellListMap above 1200 atom x threads,
 // src/energy.jl:340-349,398-404): bins of the FRACTIONAL coordinates of the MC cell.  unsafe_periodic_distance2!
 // (src/utils.jl:294-302) measures the one image whose fractional difference lies in [-1/2, 1/2), and |f_i| <= cutoff / width_i

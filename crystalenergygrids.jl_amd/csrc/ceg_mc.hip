@@ -83,7 +83,8 @@ struct McView {
     int32_t* cell_count;                       // [nb0*nb1*nb2]
     // the k-vectors as rows cut into segments and dealt to 64 lanes in rounds (ceg_rows.h)
     int32_t nrounds, ns;
-    int32_t fastwrap, _pad1;                   // every perpendicular width > 2 cutoff: a pair at the wrap boundary is beyond the cutoff (see k_mcw_pairs)
+    int32_t fastwrap, _pad1;                   // ceg_consumers::wrap_mode: 0 literal pair distances, 1 fast wrap, 2 fast wrap in an upper-triangular cell
+    const double* geom;                        // mat[9], invmat[9] in device memory (literal fall-back of the fast pair distance)
     const int32_t* desc;                       // [nrounds * 64]
     const int32_t* qof;                        // [ns * 64] k-vector of (slot, lane), -1 in the padding slots
 };
@@ -606,8 +607,11 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_mcw_ewald(McView v, int32_t m
     }
 }
 
-template <bool FAST, bool INSERT, bool CELLS>
-__global__ __launch_bounds__(64 * MCW_WAVES, (FAST && CELLS) ? 3 : 4) void k_mcw_pairs(McView v, McCompact ct, int32_t molecule, McMolecule nm, const double* __restrict__ trial,
+// WRAP (ceg_consumers::wrap_mode) is a template parameter so that an upper-triangular cell keeps twelve matrix elements live, not
+// eighteen; whether the molecule is in the system (insert = false: row 0 is its current position, its own atoms are excluded) is a
+// run-time flag
+template <bool FAST, bool CELLS, int WRAP>
+__global__ __launch_bounds__(64 * MCW_WAVES, (FAST && CELLS) ? 3 : 4) void k_mcw_pairs(McView v, McCompact ct, int32_t molecule, int32_t insert, McMolecule nm, const double* __restrict__ trial,
                                                                  int64_t nrows, double* __restrict__ out, int per_wave)
 {
     // dynamic LDS (ct.in_lds): the compact pair table: fast records, rules, offsets
@@ -615,7 +619,8 @@ __global__ __launch_bounds__(64 * MCW_WAVES, (FAST && CELLS) ? 3 : 4) void k_mcw
     __shared__ double s_pos[MCW_WAVES][MC_MAX_ATOMS * 3];
     __shared__ int s_first[CELLS ? MCW_WAVES : 1][64], s_cell[CELLS ? MCW_WAVES : 1][64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int first = INSERT ? 0 : v.mol[molecule].x, m = INSERT ? nm.m : v.mol[molecule].y;
+    const int first = insert ? 0 : v.mol[molecule].x, m = insert ? nm.m : v.mol[molecule].y;
+    const int excluded = insert ? -2 : molecule;                       // (free slots carry -1 and are skipped before this is looked at)
     const DevRule* rules = ct.rules;
     const int32_t* offset = ct.off;
     const McFastPair* fastp = ct.fast;
@@ -631,11 +636,8 @@ __global__ __launch_bounds__(64 * MCW_WAVES, (FAST && CELLS) ? 3 : 4) void k_mcw
         fastp = s_fast;
     }
     __syncthreads();
-    // unsafe_periodic_distance2! (utils.jl:294-302) measures the ONE image with fractional difference in [-1/2, 1/2).  With every
-    // perpendicular width above 2 cutoff a pair whose fractional difference is within rounding of +-1/2 lies beyond the cutoff under
-    // either image, so the wrap may be done as f - rint(f) with fused multiply-adds (30 instructions instead of 50); only a pair
-    // within 1e-9 of the cutoff itself (where the truncated potentials jump) is measured again with the reference's operation order.
-    const bool fastwrap = FAST && v.fastwrap != 0;
+    // the pair distance: ceg_consumers::pair_distance2_fast when every perpendicular width exceeds 2 cutoff (30 / 24 instructions
+    // instead of 50), the reference's operation order otherwise and for pairs within 1e-9 of the cutoff
     const double band = 1e-9 * v.cutoff2;
     const int64_t p0 = ((int64_t)blockIdx.x * MCW_WAVES + wave) * per_wave;
     const int64_t p1 = p0 + per_wave < nrows ? p0 + per_wave : nrows;
@@ -643,43 +645,24 @@ __global__ __launch_bounds__(64 * MCW_WAVES, (FAST && CELLS) ? 3 : 4) void k_mcw
     const double* M = v.mat;
     const double* I = v.invmat;
     for (int64_t row = p0; row < p1; ++row) {
-        mcw_load_row<INSERT>(v, first, m, trial, row, lane, pos);
+        if (lane < 3 * m) {
+            if (!insert && row == 0) {
+                const double4 A = v.atoms[first + lane / 3];
+                pos[lane] = (lane % 3 == 0) ? A.x : ((lane % 3 == 1) ? A.y : A.z);
+            } else {
+                pos[lane] = trial[(size_t)(insert ? row : row - 1) * m * 3 + lane];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
         double inter = 0.0;
         auto pairs_with = [&](const double4 A) __attribute__((always_inline)) {
             int kind1, mol;
             unpack(A.w, kind1, mol);
-            if (mol < 0 || (!INSERT && mol == molecule)) return;            // energy.jl:419 (and free slots)
+            if (mol < 0 || mol == excluded) return;                         // energy.jl:419 (and free slots)
             for (int a = 0; a < m; ++a) {
                 const double dx = pos[3 * a] - A.x, dy = pos[3 * a + 1] - A.y, dz = pos[3 * a + 2] - A.z;
-                auto literal = [&]() -> double {
-#pragma clang fp contract(off)
-                    double f0 = I[0] * dx + I[3] * dy + I[6] * dz;
-                    double f1 = I[1] * dx + I[4] * dy + I[7] * dz;
-                    double f2 = I[2] * dx + I[5] * dy + I[8] * dz;
-                    f0 = ((f0 + 0.5) - floor(f0 + 0.5)) - 0.5;
-                    f1 = ((f1 + 0.5) - floor(f1 + 0.5)) - 0.5;
-                    f2 = ((f2 + 0.5) - floor(f2 + 0.5)) - 0.5;
-                    const double vx = M[0] * f0 + M[3] * f1 + M[6] * f2;
-                    const double vy = M[1] * f0 + M[4] * f1 + M[7] * f2;
-                    const double vz = M[2] * f0 + M[5] * f1 + M[8] * f2;
-                    return vx * vx + vy * vy + vz * vz;
-                };
-                double r2;
-                if (fastwrap) {
-                    double f0 = __builtin_fma(I[6], dz, __builtin_fma(I[3], dy, I[0] * dx));
-                    double f1 = __builtin_fma(I[7], dz, __builtin_fma(I[4], dy, I[1] * dx));
-                    double f2 = __builtin_fma(I[8], dz, __builtin_fma(I[5], dy, I[2] * dx));
-                    f0 -= __builtin_rint(f0);
-                    f1 -= __builtin_rint(f1);
-                    f2 -= __builtin_rint(f2);
-                    const double vx = __builtin_fma(M[6], f2, __builtin_fma(M[3], f1, M[0] * f0));
-                    const double vy = __builtin_fma(M[7], f2, __builtin_fma(M[4], f1, M[1] * f0));
-                    const double vz = __builtin_fma(M[8], f2, __builtin_fma(M[5], f1, M[2] * f0));
-                    r2 = __builtin_fma(vz, vz, __builtin_fma(vy, vy, vx * vx));
-                    if (fabs(r2 - v.cutoff2) <= band) r2 = literal();       // the cutoff decision is the reference's
-                } else {
-                    r2 = literal();
-                }
+                const double r2 = WRAP == 0 ? ceg_consumers::pair_distance2_literal(M, I, dx, dy, dz)
+                                            : ceg_consumers::pair_distance2_fast<WRAP == 2>(M, I, v.geom, dx, dy, dz, v.cutoff2, band);
                 if (!(r2 < v.cutoff2)) continue;                            // :422
                 const int t = kind1 * m + a;
                 if (FAST && r2 >= 0.25) {
@@ -704,7 +687,15 @@ __global__ __launch_bounds__(64 * MCW_WAVES, (FAST && CELLS) ? 3 : 4) void k_mcw
             }
         };
         if (!CELLS) {
-            for (int l = lane; l < v.natoms; l += 64) pairs_with(v.atoms[l]);
+            // (the next 64 atoms are fetched while the current ones are worked on; free slots carry molecule -1 and are skipped)
+            const double4 none = make_double4(0.0, 0.0, 0.0, __longlong_as_double(-1ll));
+            double4 A = lane < v.natoms ? v.atoms[lane] : none;
+            for (int l0 = 0; l0 < v.natoms; l0 += 64) {
+                const int ln = l0 + 64 + lane;
+                const double4 An = ln < v.natoms ? v.atoms[ln] : none;
+                pairs_with(A);
+                A = An;
+            }
         } else {
             // only the cells the cutoff spheres of the molecule's atoms can reach (ceg_consumers.h); every lane works the range out
             int bin0[3], nbin[3];
@@ -1032,6 +1023,7 @@ struct ceg_mc {
     int stride = 0;
     // row-wise k-vector layout (ceg_rows.h) and, per distinct molecule (tuple of atom kinds), the pair-table rows of its kinds
     int32_t *d_desc = nullptr, *d_qof = nullptr;
+    double* d_geom = nullptr;
     std::vector<DevRule> h_rules;
     std::vector<int32_t> h_offset;
     std::vector<int32_t> h_kind;                 // kind per atom slot (host copy)
@@ -1148,6 +1140,11 @@ extern "C" int ceg_mc_create(ceg_mc_t** handle, int32_t device, ceg_interp_t* co
         v.nrounds = lay.nrounds; v.ns = lay.ns;
         ok = ok && upload(&h->d_desc, lay.desc.data(), lay.desc.size()) && upload(&h->d_qof, qof.data(), qof.size());
     }
+    {
+        double geom[18];
+        for (int a = 0; a < 9; ++a) { geom[a] = mat[a]; geom[9 + a] = invmat[a]; }
+        ok = ok && upload(&h->d_geom, geom, 18);
+    }
     h->h_rules.assign(dr.begin(), dr.begin() + (nr > 0 ? nr : 0));
     h->h_offset.assign(rule_offset, rule_offset + nt + 1);
     ok = ok && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
@@ -1165,7 +1162,7 @@ extern "C" int ceg_mc_create(ceg_mc_t** handle, int32_t device, ceg_interp_t* co
     }
     v.vdw = h->d_vdw; v.kind_charge = h->d_charge; v.rules = h->d_rules; v.rule_offset = h->d_offset;
     v.ijk = h->d_ijk; v.kf = h->d_kf; v.sf_fw = h->d_fw; v.sf_tot = h->d_tot;
-    v.desc = h->d_desc; v.qof = h->d_qof;
+    v.desc = h->d_desc; v.qof = h->d_qof; v.geom = h->d_geom;
     {
         CellMirror& cm = h->cm;
         cm.bins = ceg_consumers::choose_cell_bins(invmat, cutoff);
@@ -1173,7 +1170,7 @@ extern "C" int ceg_mc_create(ceg_mc_t** handle, int32_t device, ceg_interp_t* co
         for (int a = 0; a < 9; ++a) cm.invmat[a] = invmat[a];
         cm.on = cm.bins.on != 0;
         v.use_cells = cm.on ? 1 : 0;
-        v.fastwrap = (cm.bins.hfrac[0] < 0.5 * (1.0 - 1e-6) && cm.bins.hfrac[1] < 0.5 * (1.0 - 1e-6) && cm.bins.hfrac[2] < 0.5 * (1.0 - 1e-6)) ? 1 : 0;
+        v.fastwrap = ceg_consumers::wrap_mode(mat, invmat, cm.bins.hfrac);
         if (cm.on) {
             cm.members.assign((size_t)cm.ncells(), {});
             if (int rc = rebuild_cells(h)) { ceg_mc_destroy(h); return rc; }
@@ -1197,6 +1194,7 @@ extern "C" int ceg_mc_destroy(ceg_mc_t* h)
         if (h->h_flag) (void)hipHostFree(h->h_flag);
         if (h->d_done) (void)hipFree(h->d_done);
         if (h->d_desc) (void)hipFree(h->d_desc);
+        if (h->d_geom) (void)hipFree(h->d_geom);
         if (h->d_qof) (void)hipFree(h->d_qof);
         for (auto& kv : h->compact) {
             if (kv.second.d_rules) (void)hipFree(kv.second.d_rules);
@@ -1388,15 +1386,21 @@ int launch_wave_kernels(ceg_mc* h, bool insert, int32_t molecule, const McMolecu
         const size_t lds = ct.in_lds ? ct_full : 0;
         const int per_wave = rows_per_wave(rows, MCW_WAVES, 4);
         const int64_t nb = (rows + (int64_t)MCW_WAVES * per_wave - 1) / ((int64_t)MCW_WAVES * per_wave);
-#define CEG_MCW_P(F, I, CL) hipLaunchKernelGGL((k_mcw_pairs<F, I, CL>), dim3((unsigned)nb), dim3(64 * MCW_WAVES), lds, h->stream, v, ct, molecule, nm, d_in, rows, d_out, per_wave)
+#define CEG_MCW_P(F, CL, WR) hipLaunchKernelGGL((k_mcw_pairs<F, CL, WR>), dim3((unsigned)nb), dim3(64 * MCW_WAVES), lds, h->stream, v, ct, molecule, insert ? 1 : 0, nm, d_in, rows, d_out, per_wave)
+#define CEG_MCW_WR(F, CL)                                  \
+    do {                                                   \
+        if (v.fastwrap == 2) CEG_MCW_P(F, CL, 2);          \
+        else if (v.fastwrap == 1) CEG_MCW_P(F, CL, 1);     \
+        else CEG_MCW_P(F, CL, 0);                          \
+    } while (0)
 #define CEG_MCW_PICK(CL)                                                                      \
     do {                                                                                      \
-        if (insert) { if (v.fast) CEG_MCW_P(true, true, CL); else CEG_MCW_P(false, true, CL); }   \
-        else { if (v.fast) CEG_MCW_P(true, false, CL); else CEG_MCW_P(false, false, CL); }        \
+        if (v.fast) CEG_MCW_WR(true, CL); else CEG_MCW_WR(false, CL);                         \
     } while (0)
         if (v.use_cells) CEG_MCW_PICK(true);
         else CEG_MCW_PICK(false);
 #undef CEG_MCW_PICK
+#undef CEG_MCW_WR
 #undef CEG_MCW_P
     }
     return hipGetLastError() == hipSuccess ? CEG_OK : merr(CEG_ERR_HIP, "trial kernel launch failed");

@@ -11,7 +11,9 @@
 // exp/erfc (ocml): this is a consumer kernel of a few thousand atoms, not the grid build.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -36,11 +38,18 @@ struct PairsGeom {
     double cutoff2, coulombic;
     int32_t nkinds, m, exclude;
     int32_t kinds[PAIRS_MAX_ATOMS];
+    const double* geom;                  // mat[9], invmat[9] in device memory (the literal fall-back of the fast pair distance)
     int32_t nb[3];                       // neighbour cells (CELLS): bins per fractional axis, z fastest in cell_start
     double hfrac[3];
 };
 
-template <bool FAST, bool TABLE_IN_LDS, bool CELLS>
+// the libm-grade rule energies behind a call: inlined, their exp / erfc / pow temporaries set the register count of the whole kernel
+// (168 VGPRs, up to 44 B of scratch) while they serve the pairs closer than 0.5 A only (and the handles whose exp / erfc arguments leave
+// the domain of ceg_math.h)
+__device__ __attribute__((noinline)) double pairs_rule_energy_call(const DevRule* R, double r2, double coulombic) { return rule_energy(*R, r2, coulombic); }
+
+// WRAP: 0 the reference's operation order for every pair; 1 / 2: ceg_consumers::pair_distance2_fast (2: upper-triangular cell)
+template <bool FAST, bool TABLE_IN_LDS, bool CELLS, int WRAP>
 __global__ __launch_bounds__(64 * PAIRS_WAVES, 3) void k_pairs(PairsGeom g, const DevRule* __restrict__ g_rules,
                                                              const int32_t* __restrict__ g_offset, int32_t nrules,
                                                              const double4* __restrict__ atoms,      // x, y, z, (kind | molecule) bits
@@ -67,11 +76,29 @@ __global__ __launch_bounds__(64 * PAIRS_WAVES, 3) void k_pairs(PairsGeom g, cons
     const int64_t p = (int64_t)blockIdx.x * PAIRS_WAVES + wave;
     if (p >= n) return;
     __shared__ double s_trial[PAIRS_WAVES][PAIRS_MAX_ATOMS * 3];
+    __shared__ int32_t s_tk[PAIRS_WAVES][PAIRS_MAX_ATOMS];      // row offsets of the trial atoms' kinds in the pair table (not 16 scalar registers)
     double* t3 = s_trial[wave];
     if (lane < 3 * g.m) t3[lane] = trial[(size_t)p * g.m * 3 + lane];
+    if (lane < g.m) s_tk[wave][lane] = g.kinds[lane];
     __builtin_amdgcn_wave_barrier();
-    const double* M = g.mat;
-    const double* I = g.invmat;
+    const int32_t* tk = s_tk[wave];
+    const int m = g.m, nkinds = g.nkinds, exclude = g.exclude;
+    const double cutoff2 = g.cutoff2;
+    // The cell matrices of the fast pair distance live in VGPRs (the same value in every lane): as kernel arguments they are scalar
+    // registers, the kernel has more wave-uniform values than scalar registers, and the compiler spilled them into VGPR lanes -- 16
+    // v_readlane reloads per pair test, a third of the hot loop's VALU instructions (round 4).  The registers are there: 3 waves per SIMD.
+    double Mv[9], Iv[9];
+#pragma unroll
+    for (int a = 0; a < 9; ++a) {
+        Mv[a] = g.mat[a];
+        Iv[a] = g.invmat[a];
+        if (WRAP != 0) {
+            asm volatile("" : "+v"(Mv[a]));
+            asm volatile("" : "+v"(Iv[a]));
+        }
+    }
+    const double* M = Mv;
+    const double* I = Iv;
     // Only ~10 % of the tested pairs are inside the cutoff (MC cells are 2-4 cutoffs wide), but a wave almost
     // always contains one: evaluating the rules under the lane mask would cost every lane the full exp / erfc
     // price per test.  Hits are therefore compacted into a per-wave LDS queue (r2, pair-table index) and the
@@ -83,17 +110,21 @@ __global__ __launch_bounds__(64 * PAIRS_WAVES, 3) void k_pairs(PairsGeom g, cons
     int32_t* qt = s_qt[wave];
     int qn = 0;                                   // wave-uniform
     double e = 0.0;
+    const double band = 1e-9 * g.cutoff2;
+    const double coulombic = g.coulombic;
     auto flush = [&]() {
         __builtin_amdgcn_wave_barrier();
         for (int i = lane; i < qn; i += 64) {
             const double r2 = qr2[i];
             const int t = qt[i];
+            // (the FAST arithmetic stays inline: behind a call -- tried -- the kernel fits four waves per SIMD but spills 200-400 B per
+            //  lane around the call and runs 8x slower)
             if (FAST && r2 >= 0.25) {
                 double r, rinv;
                 ceg::fast_sqrt_rsqrt(r2, r, rinv);
-                for (int q = offset[t]; q < offset[t + 1]; ++q) e += rule_energy_fast(rules[q], r2, r, rinv, g.coulombic);
+                for (int q = offset[t]; q < offset[t + 1]; ++q) e += rule_energy_fast(rules[q], r2, r, rinv, coulombic);
             } else {
-                for (int q = offset[t]; q < offset[t + 1]; ++q) e += rule_energy(rules[q], r2, g.coulombic);
+                for (int q = offset[t]; q < offset[t + 1]; ++q) e += pairs_rule_energy_call(&rules[q], r2, coulombic);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -102,25 +133,13 @@ __global__ __launch_bounds__(64 * PAIRS_WAVES, 3) void k_pairs(PairsGeom g, cons
     auto process = [&](const double4 A, const bool have) __attribute__((always_inline)) {
         const long long bits = __double_as_longlong(A.w);
         const int kind1 = (int)(bits & 0xffffffffll), mol = (int)(bits >> 32);
-        const bool live = have && mol != g.exclude;
-        for (int a = 0; a < g.m; ++a) {
-            double r2;
-            {
-#pragma clang fp contract(off)
-                // buffer = pos2 - pos1 (energy.jl:420); invmat * buffer; wrap; mat * frac; norm2
-                const double dx = t3[3 * a] - A.x, dy = t3[3 * a + 1] - A.y, dz = t3[3 * a + 2] - A.z;
-                double f0 = I[0] * dx + I[3] * dy + I[6] * dz;
-                double f1 = I[1] * dx + I[4] * dy + I[7] * dz;
-                double f2 = I[2] * dx + I[5] * dy + I[8] * dz;
-                f0 = ((f0 + 0.5) - floor(f0 + 0.5)) - 0.5;
-                f1 = ((f1 + 0.5) - floor(f1 + 0.5)) - 0.5;
-                f2 = ((f2 + 0.5) - floor(f2 + 0.5)) - 0.5;
-                const double vx = M[0] * f0 + M[3] * f1 + M[6] * f2;
-                const double vy = M[1] * f0 + M[4] * f1 + M[7] * f2;
-                const double vz = M[2] * f0 + M[5] * f1 + M[8] * f2;
-                r2 = vx * vx + vy * vy + vz * vz;
-            }
-            const bool hit = live && (r2 < g.cutoff2);             // energy.jl:422 (a NaN distance is no hit there either)
+        const bool live = have && mol != exclude;
+        for (int a = 0; a < m; ++a) {
+            // buffer = pos2 - pos1 (energy.jl:420); invmat * buffer; wrap; mat * frac; norm2
+            const double dx = t3[3 * a] - A.x, dy = t3[3 * a + 1] - A.y, dz = t3[3 * a + 2] - A.z;
+            const double r2 = WRAP == 0 ? ceg_consumers::pair_distance2_literal(M, I, dx, dy, dz)
+                                        : ceg_consumers::pair_distance2_fast<WRAP == 2>(M, I, g.geom, dx, dy, dz, cutoff2, band);
+            const bool hit = live && (r2 < cutoff2);               // energy.jl:422 (a NaN distance is no hit there either)
             const unsigned long long mask = __ballot(hit);
             const int cnt = __popcll(mask);
             if (cnt == 0) continue;
@@ -128,16 +147,20 @@ __global__ __launch_bounds__(64 * PAIRS_WAVES, 3) void k_pairs(PairsGeom g, cons
             if (hit) {
                 const int slot = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
                 qr2[slot] = r2;
-                qt[slot] = kind1 * g.nkinds + g.kinds[a];
+                qt[slot] = kind1 * nkinds + tk[a];
             }
             qn += cnt;
         }
     };
     if (!CELLS) {
+        // the next 64 atoms are fetched while the current ones are worked on: a block is ~140 instructions of work against a
+        // microsecond of load latency, which three waves per SIMD do not cover by themselves (VALU issue 0.67 without the prefetch)
+        double4 A = atoms[lane < natoms ? lane : 0];
         for (int64_t l0 = 0; l0 < natoms; l0 += 64) {
-            const int64_t l = l0 + lane;
-            const bool have = l < natoms;
-            process(atoms[have ? l : 0], have);
+            const int64_t ln = l0 + 64 + lane;
+            const double4 An = atoms[ln < natoms ? ln : 0];
+            process(A, l0 + lane < natoms);
+            A = An;
         }
     } else {
         // The atoms are sorted by cell with z fastest: the cells (c0, c1, z-range) the molecule can reach are one or (across the
@@ -176,14 +199,18 @@ __global__ __launch_bounds__(64 * PAIRS_WAVES, 3) void k_pairs(PairsGeom g, cons
             run[lane] = start;
             off[lane] = incl - len;
             __builtin_amdgcn_wave_barrier();
-            for (int l0 = 0; l0 < total; l0 += 64) {
-                const int l = l0 + lane;
-                const bool have = l < total;
+            auto fetch = [&](int l) -> double4 {                       // entry l of the concatenated runs (the first atom for l >= total)
                 int j = 0;                                             // last run whose first entry is <= l
 #pragma unroll
                 for (int step = 32; step > 0; step >>= 1)
                     if (off[j + step] <= l) j += step;
-                process(atoms[have ? run[j] + (l - off[j]) : 0], have);
+                return atoms[l < total ? run[j] + (l - off[j]) : 0];
+            };
+            double4 A = fetch(lane);
+            for (int l0 = 0; l0 < total; l0 += 64) {
+                const double4 An = fetch(l0 + 64 + lane);              // one block ahead, as in the exhaustive loop
+                process(A, l0 + lane < total);
+                A = An;
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -215,6 +242,7 @@ struct ceg_pairs {
     int64_t natoms = 0, cap = 0;
     ceg_consumers::CellBins bins{};     // neighbour cells: the atoms are uploaded sorted by cell when bins.on
     int32_t* d_cell_start = nullptr;
+    double* d_geom = nullptr;           // mat[9], invmat[9]
 };
 
 extern "C" int ceg_pairs_create(ceg_pairs_t** handle, int32_t device, const double mat[9], const double invmat[9], double cutoff2,
@@ -251,8 +279,12 @@ extern "C" int ceg_pairs_create(ceg_pairs_t** handle, int32_t device, const doub
     for (int a = 0; a < 9; ++a) { h->mat[a] = mat[a]; h->invmat[a] = invmat[a]; }
     h->cutoff2 = cutoff2; h->coulombic = coulombic; h->nkinds = nkinds; h->fast = fast; h->nrules = nr;
     h->bins = ceg_consumers::choose_cell_bins(invmat, cutoff);
+    double geom[18];
+    for (int a = 0; a < 9; ++a) { geom[a] = mat[a]; geom[9 + a] = invmat[a]; }
     bool ok = hipMalloc((void**)&h->d_rules, dr.size() * sizeof(DevRule)) == hipSuccess &&
-              hipMalloc((void**)&h->d_offset, (size_t)(nt + 1) * sizeof(int32_t)) == hipSuccess;
+              hipMalloc((void**)&h->d_offset, (size_t)(nt + 1) * sizeof(int32_t)) == hipSuccess &&
+              hipMalloc((void**)&h->d_geom, sizeof geom) == hipSuccess &&
+              hipMemcpy(h->d_geom, geom, sizeof geom, hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(h->d_rules, dr.data(), dr.size() * sizeof(DevRule), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(h->d_offset, rule_offset, (size_t)(nt + 1) * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess;
     if (prev >= 0) (void)hipSetDevice(prev);
@@ -274,6 +306,7 @@ extern "C" int ceg_pairs_destroy(ceg_pairs_t* h)
         (void)hipFree(h->d_offset);
         (void)hipFree(h->d_atoms);
         (void)hipFree(h->d_cell_start);
+        (void)hipFree(h->d_geom);
     }
     if (prev >= 0) (void)hipSetDevice(prev);
     delete h;
@@ -344,6 +377,7 @@ extern "C" int ceg_pairs_energy_device(ceg_pairs_t* h, const double* d_trial, co
         g.kinds[a] = trial_kinds[a];
     }
     for (int i = 0; i < 3; ++i) { g.nb[i] = h->bins.nb[i]; g.hfrac[i] = h->bins.hfrac[i]; }
+    g.geom = h->d_geom;
     const bool cells = h->bins.on && h->d_cell_start && h->natoms > 0;
     const int64_t nblocks = (n + PAIRS_WAVES - 1) / PAIRS_WAVES;
     if (nblocks > 0x7fffffffLL) return perr(CEG_ERR_INVALID, "too many placements");
@@ -355,17 +389,26 @@ extern "C" int ceg_pairs_energy_device(ceg_pairs_t* h, const double* d_trial, co
     const size_t lds = in_lds ? table_bytes : 0;
     const dim3 grid((unsigned)nblocks), block(64 * PAIRS_WAVES);
     hipStream_t st = (hipStream_t)stream;
-#define CEG_PAIRS_LAUNCH(F, L, CL) hipLaunchKernelGGL((k_pairs<F, L, CL>), grid, block, lds, st, g, h->d_rules, h->d_offset, h->nrules, h->d_atoms, h->d_cell_start, h->natoms, d_trial, n, d_out)
+    int wrap = ceg_consumers::wrap_mode(h->mat, h->invmat, h->bins.hfrac);
+    if (const char* env = getenv("CEG_HIP_PAIRS_WRAP")) wrap = std::min(wrap, std::max(0, atoi(env)));      // measurement aid: 0 forces the literal form
+#define CEG_PAIRS_LAUNCH(F, L, CL, WR) hipLaunchKernelGGL((k_pairs<F, L, CL, WR>), grid, block, lds, st, g, h->d_rules, h->d_offset, h->nrules, h->d_atoms, h->d_cell_start, h->natoms, d_trial, n, d_out)
+#define CEG_PAIRS_WRAP(F, L, CL)                              \
+    do {                                                      \
+        if (wrap == 2) CEG_PAIRS_LAUNCH(F, L, CL, 2);         \
+        else if (wrap == 1) CEG_PAIRS_LAUNCH(F, L, CL, 1);    \
+        else CEG_PAIRS_LAUNCH(F, L, CL, 0);                   \
+    } while (0)
 #define CEG_PAIRS_PICK(CL)                                    \
     do {                                                      \
-        if (h->fast && in_lds) CEG_PAIRS_LAUNCH(true, true, CL);   \
-        else if (h->fast) CEG_PAIRS_LAUNCH(true, false, CL);       \
-        else if (in_lds) CEG_PAIRS_LAUNCH(false, true, CL);        \
-        else CEG_PAIRS_LAUNCH(false, false, CL);                   \
+        if (h->fast && in_lds) CEG_PAIRS_WRAP(true, true, CL);   \
+        else if (h->fast) CEG_PAIRS_WRAP(true, false, CL);       \
+        else if (in_lds) CEG_PAIRS_WRAP(false, true, CL);        \
+        else CEG_PAIRS_WRAP(false, false, CL);                   \
     } while (0)
     if (cells) CEG_PAIRS_PICK(true);
     else CEG_PAIRS_PICK(false);
 #undef CEG_PAIRS_PICK
+#undef CEG_PAIRS_WRAP
 #undef CEG_PAIRS_LAUNCH
     const hipError_t e = hipGetLastError();
     if (prev >= 0) (void)hipSetDevice(prev);
