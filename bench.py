@@ -221,6 +221,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # The hosts of this pool support dmabuf IPC only: with the legacy IPC mode RCCL's intra-node transport (and any sharing of device
+        # memory between processes) fails with `hipIpcGetMemHandle: invalid argument`.  The image exports HSA_ENABLE_IPC_MODE_LEGACY=0
+        # already; setdefault keeps whatever the launcher set and only fills it in for a hand-made environment.  It must be in place
+        # before the HIP runtime initialises (nothing above this line touches the GPU).
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the grid build has no CPU path)")
@@ -364,25 +368,71 @@ def main():
             gather_mode = cands[best][1]
     elif args.gather == "auto":
         gather_mode = "staged"
-    # Last line of defence for the first run on real links: ONE guarded step of the pipelined exchange before anything is timed.  If
-    # it raises on any rank, every rank drops to the simplest path there is -- contiguous x-slabs, one all-gather per channel after the
-    # kernels (allgather_grid) -- and the line says so in exchange.mode.  (A rank that hangs cannot be rescued from inside.)
+    # Last line of defence for the first run on real links: ONE guarded step of the pipelined exchange before anything is timed.  The
+    # ranks agree on its outcome through the rendezvous STORE, not through a collective: a rank that raises inside step()
+    # while its peers already sit in an all_gather must not enter another collective -- RCCL would pair its all_reduce with their
+    # all_gather.  Protocol: every rank publishes "ok" or "fail: reason" under its own key; a rank that has launched its step waits for
+    # the step's completion EVENT by polling, and looks at the peers' keys while it does.
+    #   * every rank "ok"                      -> the pipelined exchange is used;
+    #   * every rank failed BEFORE its first collective (the same cause everywhere: a bad argument, an unsupported call)
+    #                                           -> every rank drops to the simplest path there is -- contiguous x-slabs, one all-gather per
+    #                                              channel after the kernels (allgather_grid) -- and the line says so in exchange.mode;
+    #   * anything else (one rank fails while others are inside a collective, a step that does not complete in time)
+    #                                           -> cannot be repaired in-process: every rank prints the reason and exits non-zero so that the
+    #                                              launcher starts fresh processes (never re-exec a process that has touched the GPU).
     fallback_reason = None
     if pipe is not None and pipe.exchange and world > 1:
-        ok = True
+        store = dist.distributed_c10d._get_default_store()
+        key = lambda r: f"ceg_bench_first_step/{r}"          # noqa: E731
+        limit = float(os.environ.get("CEG_BENCH_FIRST_STEP_TIMEOUT", "180"))
+        mine = "ok"
+        launched = False
         try:
-            if os.environ.get("CEG_BENCH_FAIL_PIPELINE") == "1":            # test hook
+            inject = os.environ.get("CEG_BENCH_FAIL_PIPELINE", "")
+            if inject == "1" or inject == f"rank{rank}":            # test hooks: every rank / one rank fails before its first collective
                 raise RuntimeError("injected failure of the pipelined exchange (CEG_BENCH_FAIL_PIPELINE)")
+            launched = True
             step()
-            torch.cuda.synchronize()
+            if inject == f"late{rank}":                             # test hook: this rank fails AFTER its collectives were enqueued
+                raise RuntimeError("injected late failure of the pipelined exchange (CEG_BENCH_FAIL_PIPELINE)")
         except Exception as exc:              # noqa: BLE001
-            ok = False
-            fallback_reason = repr(exc)
+            mine = f"fail{'-late' if launched else ''}: {exc!r}"
             print(f"[bench] pipelined exchange failed on rank {rank}: {exc!r}", file=sys.stderr)
-        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if not bool(flag[0] > 0.5):
-            fallback_reason = fallback_reason or "another rank failed"
+        store.set(key(rank), mine)
+        done_ev = torch.cuda.Event()
+        done_ev.record()
+        t_wait = time.perf_counter()
+        states = {}
+        while True:
+            for r in range(world):
+                if r not in states:
+                    try:
+                        if store.check([key(r)]):
+                            states[r] = store.get(key(r)).decode()
+                    except Exception:         # noqa: BLE001 -- a store hiccup is not a verdict
+                        pass
+            finished = done_ev.query()
+            bad = {r: v for r, v in states.items() if v != "ok"}
+            if len(states) == world and (finished or bad):
+                break
+            if bad and not finished and any(v.startswith("fail-late") for v in bad.values()):
+                break                                               # a peer died inside the exchange: our collective will not complete
+            if time.perf_counter() - t_wait > limit:
+                states.setdefault(rank, mine)
+                bad = bad or {rank: f"fail-late: first step not finished after {limit:.0f} s"}
+                break
+            time.sleep(0.002)
+        bad = {r: v for r, v in states.items() if v != "ok"}
+        if time.perf_counter() - t_wait > limit and not bad:
+            bad = {rank: f"fail-late: first step not finished after {limit:.0f} s"}
+        if bad:
+            early_everywhere = len(bad) == world and all(v.startswith("fail:") for v in bad.values())
+            if not early_everywhere:
+                print(f"[bench] rank {rank}: the first pipelined step cannot be agreed on ({bad}); exiting so that the launcher can start fresh processes",
+                      file=sys.stderr)
+                sys.stderr.flush()
+                os._exit(3)                                         # (no destroy_process_group: peers may be stuck inside a collective)
+            fallback_reason = bad[rank]
             print("[bench] falling back to contiguous slabs + one all-gather per channel", file=sys.stderr)
             pipe, cyc, joint = None, None, None
             b, e = slab_range(nx, world, rank)
@@ -391,6 +441,8 @@ def main():
             loc_c = torch.empty((8, n_local, ny, nz), dtype=torch.float32, device=dev) if need_c else None
             locs = [t for t in (loc_v, loc_c) if t is not None]
             gather_mode = "slab (fallback)"
+        else:
+            torch.cuda.synchronize()
     # (the first launches after the set-up phase run below the steady clock: 16-18, 14.1, 13.6 then 13.4 ms on an idle card,
     # scripts/clock_ramp.py; three untimed launches belong to the set-up, whatever --warmup says)
     for _ in range(PREWARM_STEPS):
