@@ -86,6 +86,7 @@ PROTOTYPES = {
     "ceg_image_cache_stats": (C.c_int, [c_int64_p, c_int64_p, c_int64_p]),
     "ceg_plan_can_cull": (C.c_int, [C.c_void_p]),
     "ceg_plan_num_images": (C.c_int64, [C.c_void_p]),
+    "ceg_plan_copy_images": (C.c_int, [C.c_void_p, c_double_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p]),
     "ceg_plan_build_vdw": (C.c_int, [
         C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_int32,
         C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),

@@ -324,6 +324,28 @@ void block_cache_release()
     if (prev >= 0) (void)hipSetDevice(prev);
 }
 
+}  // namespace
+
+namespace ceg_host {          // the same pool for the other translation units of the library (ceg_images.hip)
+hipError_t pool_malloc(void** out, size_t bytes) { return cached_malloc(out, bytes); }
+void pool_free(void* ptr) { cached_free(ptr); }
+}
+
+namespace ceg {
+struct ImgBox {
+    double mat[9], invmat[9];
+    double lo[3], hi[3], bin[3];
+    int32_t nb[3];
+    int32_t has_rules, has_charge, vdw_only;
+    int32_t nkinds;
+    uint64_t hasbits[16];
+};
+hipError_t build_images_device(const ImgBox& B, const double4* d_atoms, const int32_t* d_kind, const int32_t* d_has, int64_t natoms,
+                               double4** out_xyzq, int32_t** out_kind, int32_t** out_atom, int32_t** out_binstart, int64_t* out_n);
+}
+
+namespace {
+
 template <class T>
 int upload(T** dst, const T* src, size_t n)
 {
@@ -344,6 +366,9 @@ int upload(T** dst, const T* src, size_t n)
 struct ImageSet {
     int device = 0;
     uint64_t key[2] = {0, 0};
+    int64_t natoms = 0;             // compared on a hit together with the 128-bit (non-cryptographic) key: a collision must also
+    double cutoff2 = 0.0;           // reproduce the atom count, the cutoff and the box to be taken for a hit
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     double4* d_images = nullptr;
     int32_t* d_imgkind = nullptr;
     int32_t* d_imgatom = nullptr;
@@ -442,7 +467,8 @@ int build_images(ceg_plan* p)
         std::lock_guard<std::mutex> lock(g_image_mutex);
         for (size_t t = 0; t < g_image_cache.size(); ++t) {
             const std::shared_ptr<ImageSet> c = g_image_cache[t];
-            if (c->device == p->device && c->key[0] == hk.a && c->key[1] == hk.b) {
+            if (c->device == p->device && c->key[0] == hk.a && c->key[1] == hk.b && c->natoms == p->natoms && c->cutoff2 == g.cutoff2 &&
+                memcmp(c->lo, lo, sizeof lo) == 0 && memcmp(c->hi, hi, sizeof hi) == 0) {
                 hit = c;
                 std::rotate(g_image_cache.begin() + t, g_image_cache.begin() + t + 1, g_image_cache.end());      // most recently used last
                 break;
@@ -462,6 +488,61 @@ int build_images(ceg_plan* p)
         return CEG_OK;
     }
     if (cap > 0) g_image_misses.fetch_add(1);
+    if (!std::getenv("CEG_HIP_IMAGES_ON_HOST")) {
+        // round 4: the list is built on the device from the atom table that is already there (ceg_images.hip) -- byte-identical to
+        // the host loop below, 1.0-1.4 ms -> ~0.2 ms for the 11 664-atom framework; CEG_HIP_IMAGES_ON_HOST=1 keeps the host build
+        ceg::ImgBox B{};
+        memcpy(B.mat, g.mat, sizeof B.mat);
+        memcpy(B.invmat, g.invmat, sizeof B.invmat);
+        for (int a = 0; a < 3; ++a) { B.lo[a] = lo[a]; B.hi[a] = hi[a]; B.bin[a] = bin[a]; B.nb[a] = nb[a]; }
+        B.has_rules = p->has_rules ? 1 : 0;
+        B.has_charge = p->has_charge ? 1 : 0;
+        B.vdw_only = (p->has_rules && !p->has_charge) ? 1 : 0;
+        B.nkinds = p->nkinds;
+        int32_t* d_has = nullptr;
+        if (p->has_rules && p->nkinds <= 1024) {
+            for (int32_t k = 0; k < p->nkinds; ++k)
+                if (kind_has_rule(k)) B.hasbits[k >> 6] |= 1ull << (k & 63);
+        } else if (p->has_rules) {
+            std::vector<int32_t> has((size_t)std::max(p->nkinds, 1), 0);
+            for (int32_t k = 0; k < p->nkinds; ++k) has[k] = kind_has_rule(k) ? 1 : 0;
+            if (int rc = upload(&d_has, has.data(), has.size())) return rc;
+        }
+        auto set = std::make_shared<ImageSet>();
+        set->device = p->device;
+        set->key[0] = hk.a; set->key[1] = hk.b;
+        set->natoms = p->natoms; set->cutoff2 = g.cutoff2;
+        memcpy(set->lo, lo, sizeof lo); memcpy(set->hi, hi, sizeof hi);
+        int64_t n = 0;
+        const hipError_t e = ceg::build_images_device(B, p->d_atoms, p->has_rules ? p->d_kind : nullptr, d_has, p->natoms, &set->d_images, &set->d_imgkind,
+                                                      &set->d_imgatom, &set->d_binstart, &n);
+        if (d_has) cached_free(d_has);          // (build_images_device has synchronised)
+        if (e != hipSuccess) return fail(CEG_ERR_HIP, "building the lattice-image list on the device failed: %s", hipGetErrorString(e));
+        set->bytes = (size_t)n * (sizeof(double4) + 2 * sizeof(int32_t)) + (size_t)(nb[0] * nb[1] * nb[2] + 1) * sizeof(int32_t);
+        p->images = set;
+        p->d_images = set->d_images; p->d_imgkind = set->d_imgkind; p->d_imgatom = set->d_imgatom; p->d_binstart = set->d_binstart;
+        ImageBins& ib = p->ib;
+        ib.xyzq = p->d_images;
+        ib.kind = p->has_rules ? p->d_imgkind : nullptr;
+        ib.atom = p->d_imgatom;
+        ib.atoms = p->d_atoms;
+        ib.bin_start = p->d_binstart;
+        for (int a = 0; a < 3; ++a) {
+            ib.lo[a] = lo[a];
+            ib.bin[a] = bin[a];
+            ib.inv_bin[a] = 1.0 / bin[a];
+            ib.nb[a] = nb[a];
+        }
+        ib.nimages = (int32_t)n;
+        p->images_built = true;
+        set->ib = ib;
+        if (cap > 0) {
+            std::lock_guard<std::mutex> lock(g_image_mutex);
+            g_image_cache.push_back(set);
+            while ((int)g_image_cache.size() > cap) g_image_cache.erase(g_image_cache.begin());
+        }
+        return CEG_OK;
+    }
     struct Img { double x, y, z, q; int32_t kind; int32_t bin; int32_t atom; };
     std::vector<Img> imgs;
     imgs.reserve((size_t)p->natoms * 8);
@@ -540,6 +621,8 @@ int build_images(ceg_plan* p)
     auto set = std::make_shared<ImageSet>();
     set->device = p->device;
     set->key[0] = hk.a; set->key[1] = hk.b;
+    set->natoms = p->natoms; set->cutoff2 = g.cutoff2;
+    memcpy(set->lo, lo, sizeof lo); memcpy(set->hi, hi, sizeof hi);
     if (int rc = upload(&set->d_images, xyzq.data(), xyzq.size())) return rc;
     if (int rc = upload(&set->d_imgkind, kind.data(), kind.size())) return rc;
     if (int rc = upload(&set->d_imgatom, atom.data(), atom.size())) return rc;
@@ -1115,6 +1198,24 @@ extern "C" int ceg_image_cache_stats(int64_t* hits, int64_t* misses, int64_t* en
 extern "C" int ceg_plan_can_cull(const ceg_plan_t* p) { return (p && p->can_cull) ? 1 : 0; }
 
 extern "C" int64_t ceg_plan_num_images(const ceg_plan_t* p) { return (p && p->images_built) ? p->ib.nimages : 0; }
+
+// the lattice-image list of a plan copied to the host (tests: the device build against the host build): xyzq [4 n], kind / atom [n],
+// bin_start [nbins + 1] with nbins = nb[0] nb[1] nb[2]; any output may be NULL; nb receives the bin counts
+extern "C" int ceg_plan_copy_images(const ceg_plan_t* p, double* xyzq, int32_t* kind, int32_t* atom, int32_t* bin_start, int32_t nb[3])
+{
+    if (!p || !p->images_built) return fail(CEG_ERR_INVALID, "the plan has no image list");
+    DeviceGuard guard(p->device);
+    if (!guard.ok) return fail(CEG_ERR_HIP, "hipSetDevice(%d) failed", p->device);
+    const size_t n = (size_t)p->ib.nimages;
+    const size_t nbins = (size_t)p->ib.nb[0] * p->ib.nb[1] * p->ib.nb[2];
+    if (nb) for (int a = 0; a < 3; ++a) nb[a] = p->ib.nb[a];
+    bool ok = hipDeviceSynchronize() == hipSuccess;
+    if (ok && xyzq && n) ok = hipMemcpy(xyzq, p->d_images, n * sizeof(double4), hipMemcpyDeviceToHost) == hipSuccess;
+    if (ok && kind && n && p->d_imgkind) ok = hipMemcpy(kind, p->d_imgkind, n * sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess;
+    if (ok && atom && n) ok = hipMemcpy(atom, p->d_imgatom, n * sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess;
+    if (ok && bin_start) ok = hipMemcpy(bin_start, p->d_binstart, (nbins + 1) * sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess;
+    return ok ? CEG_OK : fail(CEG_ERR_HIP, "copying the image list failed");
+}
 
 namespace {
 
@@ -2113,10 +2214,18 @@ extern "C" int ceg_interp_create_from_file(ceg_interp_t** handle, int32_t device
     if (iscoulomb) rd(&H.ewald_precision, 8);
     for (int a = 0; a < 3; ++a)
         if (H.dims[a] < 1 || H.dims[a] > (1 << 20) || !(H.size[a] > 0.0)) return fail(CEG_ERR_INVALID, "%s: not a .grid header (dims / size)", path);
-    const int64_t nodes = (int64_t)(H.dims[0] + 1) * (H.dims[1] + 1) * (H.dims[2] + 1);
+    // the node count is bounded by the FILE SIZE before anything is multiplied: with dims up to 2^20 per axis the product
+    // reaches 2^60 and nodes * 32 wraps around int64, so that a crafted header could satisfy the size check below with a small file
+    const off_t fsize = lseek(fd, 0, SEEK_END);
+    const int64_t max_nodes = fsize > (off_t)hbytes ? (int64_t)(fsize - (off_t)hbytes) / 32 : 0;
+    int64_t nodes = 1;
+    for (int a = 0; a < 3; ++a) {
+        const int64_t ext = (int64_t)H.dims[a] + 1;
+        if (nodes > max_nodes / ext) return fail(CEG_ERR_INVALID, "%s: file shorter than its header says", path);
+        nodes *= ext;
+    }
     const int64_t nfl = 8 * nodes;
     const int64_t payload = nfl * (int64_t)sizeof(float);
-    const off_t fsize = lseek(fd, 0, SEEK_END);
     if (fsize < (off_t)(hbytes + payload)) return fail(CEG_ERR_INVALID, "%s: file shorter than its header says", path);
     // header + payload [+ the 72-byte cell matrix] and nothing else: a VdW file opened as a Coulomb one (or the reverse) is off by the
     // 8 bytes of the Ewald precision and is refused here instead of being read 8 bytes out of step

@@ -224,6 +224,10 @@ CEG_API int ceg_plan_can_cull(const ceg_plan_t* plan);
 
 /* number of lattice images kept by the culled algorithm (0 before first use) */
 CEG_API int64_t ceg_plan_num_images(const ceg_plan_t* plan);
+/* The plan's lattice-image list copied to the host (diagnostics / tests: the list is built on the device since round 4 and must be
+ * byte-identical to the host build, CEG_HIP_IMAGES_ON_HOST=1): xyzq [4 n] (position + charge), kind [n] (kind | 1 << 25 when the kind
+ * has a VdW rule; -1 without rules), atom [n] (index of the framework atom), bin_start [nb0 nb1 nb2 + 1]; any output may be NULL. */
+CEG_API int ceg_plan_copy_images(const ceg_plan_t* plan, double* xyzq, int32_t* kind, int32_t* atom, int32_t* bin_start, int32_t nb[3]);
 
 /*
  * Build x-planes i in [i_begin, i_end) (0 <= i_begin <= i_end <= dims[0]+1).

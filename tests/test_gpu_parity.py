@@ -957,6 +957,74 @@ def test_consumer_edge_cases(hip_lib, oracle):
     rec.close()
 
 
+def _plan_images(hip_lib, plan_handle):
+    import ctypes as C
+    n = int(hip_lib.ceg_plan_num_images(plan_handle))
+    nb = np.zeros(3, dtype=np.int32)
+    _abi.check(hip_lib, hip_lib.ceg_plan_copy_images(plan_handle, None, None, None, None, _abi.i32ptr(nb)))
+    xyzq = np.empty((n, 4)); kind = np.full(n, -7, dtype=np.int32); atom = np.empty(n, dtype=np.int32)
+    start = np.empty(int(nb.prod()) + 1, dtype=np.int32)
+    _abi.check(hip_lib, hip_lib.ceg_plan_copy_images(plan_handle, _abi.dptr(xyzq.reshape(-1)), _abi.i32ptr(kind), _abi.i32ptr(atom), _abi.i32ptr(start), _abi.i32ptr(nb)))
+    return xyzq, kind, atom, start, tuple(int(x) for x in nb)
+
+
+@pytest.mark.parametrize("case", ["roofline-fused", "cit7-vdw-only", "cha-coulomb-only", "skewed-synthetic"])
+def test_image_list_built_on_the_device(hip_lib, monkeypatch, case):
+    """The lattice-image list of a plan is built ON THE DEVICE since round 4 (csrc/ceg_images.hip: count / scan / emit / stable radix
+    sort by bin / gather) instead of by the host loop of build_images (csrc/ceg_api.hip) -- the host-side analogue of the ProbeSystem
+    tiling, probes.jl:37-53.  The two builds must agree BYTE for byte: positions, charges, kind + rule flags, atom indices, bin
+    starts -- for a fused plan (every atom listed), a VdW-only plan (atoms without a rule left out), a Coulomb-only plan (no kinds)
+    and a skewed synthetic cell; and a build through each list gives bit-identical grids."""
+    from ceg_hip.plan import GridPlan
+    import torch
+    monkeypatch.setenv("CEG_HIP_IMAGE_CACHE", "0")                  # every plan builds its own list
+    if case == "roofline-fused":
+        w = W.roofline_workload("Ar", 63)
+        args = (w.cset, w.probe_vdw, w.probe_coulomb, w.alpha)
+    elif case == "cit7-vdw-only":
+        w = W.fixture_workload("CIT-7", "Ar", 0.5)
+        args = (w.cset, w.probe_vdw, None, 0.0)
+    elif case == "cha-coulomb-only":
+        w = W.fixture_workload("CHA_1.4_3b4eeb96", "Na", 0.6)
+        args = (w.cset, None, w.probe_coulomb, w.alpha)
+    else:
+        mat = mat_from_parameters((30.0, 33.0, 36.0), (65.0, 110.0, 75.0))
+        rng = np.random.default_rng(12)
+        pos = random_atoms(mat, 200, rng)
+        pv, pc = synthetic_probes(mat, pos, rng.integers(1, 5, 200), rng.uniform(-1, 1, 200))
+        cset = W.grid_setup_with_dims(mat, (23, 19, 17))
+        w = None
+        args = (cset, pv, pc, 0.265)
+    lists, grids = {}, {}
+    for where in ("device", "host"):
+        if where == "host":
+            monkeypatch.setenv("CEG_HIP_IMAGES_ON_HOST", "1")
+        else:
+            monkeypatch.delenv("CEG_HIP_IMAGES_ON_HOST", raising=False)
+        plan = GridPlan(*args)
+        lists[where] = _plan_images(hip_lib, plan._h)
+        cset = args[0]
+        nx, ny, nz = cset.npoints
+        out = torch.full((8, nx, ny, nz), float("nan"), dtype=torch.float32, device="cuda")
+        if args[1] is not None:
+            plan.build_vdw(out.data_ptr(), nx * ny * nz, 0, nx)
+        else:
+            plan.build_coulomb(out.data_ptr(), nx * ny * nz, 0, nx)
+        torch.cuda.synchronize()
+        grids[where] = out.cpu().numpy()
+        plan.close()
+    d, h = lists["device"], lists["host"]
+    assert d[4] == h[4] and len(d[0]) == len(h[0]) > 0
+    assert np.array_equal(d[0].view(np.int64), h[0].view(np.int64)), "positions / charges differ"
+    assert np.array_equal(d[1], h[1]) and np.array_equal(d[2], h[2]) and np.array_equal(d[3], h[3])
+    assert d[3][0] == 0 and d[3][-1] == len(d[0]) and (np.diff(d[3]) >= 0).all()
+    if case == "cit7-vdw-only":                                     # Si / Al carry no Ar rule: a third of the framework is not listed
+        assert (d[1] >> 25 & 1).all() and len(np.unique(d[2])) < 1080
+    if case == "cha-coulomb-only":
+        assert (d[1] == -1).all()                                   # a Coulomb-only plan carries no kinds
+    assert np.array_equal(grids["device"].view(np.int32), grids["host"].view(np.int32))
+
+
 def test_bench_line_and_exchange_rehearsal(hip_lib):
     """bench.py as the driver runs it: exactly ONE line on stdout, valid JSON with the contract's keys, the
     roofline / cpu_baseline objects, and -- with --force-exchange -- the N > 1 code path (RCCL group, chunked
@@ -1547,6 +1615,15 @@ def test_cached_grid_file_straight_to_the_device(hip_lib, oracle, tmp_path, forc
         with pytest.raises(_abi.CegError) as ei:
             GridInterpolator.from_file(tmp_path / bad, False)
         assert ei.value.code == -1
+    # a crafted header whose point count wraps around 64 bits (dims 2^20 - 1 on every axis: nodes = 2^60, nodes * 32 = 2^65 = 0 mod 2^64,
+    # so that "header + payload == file size" would hold for a header-only file): refused before anything is allocated or read
+    import struct
+    crafted = bytearray(data[:128])
+    crafted[8:20] = struct.pack("<3i", 2 ** 20 - 1, 2 ** 20 - 1, 2 ** 20 - 1)
+    (tmp_path / "crafted.grid").write_bytes(bytes(crafted))
+    with pytest.raises(_abi.CegError) as ei:
+        GridInterpolator.from_file(tmp_path / "crafted.grid", False)
+    assert ei.value.code == -1 and "shorter" in str(ei.value)
     for wrong, isc in (("v.grid", True), ("c.grid", False)):           # a VdW file opened as a Coulomb grid and the reverse
         with pytest.raises(_abi.CegError) as ei:
             GridInterpolator.from_file(tmp_path / wrong, isc)
