@@ -12,7 +12,7 @@ from typing import Optional
 import numpy as np
 
 from . import _abi
-from .ewald import EwaldFramework, ewald_context_constants
+from .hostmirror.ewald import EwaldFramework, ewald_context_constants
 from .grids import CrystalEnergySetup, _matT
 from .interp import GridInterpolator
 
@@ -125,7 +125,7 @@ class PairEnergies:
     """Device-resident guest atoms + pair table (``ceg_pairs_*``): batched single_contribution_vdw."""
 
     def __init__(self, ff, mat, invmat, device: int = 0):
-        from .constants import COULOMBIC_CONVERSION_FACTOR
+        from .hostmirror.constants import COULOMBIC_CONVERSION_FACTOR
         self._lib = _abi.load_library()
         self.ff = ff
         rules, offsets = ff.pair_table()
@@ -164,12 +164,12 @@ class PairEnergies:
 
 
 class GpuMonteCarloEnergy:
-    """``movement_energy`` (montecarlo.jl:563-579) of a :class:`ceg_hip.montecarlo.MonteCarloSetup` for
+    """``movement_energy`` (montecarlo.jl:563-579) of a :class:`ceg_hip.hostmirror.montecarlo.MonteCarloSetup` for
     many trial placements at once: framework terms by batched grid interpolation, guest-guest terms by
     ``ceg_pairs_*``, reciprocal term by ``ceg_recip_*`` against the structure factor of everything else."""
 
     def __init__(self, mc, device: int = 0):
-        from . import montecarlo as M
+        from .hostmirror import montecarlo as M
         self.mc, self._M = mc, M
         self.interp = [GridInterpolator(g, device) if (g is not None and g.ewald_precision == math.inf) else None for g in mc.grids]
         self.has_coulomb = mc.coulomb.ewald_precision != -math.inf
@@ -241,12 +241,12 @@ class GpuMonteCarloEnergy:
 
 
 class DeviceMonteCarlo:
-    """Device-resident energy state of a :class:`ceg_hip.montecarlo.MonteCarloSetup` (``ceg_mc_*``, BASELINE config 5):
+    """Device-resident energy state of a :class:`ceg_hip.hostmirror.montecarlo.MonteCarloSetup` (``ceg_mc_*``, BASELINE config 5):
     ``movement_energy`` (montecarlo.jl:563-579) of a batch of trial placements in ONE launch, ``update_mc!``
     (montecarlo.jl:615-628) applied on the device.  The MC driver (proposals, acceptance) stays with the caller."""
 
     def __init__(self, mc, device: int = 0):
-        from .constants import COULOMBIC_CONVERSION_FACTOR
+        from .hostmirror.constants import COULOMBIC_CONVERSION_FACTOR
         self._lib = _abi.load_library()
         self.mc = mc
         ff = mc.ff
@@ -356,8 +356,8 @@ class DeviceMonteCarlo:
         """baseline_energy (montecarlo.jl:530-542) from the device-resident state: framework and guest-guest terms from row 0 of one
         trial launch per molecule (every pair is seen from both sides, hence the 1/2), the reciprocal term from the total guest
         structure factor kept on the device and the two EwaldContext constants (ewald.jl:497-544)."""
-        from . import montecarlo as M
-        from .ewald import ewald_context_constants
+        from .hostmirror import montecarlo as M
+        from .hostmirror.ewald import ewald_context_constants
         mc = self.mc
         fv = fd = inter = 0.0
         for i, kind in enumerate(self._slot):

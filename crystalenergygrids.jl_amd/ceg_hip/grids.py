@@ -19,12 +19,12 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _abi
-from .constants import COULOMBIC_CONVERSION_FACTOR, GRID_TO_KELVIN, tricubic_coeff
-from .coordinates import CellMatrix, GridCoordinatesSetup, offsetpoint
-from .ewald import EwaldFramework, compute_ewald, initialize_ewald
-from .forcefields import ForceField
-from .probes import ProbeSystem
-from .utils import find_supercell
+from .hostmirror.constants import COULOMBIC_CONVERSION_FACTOR, GRID_TO_KELVIN, tricubic_coeff
+from .hostmirror.coordinates import CellMatrix, GridCoordinatesSetup, offsetpoint
+from .hostmirror.ewald import EwaldFramework, compute_ewald, initialize_ewald
+from .hostmirror.forcefields import ForceField
+from .hostmirror.probes import ProbeSystem
+from .hostmirror.utils import find_supercell
 
 
 # ------------------------------------------------------------------ EnergyGrid
@@ -462,7 +462,7 @@ class BlockFile:
 def read_block_spheres(file, csetup: GridCoordinatesSetup):
     """The host part of parse_blockfile (coordinates.jl:113-133): sphere centres snapped through
     offsetpoint / inverse_offsetpoint, squared radii -> (centers[n, 3], radius2[n])."""
-    from .coordinates import inverse_offsetpoint
+    from .hostmirror.coordinates import inverse_offsetpoint
     with open(file) as f:
         lines = f.read().splitlines()
     num = int(lines.pop(0))
@@ -478,7 +478,7 @@ def read_block_spheres(file, csetup: GridCoordinatesSetup):
 
 def parse_blockfile_gpu(file, csetup: GridCoordinatesSetup, device: int = 0) -> BlockFile:
     """parse_blockfile with the point x sphere scan (coordinates.jl:139-152) on the GPU (``ceg_block_spheres``)."""
-    from .utils import prepare_periodic_distance_computations
+    from .hostmirror.utils import prepare_periodic_distance_computations
     centers, radius2 = read_block_spheres(file, csetup)
     if len(radius2) == 0:
         return BlockFile(csetup)
@@ -506,8 +506,8 @@ def blockfile_from_grid_gpu(g: EnergyGrid, device: int = 0, threshold: float = 5
 
 def parse_blockfile(file, csetup: GridCoordinatesSetup) -> BlockFile:
     """coordinates.jl:112-167 (min-image sphere test on every grid point), host-side numpy mirror."""
-    from .coordinates import inverse_offsetpoint
-    from .utils import prepare_periodic_distance_computations
+    from .hostmirror.coordinates import inverse_offsetpoint
+    from .hostmirror.utils import prepare_periodic_distance_computations
     with open(file) as f:
         lines = f.read().splitlines()
     num = int(lines.pop(0))

@@ -181,7 +181,7 @@ class ForceField:
         ``rules`` structured array + ``rule_offset`` (nkinds+1 int32), i.e. what
         ``derivatives_nocutoff(ff, kind_i, probe, d2)`` (forcefields.jl:302-304) dispatches
         on.  Raises the Julia-side errors for kinds ``derivativesGrid`` rejects."""
-        from ._abi import RULE_DTYPE
+        from .._abi import RULE_DTYPE
         flat: List[InteractionRule] = []
         offsets = [0]
         for k in range(self.nkinds):
@@ -200,7 +200,7 @@ class ForceField:
     def pair_table(self):
         """Every pair rule flattened for ``ceg_pairs_create``: ``rules`` structured array and
         ``rule_offset`` (nkinds*nkinds + 1 int32), pair (a, b) 0-based at index ``a*nkinds + b``."""
-        from ._abi import RULE_DTYPE
+        from .._abi import RULE_DTYPE
         flat: List[InteractionRule] = []
         offsets = [0]
         for a in range(self.nkinds):

@@ -18,7 +18,7 @@ import numpy as np
 from .coordinates import GridCoordinatesSetup
 from .ewald import EwaldFramework, _structure_factor, ewald_context_constants, initialize_ewald
 from .forcefields import ForceField
-from .grids import EnergyGrid, interpolate_grid
+from ..grids import EnergyGrid, interpolate_grid
 from .raspa import RASPASystem, _ff, load_framework_RASPA
 from .setup_raspa import decide_parse_block, default_system, grid_locations, retrieve_or_create_grid
 from .utils import find_supercell, get_atom_name, perpendicular_lengths

@@ -11,9 +11,9 @@ import numpy as np
 
 from .ewald import EwaldFramework, initialize_ewald
 from .forcefields import ForceField
-from .grids import (BlockFile, CrystalEnergySetup, EnergyGrid, create_grid_coulomb, create_grid_vdw, create_grids_multi,
+from ..grids import (BlockFile, CrystalEnergySetup, EnergyGrid, create_grid_coulomb, create_grid_vdw, create_grids_multi,
                     parse_blockfile, parse_blockfile_gpu, parse_grid)
-from . import _abi
+from .. import _abi
 from .coordinates import GridCoordinatesSetup
 from .raspa import (RASPASystem, _ff, _ffname, _ffpal, getdir_RASPA, load_framework_RASPA,
                     load_molecule_RASPA)

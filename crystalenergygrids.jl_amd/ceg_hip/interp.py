@@ -50,8 +50,8 @@ class GridInterpolator:
         + ``GridInterpolator(g)`` do, without the host array -- payload streamed file -> pinned ring -> device, scaled by
         GRID_TO_KELVIN there.  ``mat``: the unit-cell matrix as for ``parse_grid``; None = the one stored in the file."""
         import os
-        from .constants import GRID_TO_KELVIN
-        from .coordinates import CellMatrix
+        from .hostmirror.constants import GRID_TO_KELVIN
+        from .hostmirror.coordinates import CellMatrix
         self = cls.__new__(cls)
         self._lib = _abi.load_library()
         m = i = None

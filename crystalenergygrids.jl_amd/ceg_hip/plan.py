@@ -14,9 +14,9 @@ from typing import Optional
 import numpy as np
 
 from . import _abi
-from .coordinates import GridCoordinatesSetup
+from .hostmirror.coordinates import GridCoordinatesSetup
 from .grids import _grid_args, _matT, coulomb_scaling, vdw_scaling
-from .probes import ProbeSystem
+from .hostmirror.probes import ProbeSystem
 
 
 class GridPlan:

@@ -10,11 +10,11 @@ from typing import Optional, Tuple
 import numpy as np
 
 from ._abi import REPO_DIR
-from .coordinates import CellMatrix, GridCoordinatesSetup
-from .ewald import ewald_alpha
-from .forcefields import ForceField
-from .probes import ProbeSystem
-from .raspa import RASPASystem, load_framework_RASPA, parse_forcefield_RASPA, setdir_RASPA
+from .hostmirror.coordinates import CellMatrix, GridCoordinatesSetup
+from .hostmirror.ewald import ewald_alpha
+from .hostmirror.forcefields import ForceField
+from .hostmirror.probes import ProbeSystem
+from .hostmirror.raspa import RASPASystem, load_framework_RASPA, parse_forcefield_RASPA, setdir_RASPA
 
 FIXTURE_RASPA = REPO_DIR / "tests" / "golden" / "raspa"
 FORCEFIELD = "BoulfelfelSholl2021"
@@ -138,7 +138,7 @@ def synthetic_workload(natoms: int, n: int = 127, edge: float = 40.0, seed: int 
     """SURVEY §8d fully synthetic sweep variant: orthorhombic ``edge`` A cube, ``natoms`` uniform-random
     atoms with 1.5 A minimum separation (``numpy.random.default_rng(seed)``), a single LJ kind
     (eps = 100 K, sigma = 3 A, shifted at the 12 A cutoff), charges +1/-1 alternating; (n+1)^3 grid."""
-    from .interactions import FF, InteractionRule, make_rule
+    from .hostmirror.interactions import FF, InteractionRule, make_rule
     rng = np.random.default_rng(seed)
     pos = _random_atoms_min_sep(natoms, edge, 1.5, rng)
     mat = np.diag([edge] * 3)
@@ -188,7 +188,7 @@ def count_pair_work(w: Workload, planes: int = 8, stride: int = 4) -> dict:
     out = {"sampled_points": int(len(pts)), "in_cutoff_per_point": float(np.mean(n_in)), "lj_per_point": 0.0,
            "buckingham_per_point": 0.0, "other_vdw_per_point": 0.0}
     if w.probe_vdw is not None:
-        from .interactions import FF, rules_of
+        from .hostmirror.interactions import FF, rules_of
         ff, probe = w.forcefield, w.probe_vdw.probe
         kinds = np.asarray(w.probe_vdw.atomkinds)
         cls = np.zeros(ff.nkinds + 1, dtype=np.int8)           # 0 none, 1 LJ, 2 Buckingham (+ hard sphere), 3 anything else

@@ -1,6 +1,6 @@
 """Host-side pieces of the reference the CHECKER needs, restated under oracle/ so that the oracle does not
-import the product package's host mirror (a bug in ``ceg_hip.ewald`` / ``ceg_hip.utils`` /
-``ceg_hip.constants`` used to be common-mode to the GPU path and to its checker).
+import the product package's host mirror (a bug in ``ceg_hip.hostmirror.ewald`` / ``ceg_hip.hostmirror.utils`` /
+``ceg_hip.hostmirror.constants`` used to be common-mode to the GPU path and to its checker).
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, ``__graft_entry__.smoke()`` and bench.py's ``cpu_baseline`` /
 self-check legs -- never by the product package.  Nothing here imports ``ceg_hip``.

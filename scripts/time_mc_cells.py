@@ -8,8 +8,8 @@ sys.path[:0] = [os.path.join(here, '..', 'crystalenergygrids.jl_amd')]
 import numpy as np
 import ceg_hip as ceg
 from ceg_hip import _abi
-from ceg_hip.constants import COULOMBIC_CONVERSION_FACTOR
-from ceg_hip.utils import mat_from_parameters
+from ceg_hip.hostmirror.constants import COULOMBIC_CONVERSION_FACTOR
+from ceg_hip.hostmirror.utils import mat_from_parameters
 
 ceg.setdir_RASPA(os.path.join(here, '..', 'tests', 'golden', 'raspa'))
 FF = "BoulfelfelSholl2021"

@@ -4,8 +4,8 @@ sys.path[:0] = [os.path.join(here, '..', 'crystalenergygrids.jl_amd'), os.path.j
 import numpy as np, torch
 from ceg_hip import workloads as W
 from ceg_hip.plan import GridPlan
-from ceg_hip.raspa import RASPASystem
-from ceg_hip.probes import ProbeSystem
+from ceg_hip.hostmirror.raspa import RASPASystem
+from ceg_hip.hostmirror.probes import ProbeSystem
 
 def t(w, mode="vdw", reps=5):
     plan = GridPlan(w.cset, w.probe_vdw, w.probe_coulomb, w.alpha)

@@ -70,7 +70,7 @@ def headers():
     (grids.jl:108-116 header, :154/:182 trailer, :180 Ewald precision) for the fixtures' default grids."""
     import io
     import json
-    from ceg_hip.utils import find_supercell
+    from ceg_hip.hostmirror.utils import find_supercell
     out = {}
     for fwname, spacing in (("CHA_1.4_3b4eeb96", 0.15), ("CHA_1.4_3b4eeb96", 0.5), ("CIT-7", 0.15)):
         w = W.fixture_workload(fwname, "Ar", spacing, coulomb=False)

@@ -8,8 +8,8 @@ sys.path[:0] = [os.path.join(here, '..', '..', 'crystalenergygrids.jl_amd'), os.
 import numpy as np
 import ceg_hip as ceg
 from ceg_hip.energy import ReciprocalEwald
-from ceg_hip.raspa import RASPASystem
-from ceg_hip.utils import mat_from_parameters
+from ceg_hip.hostmirror.raspa import RASPASystem
+from ceg_hip.hostmirror.utils import mat_from_parameters
 from oracle import oracle as O
 
 n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 200

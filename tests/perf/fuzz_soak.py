@@ -6,7 +6,7 @@ sys.path[:0] = [os.path.join(here, '..', '..', 'crystalenergygrids.jl_amd'), os.
 import numpy as np
 from ceg_hip import _abi, grids as G, workloads as W
 from ceg_hip.plan import GridPlan
-from ceg_hip.utils import mat_from_parameters, perpendicular_lengths
+from ceg_hip.hostmirror.utils import mat_from_parameters, perpendicular_lengths
 from oracle import oracle as O
 from oracle.compare import compare_grids
 from util import compare_raw, grid_points, random_atoms, synthetic_probes

@@ -7,7 +7,7 @@ sys.path[:0] = [os.path.join(here, '..', '..', 'crystalenergygrids.jl_amd'), os.
 import numpy as np
 import ceg_hip as ceg
 from ceg_hip import grids as G
-from ceg_hip.probes import ProbeSystem
+from ceg_hip.hostmirror.probes import ProbeSystem
 from oracle import oracle as O
 ceg.setdir_RASPA(os.path.join(here, '..', 'golden', 'raspa'))
 FF = "BoulfelfelSholl2021"
@@ -49,7 +49,7 @@ def report(name, fwname, pos, literal, supercell=None):
     cset = ceg.GridCoordinatesSetup.from_cell(fw.mat, 0.15)
     pv = ProbeSystem.build(fw, ff, "Na")
     pc = ProbeSystem.build(fw, ff)
-    from ceg_hip.utils import find_supercell
+    from ceg_hip.hostmirror.utils import find_supercell
     sc = tuple(find_supercell(fw.mat, 12.0))
     ew = ceg.initialize_ewald(fw, sc)
     na = ceg.load_molecule_RASPA("Na", "TraPPE", FF, fw)
@@ -67,7 +67,7 @@ def report(name, fwname, pos, literal, supercell=None):
 
 
 if __name__ == "__main__":
-    from ceg_hip import montecarlo as M
+    from ceg_hip.hostmirror import montecarlo as M
     # --- Na in CIT-7 (runtests.jl:222-228)
     solo = [-4.728415488310421, 32.03533696753957, 2.943765448968882]
     v, d, r, vx, dx, ctx = report("baseSolo", "CIT-7", solo, -21375.116833457894)
@@ -99,7 +99,7 @@ if __name__ == "__main__":
     print(f"   total {vm + dm + rm:.6f}   literal -1927894.436476   residue {vm + dm + rm + 1927894.4364761321:+.4f} K;  with exact framework terms "
           f"{vxm + dxm + rm + 1927894.4364761321:+.4f} K")
     # --- Ewald convergence of the restatement: exact direct sum + reciprocal sum for precision 1e-6 ... 1e-12
-    from ceg_hip.utils import find_supercell
+    from ceg_hip.hostmirror.utils import find_supercell
     fwc = ceg.load_framework_RASPA("CIT-7", FF)
     pcc = ProbeSystem.build(fwc, ff)
     nac = ceg.load_molecule_RASPA("Na", "TraPPE", FF, fwc)

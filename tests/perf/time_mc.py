@@ -7,7 +7,8 @@ here = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [os.path.join(here, '..', '..', 'crystalenergygrids.jl_amd'), os.path.join(here, '..', '..')]
 import numpy as np
 import ceg_hip as ceg
-from ceg_hip import montecarlo as M, workloads as W
+from ceg_hip import workloads as W
+from ceg_hip.hostmirror import montecarlo as M
 from ceg_hip.energy import DeviceMonteCarlo
 from oracle import oracle as O
 
@@ -102,5 +103,5 @@ print(f"CPU oracle, 1 thread, per placement: pairs {t_pair / n * 1e6:.1f} us + i
 t = time.perf_counter()
 for k in range(20):
     M.movement_energy(mc, idx, trial[k])
-print(f"Python host mirror ceg_hip.montecarlo.movement_energy: {(time.perf_counter() - t) / 20 * 1e6:.0f} us per placement")
+print(f"Python host mirror ceg_hip.hostmirror.montecarlo.movement_energy: {(time.perf_counter() - t) / 20 * 1e6:.0f} us per placement")
 dev.close()

@@ -5,7 +5,8 @@ here = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [os.path.join(here, '..', '..', 'crystalenergygrids.jl_amd'), os.path.join(here, '..', '..')]
 import numpy as np, torch
 import ceg_hip as ceg
-from ceg_hip import _abi, montecarlo as M, grids as G, workloads as W
+from ceg_hip import _abi, grids as G, workloads as W
+from ceg_hip.hostmirror import montecarlo as M
 from ceg_hip.energy import PairEnergies
 from oracle import oracle as O
 ceg.setdir_RASPA(os.path.join(here, '..', 'golden', 'raspa'))

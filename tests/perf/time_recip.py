@@ -7,7 +7,7 @@ import numpy as np, torch
 import ceg_hip as ceg
 from ceg_hip import _abi
 from ceg_hip.energy import ReciprocalEwald
-from ceg_hip.ewald import ewald_context_constants
+from ceg_hip.hostmirror.ewald import ewald_context_constants
 from oracle import oracle as O
 ceg.setdir_RASPA(os.path.join(here, '..', 'golden', 'raspa'))
 fw = ceg.load_framework_RASPA("CHA_1.4_3b4eeb96", "BoulfelfelSholl2021")

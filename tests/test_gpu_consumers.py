@@ -10,7 +10,7 @@ import pytest
 
 import ceg_hip as ceg
 from ceg_hip import _abi, workloads as W
-from ceg_hip.constants import COULOMBIC_CONVERSION_FACTOR
+from ceg_hip.hostmirror.constants import COULOMBIC_CONVERSION_FACTOR
 
 pytestmark = pytest.mark.gpu
 
@@ -104,7 +104,7 @@ def test_pairs_config5_scale(hip_lib, oracle, forcefield, trial_mol):
 
 def _synthetic_table(nkinds, alpha, rng, cutoff):
     """Every pair: shifted LJ + CoulombEwaldDirect(alpha); a quarter of them Buckingham instead of LJ."""
-    from ceg_hip.interactions import FF
+    from ceg_hip.hostmirror.interactions import FF
     rules = np.zeros(2 * nkinds * nkinds, dtype=_abi.RULE_DTYPE)
     offsets = np.arange(0, 2 * nkinds * nkinds + 1, 2, dtype=np.int32)
     q = rng.uniform(-1.0, 1.0, nkinds)
@@ -156,7 +156,7 @@ def _mc_setup(tmp_path):
     """Na + 4 CO2 in CIT-7 (2x3x3 supercell, triclinic): grids at 0.15 A built by the HIP kernels via setup_montecarlo."""
     import os
     from pathlib import Path
-    from ceg_hip import montecarlo as M
+    from ceg_hip.hostmirror import montecarlo as M
     golden = Path(__file__).parent / "golden" / "raspa"
     raspa = tmp_path / "raspa"
     raspa.mkdir()
@@ -190,7 +190,7 @@ def test_mc_replay_1000_moves(hip_lib, tmp_path):
     between moves) and on the ORACLE's state (oracle/montecarlo.OracleMonteCarlo: movement_energy composed of the C restatements
     oracle_interpolate_grid + oracle_single_contribution_vdw + power-table structure factors + the rest sum of ewald.jl:718-737,
     nothing of the product package in it); every movement_energy (before, after; four terms) must agree to 1e-9, and so must
-    the final positions and total structure factor.  The host mirror ceg_hip.montecarlo is checked as a second assert."""
+    the final positions and total structure factor.  The host mirror ceg_hip.hostmirror.montecarlo is checked as a second assert."""
     from ceg_hip.energy import DeviceMonteCarlo
     from oracle.montecarlo import OracleMonteCarlo
     try:
@@ -672,7 +672,8 @@ def test_incremental_ewald_context_testset(hip_lib, monkeypatch):
     """The reference's "IncrementalEwaldContext" testset, runtests.jl:61-121, on the device-resident state: the flat index a
     removal returns (the last species takes the freed index, ewald.jl:403-431), the index an addition returns, and after every
     step the total guest structure factor (hence compute_ewald) equal to that of the equivalent system built from scratch."""
-    from ceg_hip import grids as G, montecarlo as M
+    from ceg_hip import grids as G
+    from ceg_hip.hostmirror import montecarlo as M
     from ceg_hip.energy import DeviceMonteCarlo
     monkeypatch.setattr(M, "retrieve_or_create_grid", lambda *a, **k: G.EnergyGrid.trivial(True))      # Ewald only: no grids
     na = ceg.load_molecule_RASPA("Na", "TraPPE", "BoulfelfelSholl2021")

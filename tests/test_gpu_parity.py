@@ -13,7 +13,7 @@ import pytest
 import ceg_hip as ceg
 from ceg_hip import _abi, grids as G, workloads as W
 from ceg_hip.plan import GridPlan
-from ceg_hip.utils import mat_from_parameters, perpendicular_lengths, prepare_periodic_distance_computations
+from ceg_hip.hostmirror.utils import mat_from_parameters, perpendicular_lengths, prepare_periodic_distance_computations
 from oracle.compare import compare_grids
 
 from util import compare_raw, grid_points, random_atoms, synthetic_probes
@@ -673,7 +673,7 @@ def test_device_resident_oneshot(hip_lib, monkeypatch):
     (oversubscribed onto one card where there is only one) 2-4 slabs incl. uneven splits; and the grid goes on to the
     interpolation consumer without leaving the GPU (ceg_scale_grid_device + ceg_interp_create on the device pointer)."""
     import torch
-    from ceg_hip.constants import GRID_TO_KELVIN
+    from ceg_hip.hostmirror.constants import GRID_TO_KELVIN
     from ceg_hip.interp import GridInterpolator
     n = hip_lib.ceg_device_count()
     w = W.fixture_workload("CIT-7", "Ar", 0.6)
@@ -736,7 +736,7 @@ def test_reciprocal_rows_layout_edge_cases(hip_lib, oracle):
     a 16-atom rigid molecule, and a replaced structure factor -- each against the oracle / against the sorted order."""
     import ctypes as C
     from ceg_hip.energy import ReciprocalEwald
-    from ceg_hip.ewald import ewald_context_constants
+    from ceg_hip.hostmirror.ewald import ewald_context_constants
     rng = np.random.default_rng(77)
     fw = ceg.load_framework_RASPA("CIT-7", "BoulfelfelSholl2021")
     co2 = ceg.load_molecule_RASPA("CO2", "TraPPE", "BoulfelfelSholl2021")
@@ -916,7 +916,7 @@ def test_consumer_edge_cases(hip_lib, oracle):
     larger than the kernels hold, a trial atom exactly on a guest atom (r = 0), the excluded molecule
     being the only one."""
     import ctypes as C
-    from ceg_hip import montecarlo as M
+    from ceg_hip.hostmirror import montecarlo as M
     from ceg_hip.energy import PairEnergies, ReciprocalEwald
     ff = ceg.parse_forcefield_RASPA("BoulfelfelSholl2021")
     co2 = ceg.load_molecule_RASPA("CO2", "TraPPE", "BoulfelfelSholl2021")
@@ -1474,7 +1474,7 @@ def test_setup_raspa_builds_missing_grids_in_one_pass(hip_lib, oracle, tmp_path)
         # the same values as the one-by-one path
         calls = []
         real = G.create_grids_multi
-        import ceg_hip.setup_raspa as SR
+        import ceg_hip.hostmirror.setup_raspa as SR
         SR.create_grids_multi = lambda *a, **k: (calls.append(a[5]), real(*a, **k))[1]
         try:
             na = ceg.setup_RASPA("CIT-7", "BoulfelfelSholl2021", "Na", gridstep=0.6, new=True)
@@ -1483,7 +1483,7 @@ def test_setup_raspa_builds_missing_grids_in_one_pass(hip_lib, oracle, tmp_path)
         assert len(calls) == 1 and len(calls[0]) == 1, calls
         # the multi path never leaves a truncated file at a cache path: the second of the two files fails half way ->
         # neither target is touched, no temporary stays behind, and the next call builds both
-        from ceg_hip.raspa import getdir_RASPA
+        from ceg_hip.hostmirror.raspa import getdir_RASPA
         raspa = Path(getdir_RASPA())
         before = {p: p.read_bytes() for p in (raspa / "grids").rglob("*") if p.is_file()}
         assert len(before) >= 2

@@ -11,10 +11,10 @@ import pytest
 
 import ceg_hip as ceg
 from ceg_hip import _abi, grids as G, workloads as W
-from ceg_hip.constants import tricubic_coeff
-from ceg_hip.interactions import FF, InteractionRule, InteractionRuleSum, make_rule
-from ceg_hip.probes import ProbeSystem
-from ceg_hip.utils import find_supercell, get_atom_name, mat_from_parameters, prepare_periodic_distance_computations
+from ceg_hip.hostmirror.constants import tricubic_coeff
+from ceg_hip.hostmirror.interactions import FF, InteractionRule, InteractionRuleSum, make_rule
+from ceg_hip.hostmirror.probes import ProbeSystem
+from ceg_hip.hostmirror.utils import find_supercell, get_atom_name, mat_from_parameters, prepare_periodic_distance_computations
 
 ROOT = Path(__file__).resolve().parent.parent
 FFNAME = "BoulfelfelSholl2021"
@@ -254,7 +254,7 @@ def test_rule_table_flattening():
 
 def test_vdw_grid_rule_errors_mirror_reference():
     """interactions.jl:442-443,462-467: the shim raises before the device call."""
-    from ceg_hip.interactions import check_vdw_grid_rule, UndefinedInteractionError
+    from ceg_hip.hostmirror.interactions import check_vdw_grid_rule, UndefinedInteractionError
     with pytest.raises(UndefinedInteractionError):
         check_vdw_grid_rule(make_rule(FF.UndefinedInteraction))
     with pytest.raises(RuntimeError, match="Monomial"):

@@ -1,6 +1,6 @@
 """Row f3 (guest-guest energies) and the consumers of the grids: the reference's Monte-Carlo
 energy literals of ``test/runtests.jl:186-267`` (CIT-7, 2x3x3 supercell, triclinic), rebuilt with
-the host mirror ``ceg_hip.montecarlo`` on top of grids whose needed corners come from the CPU
+the host mirror ``ceg_hip.hostmirror.montecarlo`` on top of grids whose needed corners come from the CPU
 oracle.  Each literal exercises the VdW grids (Ar: LJ; Na: Buckingham + hard sphere; CO2: O/C LJ),
 the Coulomb grid, reciprocal Ewald for several molecules, guest-guest pair terms and the tail
 correction at once; rtol is 1e-3 in the reference, the observed agreement is recorded per assert."""
@@ -10,8 +10,9 @@ import numpy as np
 import pytest
 
 import ceg_hip as ceg
-from ceg_hip import grids as G, montecarlo as M
-from ceg_hip.probes import ProbeSystem
+from ceg_hip import grids as G
+from ceg_hip.hostmirror import montecarlo as M
+from ceg_hip.hostmirror.probes import ProbeSystem
 
 from test_reference_pins import FFNAME, interpolate_with_oracle
 
@@ -23,7 +24,7 @@ class OracleGrid(G.EnergyGrid):
 @pytest.fixture()
 def oracle_grids(oracle, forcefield, monkeypatch):
     """setup_montecarlo with grids that are never built: each interpolation asks the oracle for its 8 corners."""
-    from ceg_hip.utils import find_supercell
+    from ceg_hip.hostmirror.utils import find_supercell
     probes = {}
 
     def fake_retrieve(grid_path, syst_framework, ff, gridstep, atom_or_ef, mat, new, cutoff, ngpus=1):

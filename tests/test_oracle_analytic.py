@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from ceg_hip import _abi
-from ceg_hip.utils import mat_from_parameters, prepare_periodic_distance_computations
+from ceg_hip.hostmirror.utils import mat_from_parameters, prepare_periodic_distance_computations
 
 mp.mp.dps = 40
 
@@ -188,7 +188,7 @@ def test_set_gridpoint_scaling_and_clamp(oracle):
 def test_coulomb_value_is_inf_within_one_angstrom(oracle, forcefield):
     """probes.jl:116"""
     import ceg_hip as ceg
-    from ceg_hip.probes import ProbeSystem
+    from ceg_hip.hostmirror.probes import ProbeSystem
     fw = ceg.load_framework_RASPA("CIT-7", "BoulfelfelSholl2021")
     pc = ProbeSystem.build(fw, forcefield)
     alpha = 0.26505830360350674

@@ -78,7 +78,7 @@ def test_oracle_interpolation_equals_host_mirror(oracle):
 def test_oracle_reciprocal_equals_host_mirror(oracle):
     """Row f2: the literal restatement of compute_ewald (power tables by repeated multiplication,
     reference summation order; ewald.jl:109-185, 555-577) against the direct-exponential mirror
-    ``ceg_hip.ewald.compute_ewald`` that test_reference_pins pins to the runtests.jl literals."""
+    ``ceg_hip.hostmirror.ewald.compute_ewald`` that test_reference_pins pins to the runtests.jl literals."""
     import ceg_hip as ceg
     rng = np.random.default_rng(11)
     for fwname, sc in (("CHA_1.4_3b4eeb96", (1, 1, 1)), ("CIT-7", None)):

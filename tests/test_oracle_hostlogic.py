@@ -41,7 +41,7 @@ def test_coeff_equals_the_reference_literal(oracle):
     """Three sources, one matrix: the reference's literal (golden data), the oracle's derivation (tensor product of the 1-D
     Hermite matrix) and the host mirror's derivation (rational inverse of the evaluation matrix)."""
     from oracle import hostlogic as H
-    from ceg_hip.constants import tricubic_coeff
+    from ceg_hip.hostmirror.constants import tricubic_coeff
     lit = H.reference_coeff_literal()
     assert lit.shape == (64, 64) and np.count_nonzero(lit) == 1000
     assert np.array_equal(H.tricubic_coeff(), lit)
@@ -69,7 +69,7 @@ def test_coeff_equals_the_reference_literal(oracle):
 def _cells():
     rng = np.random.default_rng(3)
     out = [ceg.load_framework_RASPA(n, FFNAME).mat for n in ("CHA_1.4_3b4eeb96", "CIT-7")]
-    from ceg_hip.utils import mat_from_parameters
+    from ceg_hip.hostmirror.utils import mat_from_parameters
     # angles around the Float16 / 2 % boundary of `ortho` (88.2 and 91.8 degrees) and exact right angles
     for ang in ((90, 90, 90), (88.19, 90, 90), (88.21, 90, 91.79), (91.81, 90, 90), (91.84, 88.17, 90.03), (90, 90, 120), (60, 60, 60)):
         out.append(mat_from_parameters((11.0, 13.5, 9.25), ang))
@@ -80,7 +80,7 @@ def _cells():
 
 def test_prepare_periodic_distance_computations_two_restatements(oracle):
     from oracle import hostlogic as H
-    from ceg_hip.utils import prepare_periodic_distance_computations
+    from ceg_hip.hostmirror.utils import prepare_periodic_distance_computations
     seen = set()
     for mat in _cells():
         o1, s1 = H.prepare_periodic_distance_computations(mat)
@@ -149,7 +149,7 @@ def test_reciprocal_ewald_two_co2_through_the_oracle_alone(oracle):
 
 def test_context_constants_two_restatements(oracle):
     from oracle import hostlogic as H
-    from ceg_hip.ewald import ewald_context_constants
+    from ceg_hip.hostmirror.ewald import ewald_context_constants
     fw = ceg.load_framework_RASPA("CIT-7", FFNAME)
     mirror = ceg.initialize_ewald(fw, (2, 3, 3))
     ef = H.adapt_ewald_framework(mirror)
@@ -165,9 +165,9 @@ def test_context_constants_two_restatements(oracle):
 
 def _small_mc(oracle, tmp_path, spacing=0.75):
     """Na + 3 CO2 in CIT-7 with REAL (coarse) grids built by the oracle's brute-force loop nest."""
-    from ceg_hip import montecarlo as M
-    from ceg_hip.utils import find_supercell
-    import ceg_hip.montecarlo as MM
+    from ceg_hip.hostmirror import montecarlo as M
+    from ceg_hip.hostmirror.utils import find_supercell
+    import ceg_hip.hostmirror.montecarlo as MM
 
     def build(grid_path, syst_framework, ff, gridstep, atom_or_ef, mat, new, cutoff, ngpus=1):
         iscoulomb = isinstance(atom_or_ef, ceg.EwaldFramework)
@@ -199,7 +199,7 @@ def _small_mc(oracle, tmp_path, spacing=0.75):
 
 def test_oracle_movement_energy_equals_the_pinned_mirror(oracle, tmp_path):
     """oracle/montecarlo.OracleMonteCarlo (C restatements: literal COEFF*X interpolation, literal pair loop, power-table structure
-    factors, the reference's summation order) against the host mirror ceg_hip.montecarlo that test_montecarlo_pins.py pins to
+    factors, the reference's summation order) against the host mirror ceg_hip.hostmirror.montecarlo that test_montecarlo_pins.py pins to
     runtests.jl:186-267 -- over displacements, rotations, insertions and removals, term by term."""
     from oracle.montecarlo import OracleMonteCarlo
     M, mc = _small_mc(oracle, tmp_path)

@@ -19,7 +19,7 @@ import pytest
 
 import ceg_hip as ceg
 from ceg_hip import grids as G
-from ceg_hip.probes import ProbeSystem
+from ceg_hip.hostmirror.probes import ProbeSystem
 
 PINS = json.loads((Path(__file__).parent / "golden" / "pins.json").read_text())
 FFNAME = "BoulfelfelSholl2021"
@@ -141,7 +141,7 @@ def test_reciprocal_ewald_two_co2(forcefield):
 
 def test_blocking_spheres(forcefield):
     """runtests.jl:269-272 -- a blocked position short-circuits energy_point to (1e100, 0)."""
-    from ceg_hip.setup_raspa import parse_block
+    from ceg_hip.hostmirror.setup_raspa import parse_block
     pin = PINS["blocked_points"]
     fw = ceg.load_framework_RASPA(pin["framework"], FFNAME)
     ar = ceg.load_molecule_RASPA("Ar", "TraPPE", FFNAME, fw)

@@ -3,10 +3,10 @@ from __future__ import annotations
 
 import numpy as np
 
-from ceg_hip.coordinates import GridCoordinatesSetup
-from ceg_hip.forcefields import ForceField
-from ceg_hip.interactions import FF, InteractionRule, InteractionRuleSum, make_rule
-from ceg_hip.probes import ProbeSystem
+from ceg_hip.hostmirror.coordinates import GridCoordinatesSetup
+from ceg_hip.hostmirror.forcefields import ForceField
+from ceg_hip.hostmirror.interactions import FF, InteractionRule, InteractionRuleSum, make_rule
+from ceg_hip.hostmirror.probes import ProbeSystem
 from ceg_hip.workloads import grid_setup_with_dims
 
 
