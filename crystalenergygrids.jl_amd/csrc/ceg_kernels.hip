@@ -1273,7 +1273,24 @@ template <int MODE, bool POINTS>
 static hipError_t launch_cull_flags(int vdwk, int ewk, hipStream_t stream, const PlanConst* pc, const Output& out, const Points& pts,
                                     int tj, int tk, int64_t ntiles)
 {
-    // flags that do not matter for a mode are normalised so fewer variants get instantiated
+    // Which k_culled<MODE, POINTS, VDWK, EWK> runs for a plan's (vdwk, ewk).  The plan classifies its rules (ceg_api.hip convert_rules:
+    // vdwk 1 = every present kind has at most one Lennard-Jones rule; 3 = one Buckingham (+ hard sphere) parameter set, G0(r^2) tabulated;
+    // 2 = per-kind Lennard-Jones / Buckingham classes; 0 = anything else, generic rule interpreter) and its Ewald arithmetic (ewk 2 = r^2-indexed
+    // tables built; 1 = erfcx table, alpha * cutoff <= 5; 0 = libm-grade).  Flags that cannot matter for a mode are normalised so that fewer
+    // variants get instantiated -- every (plan, mode) still gets arithmetic it is entitled to (a lower class is always valid for a higher one):
+    //
+    //   mode      plan (vdwk, ewk)      kernel <VDWK, EWK>   why
+    //   VDW       (v, any)              <v, 1>               no Coulomb term: EWK is dead code, one value instantiated; v = 3 keeps <3, 1>
+    //   COULOMB   (any, e)              <1, e>               no VdW term: VDWK is dead code, one value instantiated
+    //   FUSED     (0, 2)                <0, 1>               the generic rule interpreter is only instantiated beside the erfcx variant
+    //   FUSED     (0, 1) (0, 0)         <0, 1> <0, 0>
+    //   FUSED     (1, e)                <1, e>               e = 2, 1, 0
+    //   FUSED     (2, e)                <2, e>
+    //   FUSED     (3, 2)                <3, 2>               the tabulated Buckingham class shares its interval key with the Ewald tables
+    //   FUSED     (3, 1) (3, 0)         <2, 1> <2, 0>        without the r^2-indexed Ewald tables the Buckingham probe runs as class 2 (per-candidate
+    //                                                        parameters, table exp): same terms, other arithmetic, within the suite's tolerance
+    //   (ewk == 0 and vdwk == 3 in VDW mode cannot meet: MODE_VDW forces ewk = 1 first.)
+    // Multi-probe launches (launch_multi_t) are <1, 2, NP> only: Lennard-Jones probes on the r^2-indexed tables.
     if (MODE == MODE_VDW) ewk = 1;
     if (MODE == MODE_COULOMB) vdwk = 1;
     if (ewk == 2 && vdwk == 0) ewk = 1;          // the generic rule interpreter keeps the erfcx variant

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/stats_$tag
 mkdir -p $out
 warm=2; steps=20
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/raw -- python bench.py --steps $steps --warmup $warm --cpu-rows 0 --no-check "$@" > $out/bench.json 2> $out/bench.err || { echo "rocprofv3 failed"; tail -5 $out/bench.err; }
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/raw -- python bench.py --steps $steps --warmup $warm --cpu-rows 0 --no-check --no-oneshot "$@" > $out/bench.json 2> $out/bench.err || { echo "rocprofv3 failed"; tail -5 $out/bench.err; }
 python - "$out" "$warm" "$steps" "$*" <<'PY'
 import csv, glob, sys, json, collections
 out, warm, steps, args = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
@@ -16,7 +16,7 @@ for f in glob.glob(out + "/raw/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         rows[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
 with open(out + "/summary.csv", "w") as fh:
-    fh.write(f"# rocprofv3 --kernel-trace -- python bench.py --steps {steps} --warmup {warm} --cpu-rows 0 --no-check {args}; warm-up launches excluded for the grid-build kernels\n")
+    fh.write(f"# rocprofv3 --kernel-trace -- python bench.py --steps {steps} --warmup {warm} --cpu-rows 0 --no-check --no-oneshot {args}; warm-up launches excluded for the grid-build kernels\n")
     fh.write("kernel,calls,dropped_warmup,avg_ms,min_ms,max_ms,total_ms\n")
     for name, spans in sorted(rows.items(), key=lambda kv: -sum(e - s for s, e in kv[1])):
         spans.sort()

@@ -16,7 +16,7 @@ for ctrs in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_
             "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES" \
             "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $ctrs --output-format csv -d gpurun_out/pmc_$tag/p$i -- python bench.py --steps $steps --warmup $warm --cpu-rows 0 --no-check "$@" > gpurun_out/pmc_$tag/p$i.log 2>&1 || { echo "pass $i ($ctrs) failed"; tail -5 gpurun_out/pmc_$tag/p$i.log; }
+  timeout -k 10 300 rocprofv3 --pmc $ctrs --output-format csv -d gpurun_out/pmc_$tag/p$i -- python bench.py --steps $steps --warmup $warm --cpu-rows 0 --no-check --no-oneshot "$@" > gpurun_out/pmc_$tag/p$i.log 2>&1 || { echo "pass $i ($ctrs) failed"; tail -5 gpurun_out/pmc_$tag/p$i.log; }
 done
 python - "$tag" "$key" "$steps" "$warm" "$*" <<'PY'
 import csv, glob, collections, hashlib, json, os, socket, subprocess, sys
@@ -83,6 +83,6 @@ summ["csrc_sha256"] = h.hexdigest()
 summ["host"] = socket.gethostname()
 summ["timed_launches_per_pass"] = steps
 summ["key"] = key
-summ["command"] = f"python bench.py --steps {steps} --warmup {warm} --cpu-rows 0 --no-check {args}"
+summ["command"] = f"python bench.py --steps {steps} --warmup {warm} --cpu-rows 0 --no-check --no-oneshot {args}"
 json.dump(summ, open(f"gpurun_out/pmc_{tag}/summary.json", "w"), indent=1)
 PY

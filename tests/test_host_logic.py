@@ -488,3 +488,19 @@ def test_round3_entry_points_validate_and_have_no_cpu_path(tmp_path):
     assert ei.value.code == -2
     (tmp_path / "x.grid").write_bytes(b"\0" * 400)
     assert lib.ceg_interp_create_from_file(C.byref(h), 0, str(tmp_path / "x.grid").encode(), 0, 1.0, None, None, None) == -2
+
+
+def test_pmc_record_matches_the_grid_kernel_sources():
+    """bench.py takes roofline.frac from profiles/pmc_summary.json; a record collected on OTHER grid-kernel sources is flagged stale in
+    the line the driver records.  A round must not end on a stale headline record: this fails until scripts/pmc.sh +
+    scripts/pmc_merge.py have been re-run on the current csrc/ (the hash covers bench.GRID_KERNEL_SOURCES only -- edits of the consumer
+    kernels do not invalidate it)."""
+    import json
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root))
+    import bench
+    rec = json.loads((root / "profiles" / "pmc_summary.json").read_text())["fused/Ar/255/1"]
+    assert rec["csrc_sha256"] == bench.csrc_sha256(), "profiles/pmc_summary.json is stale: re-run scripts/pmc.sh fused_ar fused/Ar/255/1 and scripts/pmc_merge.py"
+    assert rec["source"].startswith("profiles/")
