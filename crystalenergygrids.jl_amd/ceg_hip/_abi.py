@@ -146,6 +146,8 @@ PROTOTYPES = {
     "ceg_mc_destroy": (C.c_int, [C.c_void_p]),
     "ceg_mc_set_guests": (C.c_int, [C.c_void_p, c_double_p, c_int32_p, c_int32_p, C.c_int32]),
     "ceg_mc_trial": (C.c_int, [C.c_void_p, C.c_int32, c_double_p, C.c_int64, c_double_p]),
+    "ceg_mc_trial_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "ceg_mc_trial_insert_device": (C.c_int, [C.c_void_p, c_int32_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "ceg_mc_accept": (C.c_int, [C.c_void_p, C.c_int32, c_double_p]),
     "ceg_mc_get_state": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
     "ceg_mc_neighbour_cells": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p]),

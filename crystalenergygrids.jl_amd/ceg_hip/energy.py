@@ -313,6 +313,18 @@ class DeviceMonteCarlo:
         _abi.check(self._lib, self._lib.ceg_mc_trial(self._h, mol, _abi.dptr(t.reshape(-1)) if len(t) else None, len(t), _abi.dptr(out.reshape(-1))))
         return out
 
+    def trial_device(self, idx, d_trial: int, n: int, d_out: int, stream: int = 0) -> None:
+        """``ceg_mc_trial_device``: ``n`` trial placements at device address ``d_trial`` (float64[n, m, 3]) -> rows at device address
+        ``d_out`` (float64[n + 1, 4]), enqueued on ``stream``; nothing is copied or synchronised."""
+        _abi.check(self._lib, self._lib.ceg_mc_trial_device(self._h, self._slot[idx[0]][idx[1]], C.c_void_p(d_trial), int(n), C.c_void_p(d_out),
+                                                            C.c_void_p(stream) if stream else None))
+
+    def trial_insert_device(self, i: int, d_trial: int, n: int, d_out: int, stream: int = 0) -> None:
+        """``ceg_mc_trial_insert_device``: rows float64[n, 4] at ``d_out`` for a NEW molecule of kind ``i``."""
+        k = np.ascontiguousarray([ix - 1 for ix in self.mc.ffidx[i]], dtype=np.int32)
+        _abi.check(self._lib, self._lib.ceg_mc_trial_insert_device(self._h, _abi.i32ptr(k), len(k), C.c_void_p(d_trial), int(n), C.c_void_p(d_out),
+                                                                   C.c_void_p(stream) if stream else None))
+
     def accept(self, idx, positions) -> None:
         """update_mc!(mc, idx, positions) on the device (asynchronous).  The host-side ``mc`` is NOT touched."""
         p = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1)

@@ -1559,6 +1559,54 @@ extern "C" int ceg_mc_set_guests(ceg_mc_t* h, const double* positions, const int
     return CEG_OK;
 }
 
+namespace {
+// trial placements and result rows in DEVICE memory, enqueued on the caller's stream (after what this handle has enqueued so far):
+// the wave-per-placement kernels whatever the batch size -- no host copies, no synchronisation
+int run_trial_device(ceg_mc* h, bool insert, int32_t molecule, const McMolecule& nm, int m, const double* d_trial, int64_t n, double* d_out, void* stream)
+{
+    const int64_t rows = insert ? n : n + 1;
+    if (rows <= 0) return CEG_OK;
+    if (rows > 0x7fffffffLL) return merr(CEG_ERR_INVALID, "too many placements");
+    if (tables_bytes(h, m) > 64 * 1024) return merr(CEG_ERR_UNSUPPORTED, "k-space tables of the molecule do not fit in LDS");
+    Guard guard(h->device);
+    if (!guard.ok) return merr(CEG_ERR_HIP, "hipSetDevice failed");
+    hipStream_t user = (hipStream_t)stream;
+    // order the caller's stream behind the handle's own (accept / insert / remove are asynchronous on it), run there, and make the
+    // handle's stream wait for the trial in turn so that a later accept does not overtake it
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return merr(CEG_ERR_HIP, "event creation failed");
+    bool ok = hipEventRecord(ev, h->stream) == hipSuccess && hipStreamWaitEvent(user, ev, 0) == hipSuccess;
+    int rc = CEG_OK;
+    if (ok) {
+        hipStream_t own = h->stream;
+        h->stream = user;
+        rc = launch_wave_kernels(h, insert, molecule, nm, m, d_trial, rows, d_out);
+        h->stream = own;
+    }
+    ok = ok && !rc && hipEventRecord(ev, user) == hipSuccess && hipStreamWaitEvent(h->stream, ev, 0) == hipSuccess;
+    (void)hipEventDestroy(ev);
+    if (rc) return rc;
+    return ok ? CEG_OK : merr(CEG_ERR_HIP, "stream ordering failed");
+}
+}  // namespace
+
+extern "C" int ceg_mc_trial_device(ceg_mc_t* h, int32_t molecule, const double* d_trial, int64_t n, double* d_out, void* stream)
+{
+    if (!h || n < 0 || !d_out || (n > 0 && !d_trial)) return merr(CEG_ERR_INVALID, "bad argument");
+    if (h->poisoned) return refuse_poisoned();
+    if (molecule < 0 || molecule >= h->v.nmol) return merr(CEG_ERR_INVALID, "no such molecule");
+    return run_trial_device(h, false, molecule, McMolecule{}, h->h_mol[molecule].y, d_trial, n, d_out, stream);
+}
+
+extern "C" int ceg_mc_trial_insert_device(ceg_mc_t* h, const int32_t* kinds, int32_t m, const double* d_trial, int64_t n, double* d_out, void* stream)
+{
+    if (!h || n < 0 || (n > 0 && (!d_trial || !d_out))) return merr(CEG_ERR_INVALID, "bad argument");
+    if (h->poisoned) return refuse_poisoned();
+    McMolecule nm{};
+    if (int rc = check_molecule(h, kinds, m, &nm)) return rc;
+    return run_trial_device(h, true, -1, nm, m, d_trial, n, d_out, stream);
+}
+
 extern "C" int ceg_mc_trial(ceg_mc_t* h, int32_t molecule, const double* trial, int64_t n, double* out)
 {
     if (!h || n < 0 || !out || (n > 0 && !trial)) return merr(CEG_ERR_INVALID, "bad argument");

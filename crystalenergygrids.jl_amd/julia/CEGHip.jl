@@ -493,6 +493,25 @@ function mc_trial(h::Ptr{Cvoid}, ij::Int, newpos)
     out
 end
 
+"""
+`n` trial placements of species `ij` that already lie in DEVICE memory (`d_trial`: 3 x m x n Float64, e.g. `pointer(::ROCArray)`),
+rows into device memory `d_out` (4 x (n + 1) Float64, column 1 = where it is), enqueued on `stream` (a `hipStream_t`, `C_NULL` = null stream):
+no copy, no synchronisation.
+"""
+function mc_trial_device(h::Ptr{Cvoid}, ij::Int, d_trial::Ptr{Float64}, n::Integer, d_out::Ptr{Float64}, stream::Ptr{Cvoid}=C_NULL)
+    _check(ccall((:ceg_mc_trial_device, LIB[]), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Cvoid}),
+                 h, ij - 1, d_trial, n, d_out, stream))
+    nothing
+end
+
+"the same for a NEW species with ff indices `idx` (rows 4 x n)"
+function mc_trial_insert_device(h::Ptr{Cvoid}, idx::Vector{Int}, d_trial::Ptr{Float64}, n::Integer, d_out::Ptr{Float64}, stream::Ptr{Cvoid}=C_NULL)
+    kinds = Int32.(idx .- 1)
+    GC.@preserve kinds _check(ccall((:ceg_mc_trial_insert_device, LIB[]), Cint,
+        (Ptr{Cvoid}, Ptr{Int32}, Int32, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Cvoid}), h, kinds, length(kinds), d_trial, n, d_out, stream))
+    nothing
+end
+
 "update_mc!(mc, idx, newpos) for a displacement, on the device (asynchronous)"
 function mc_accept(h::Ptr{Cvoid}, ij::Int, newpos)
     pts = _pts(newpos)

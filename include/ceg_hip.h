@@ -496,6 +496,14 @@ CEG_API int ceg_mc_set_guests(ceg_mc_t* handle, const double* positions, const i
  * guest-guest, reciprocal.  Host memory; one launch + one stream synchronisation (small batches travel through pinned,
  * device-mapped buffers). */
 CEG_API int ceg_mc_trial(ceg_mc_t* handle, int32_t molecule, const double* trial, int64_t n, double* out);
+/* The same with the trial placements and the result rows in DEVICE memory (like ceg_recip_energy_device / ceg_pairs_energy_device):
+ * for callers that generate trials on the device or evaluate large batches repeatedly -- a 65 536-placement call through the host
+ * entry point spends a third of its time moving 4.7 MB in and 2.1 MB out of pageable memory.  Enqueued on `stream` (a hipStream_t,
+ * NULL = the null stream), ordered behind everything this handle has enqueued so far; later accept / insert / remove calls are
+ * ordered behind it; no synchronisation: the rows are valid when `stream` has reached this point.  Always the wave-per-placement
+ * kernels.  ceg_mc_trial_insert_device: the GCMC counterpart (see ceg_mc_trial_insert). */
+CEG_API int ceg_mc_trial_device(ceg_mc_t* handle, int32_t molecule, const double* d_trial, int64_t n, double* d_out, void* stream);
+CEG_API int ceg_mc_trial_insert_device(ceg_mc_t* handle, const int32_t* kinds, int32_t m, const double* d_trial, int64_t n, double* d_out, void* stream);
 /* the molecule now sits at positions [m][3]: update_mc! on the device.  Asynchronous; later calls on this handle are
  * ordered behind it. */
 CEG_API int ceg_mc_accept(ceg_mc_t* handle, int32_t molecule, const double* positions);

@@ -47,14 +47,42 @@ def bench(nbatch, reps):
     dt = (time.perf_counter() - t) / reps
     return dt, e
 
+def bench_device(nbatch, reps, own_stream=True, sync_each=True):
+    """ceg_mc_trial_device: trials and rows resident on the GPU, on a stream of the caller; completion by one stream synchronisation
+    per call (sync_each) or one at the end of ``reps`` enqueued calls"""
+    import torch
+    idx = mols[7 % len(mols)]
+    cur = mc.positions[idx[0]][idx[1]]
+    d_trial = torch.tensor(cur[None] + rng.uniform(-0.5, 0.5, (nbatch, 1, 3)), dtype=torch.float64, device="cuda")
+    d_rows = torch.empty((nbatch + 1, 4), dtype=torch.float64, device="cuda")
+    st = torch.cuda.Stream() if own_stream else torch.cuda.default_stream()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        dev.trial_device(idx, d_trial.data_ptr(), nbatch, d_rows.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    t = time.perf_counter()
+    for k in range(reps):
+        dev.trial_device(idx, d_trial.data_ptr(), nbatch, d_rows.data_ptr(), st.cuda_stream)
+        if sync_each:
+            st.synchronize()
+    st.synchronize()
+    return (time.perf_counter() - t) / reps
+
 if os.environ.get("CEG_TIME_MC_ONLY_BIG"):          # profiling runs: the large batch alone
     dt = bench(65536, 20)[0]
     print(f"GPU  batch  65536: {dt * 1e6:9.1f} us per call")
+    dtd = bench_device(65536, 20)
+    print(f"   (the same on the null stream: {bench_device(65536, 20, own_stream=False) * 1e6:9.1f} us; 20 calls enqueued, one synchronisation: {bench_device(65536, 20, sync_each=False) * 1e6:9.1f} us per call)")
+    fl_ = 65537 * (3 * 1368 * 16.0 + 1368 * 10.0 + 3 * 51 * 40.0 + 3 * 189 * 47.0 + 60 * 72.0 + 1500.0)
+    print(f"GPU  batch  65536, trials and rows resident on the device (ceg_mc_trial_device): {dtd * 1e6:9.1f} us per call = {fl_ / dtd / 78.6e12:.3f} of the FP64 vector peak")
     dev.close()
     sys.exit(0)
 for nbatch, reps in ((1, 2000), (16, 1000), (1024, 200), (65536, 10)):
     dt, e = bench(nbatch, reps)
     print(f"GPU  batch {nbatch:6d}: {dt * 1e6:9.1f} us per call (trial launch + every second call an accept) = {dt * 1e6 / nbatch:9.3f} us per trial placement")
+
+dtd = bench_device(65536, 10)
+print(f"GPU  batch  65536, trials and rows resident on the device (ceg_mc_trial_device): {dtd * 1e6:9.1f} us per call = {dtd * 1e6 / 65536:9.4f} us per trial placement")
 
 # where the wave-per-placement kernels (three launches: k_mcw_frame / k_mcw_ewald / k_mcw_pairs) take over from the
 # workgroup-per-placement kernel (one launch: k_mc_trial): both forced on the same batches

@@ -132,7 +132,7 @@ def test_julia_ccalls_match_the_header():
             assert _compatible(h, _JULIA_CLASS[t]), f"{name} argument {pos}: Julia {t} vs C {h}"
     # the two methods the shim overrides and the streamed variant all reach their entry point
     assert {"ceg_grid_vdw", "ceg_grid_coulomb", "ceg_grid_vdw_file", "ceg_grids_multi", "ceg_last_error", "ceg_mc_create", "ceg_mc_set_guests", "ceg_mc_trial",
-            "ceg_mc_accept", "ceg_mc_trial_insert", "ceg_mc_insert", "ceg_mc_remove"} <= {c[0] for c in calls}
+            "ceg_mc_accept", "ceg_mc_trial_insert", "ceg_mc_insert", "ceg_mc_remove", "ceg_mc_trial_device", "ceg_mc_trial_insert_device"} <= {c[0] for c in calls}
 
 
 def test_julia_shim_does_not_strip_units_off_unitless_constants():

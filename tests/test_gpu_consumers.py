@@ -391,6 +391,31 @@ def test_mc_large_batches_take_the_wave_kernels(hip_lib, tmp_path, monkeypatch):
             rows = both_paths(lambda: dev.trial_insert(kind, trial))
             assert rows.shape == (n, 4)
             check_rows(rows, {t: omc.insertion_energy(kind, trial[t]) for t in (0, 5, 640, n - 1)}, ("insertion", kind))
+        # the device-pointer entry points (ceg_mc_trial_device / _insert_device): trials and rows stay on the GPU, launches on the
+        # caller's stream, ordered behind an asynchronous accept and in front of the next one -- the same rows as the host entry points
+        import torch
+        kind, j = 1, 1
+        cur = mc.positions[kind][j]
+        trial = cur[None] + rng.uniform(-1.0, 1.0, (777, 1, 3))                 # (small too: the device route always takes the wave kernels)
+        moved = cur + np.array([0.3, -0.2, 0.1])
+        dev.accept((kind, j), moved); omc.update((kind, j), moved); M.update_mc(mc, (kind, j), moved)
+        d_trial = torch.tensor(trial, dtype=torch.float64, device="cuda")
+        d_rows = torch.full((len(trial) + 1, 4), float("nan"), dtype=torch.float64, device="cuda")
+        side = torch.cuda.Stream()
+        dev.trial_device((kind, j), d_trial.data_ptr(), len(trial), d_rows.data_ptr(), side.cuda_stream)
+        back = cur + np.array([-0.1, 0.2, 0.0])
+        dev.accept((kind, j), back)                                               # must not overtake the trial enqueued before it
+        side.synchronize()
+        rows_dev = d_rows.cpu().numpy()
+        check_rows(rows_dev, {0: omc.movement_energy((kind, j)), 1: omc.movement_energy((kind, j), trial[0]), 500: omc.movement_energy((kind, j), trial[499])},
+                   "device-pointer trial")
+        omc.update((kind, j), back); M.update_mc(mc, (kind, j), back)
+        rows_host = dev.trial((kind, j), trial)
+        assert np.all(np.abs(rows_host[0] - omc.movement_energy((kind, j))) <= 1e-9 * np.abs(rows_host[0]) + 1e-7)
+        d_rows_i = torch.empty((len(trial), 4), dtype=torch.float64, device="cuda")
+        dev.trial_insert_device(1, d_trial.data_ptr(), len(trial), d_rows_i.data_ptr())
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(d_rows_i.cpu().numpy(), dev.trial_insert(1, trial), rtol=1e-10, atol=1e-7)
         dev.close()
     finally:
         ceg.setdir_RASPA(Path(__file__).parent / "golden" / "raspa")
