@@ -151,6 +151,96 @@ def test_pairs_kernel_variants(hip_lib, oracle, nkinds, alpha, what):
     _assert_energies(got, ref, what)
 
 
+@pytest.mark.parametrize("cell", ["upper-triangular", "general"])
+def test_pairs_fractional_kernel(hip_lib, oracle, forcefield, monkeypatch, cell):
+    """k_pairs_frac (round 4: pair tests on fractional coordinates, trial atoms K at a time, 384-entry hit queue worked off in full
+    batches) for molecules of 1-16 atoms (the exact-size variants 1-4 and the four-at-a-time variant), in an upper-triangular and in a
+    general cell, with and without neighbour cells -- against the oracle at 1e-9 and against the Cartesian kernel
+    (CEG_HIP_PAIRS_FRAC=0) and the literal wrap (CEG_HIP_PAIRS_WRAP=0), which test the same pairs."""
+    ff = forcefield
+    rng = np.random.default_rng(41)
+    mat0, pos, kinds, mol, base, ids = _config5_guests(ff, rng)
+    if cell == "general":
+        rot = _rotation(rng)
+        mat = rot @ mat0
+        pos = pos @ rot.T
+    else:
+        mat = mat0
+    inv = np.linalg.inv(mat)
+    rules, offsets = ff.pair_table()
+    pool = [ff.sdict[a] - 1 for a in ("C_co2", "O_co2", "Na", "C_ch4", "H_ch4")]
+    for m, n in ((1, 4096), (2, 2048), (3, 4096), (4, 2048), (5, 2048), (9, 1024), (16, 1024)):
+        tk = [pool[i % len(pool)] for i in range(m)]
+        tbase = rng.uniform(-1.6, 1.6, (m, 3))
+        trial = (rng.uniform(-0.5, 1.5, (n, 3)) @ mat.T)[:, None, :] + tbase[None]
+        cl = (rng.uniform(0, 6.0, (n // 8, 3)) + np.array([17.0, 21.0, 9.0]))
+        trial[: n // 8] = (cl @ (mat @ np.linalg.inv(mat0)).T)[:, None, :] + tbase[None]                      # into the dense cluster
+        args = (mat, ff.cutoff ** 2, rules, offsets, ff.nkinds, COULOMBIC_CONVERSION_FACTOR, pos, kinds, mol, trial, tk, 500)
+        ref = oracle.single_contribution_vdw_raw(mat, inv, *args[1:])
+        monkeypatch.delenv("CEG_HIP_PAIRS_FRAC", raising=False)
+        monkeypatch.delenv("CEG_HIP_PAIRS_WRAP", raising=False)
+        got = _pairs_gpu(hip_lib, *args)
+        _assert_energies(got, ref, f"fractional kernel, {m} atoms, {cell}")
+        monkeypatch.setenv("CEG_HIP_PAIRS_FRAC", "0")
+        cart = _pairs_gpu(hip_lib, *args)
+        _assert_energies(cart, ref, f"Cartesian kernel, {m} atoms, {cell}")
+        fin = np.isfinite(ref)
+        assert np.array_equal(got[~fin], cart[~fin])
+        assert np.all(np.abs(got[fin] - cart[fin]) <= 1e-10 * (np.abs(cart[fin]) + 1e-3 * np.percentile(np.abs(ref[fin]), 75)))
+        if m in (3, 5):
+            monkeypatch.setenv("CEG_HIP_PAIRS_WRAP", "0")
+            _assert_energies(_pairs_gpu(hip_lib, *args), ref, f"literal wrap, {m} atoms, {cell}")
+    # with neighbour cells (forced on in this 40 A cell: 2.5 A bins)
+    monkeypatch.delenv("CEG_HIP_PAIRS_FRAC", raising=False)
+    monkeypatch.delenv("CEG_HIP_PAIRS_WRAP", raising=False)
+    monkeypatch.setenv("CEG_HIP_MC_CELLS", "1")
+    monkeypatch.setenv("CEG_HIP_MC_BIN", "2.5")
+    for m, n in ((3, 4096), (6, 1024)):
+        tk = [pool[i % len(pool)] for i in range(m)]
+        tbase = rng.uniform(-1.6, 1.6, (m, 3))
+        trial = (rng.uniform(-0.5, 1.5, (n, 3)) @ mat.T)[:, None, :] + tbase[None]
+        args = (mat, ff.cutoff ** 2, rules, offsets, ff.nkinds, COULOMBIC_CONVERSION_FACTOR, pos, kinds, mol, trial, tk, 500)
+        ref = oracle.single_contribution_vdw_raw(mat, inv, *args[1:])
+        _assert_energies(_pairs_gpu(hip_lib, *args), ref, f"fractional kernel + neighbour cells, {m} atoms, {cell}")
+
+
+@pytest.mark.parametrize("cell", ["upper-triangular", "general"])
+def test_pairs_cutoff_decision_is_the_references(hip_lib, oracle, forcefield, monkeypatch, cell):
+    """The approximate pair distances (fractional-coordinate form, f - rint(f) with FMAs) never decide r2 < cutoff2 (energy.jl:422):
+    pairs within 1e-9 of the cutoff are re-measured in the reference's operation order (utils.jl:294-302).  One guest atom, one
+    trial atom per placement at cutoff * (1 + delta), delta from 0 to 1e-8 either side, in random directions, across the cell
+    faces: whether the pair counts must agree with the oracle placement by placement, in all three kernel forms."""
+    ff = forcefield
+    rng = np.random.default_rng(43)
+    mat = np.array([[40.0, 0, 0], [3.0, 40.0, 0], [-2.0, 4.0, 40.0]]).T
+    if cell == "general":
+        mat = _rotation(rng) @ mat
+    inv = np.linalg.inv(mat)
+    rules, offsets = ff.pair_table()
+    kind = ff.sdict["O_co2"] - 1
+    for atom_frac in ([0.31, 0.52, 0.47], [0.02, 0.97, 0.5], [1.99, -0.98, 0.01]):
+        atom = mat @ np.array(atom_frac)
+        deltas = np.array([0.0, 1e-16, -1e-16, 3e-16, -3e-16, 1e-14, -1e-14, 1e-12, -1e-12, 1e-10, -1e-10, 1e-8, -1e-8])
+        n = 256 * len(deltas)
+        u = rng.normal(size=(n, 3))
+        u /= np.linalg.norm(u, axis=1)[:, None]
+        d = np.tile(deltas, 256)
+        trial = (atom[None] + ff.cutoff * (1.0 + d)[:, None] * u)[:, None, :]
+        trial[::3] += (mat @ rng.integers(-2, 3, (3, len(trial[::3])))).T[:, None, :]      # other images of the same placement
+        args = (mat, ff.cutoff ** 2, rules, offsets, ff.nkinds, COULOMBIC_CONVERSION_FACTOR, atom[None], [kind], [0], trial, [kind], -1)
+        ref = oracle.single_contribution_vdw_raw(mat, inv, *args[1:])
+        counted = ref != 0.0
+        assert 0.3 < counted.mean() < 0.7                                  # both sides of the cutoff are populated
+        for env in ({}, {"CEG_HIP_PAIRS_FRAC": "0"}, {"CEG_HIP_PAIRS_WRAP": "0"}):
+            monkeypatch.delenv("CEG_HIP_PAIRS_FRAC", raising=False)
+            monkeypatch.delenv("CEG_HIP_PAIRS_WRAP", raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            got = _pairs_gpu(hip_lib, *args)
+            assert np.array_equal(got != 0.0, counted), f"{cell} {env}: {int(((got != 0.0) != counted).sum())} cutoff decisions differ from the oracle's"
+            np.testing.assert_allclose(got, ref, rtol=1e-9, atol=0.0)
+
+
 # ------------------------------------------------------------------ BASELINE config 5: device-resident MC state
 def _mc_setup(tmp_path):
     """Na + 4 CO2 in CIT-7 (2x3x3 supercell, triclinic): grids at 0.15 A built by the HIP kernels via setup_montecarlo."""
