@@ -30,6 +30,7 @@
 #include "../../include/ceg_hip.h"
 #include "ceg_consumers.h"
 #include "ceg_rows.h"
+#include "ceg_pairfrac.h"
 
 using ceg::DevRule;
 using ceg_consumers::InterpGeom;
@@ -73,6 +74,7 @@ struct McView {
     double2* sf_tot;                           // [nk] sums[:, 1]
     double2* sf_mol;                           // [nmol][nk] sums[:, ij+1]
     double4* atoms;                            // x, y, z, (molecule << 32 | kind); molecule < 0: free slot
+    double4* fatoms;                           // the same slots with invmat * position (the pair tests of ceg_pairfrac.h)
     int2* mol;                                 // [nmol] atoms of molecule j: slots [mol[j].x, mol[j].x + mol[j].y)
     // neighbour cells of the guest atoms (what the reference gets from CellListMap, src/energy.jl:341-349,399-404):
     // fractional bins of the MC cell, fixed capacity, each holding COPIES of its atoms' records
@@ -80,6 +82,7 @@ struct McView {
     int32_t nb[3];
     double hfrac[3];                           // cutoff / perpendicular width: fractional half-extent of the cutoff sphere
     double4* cells;                            // [nb0*nb1*nb2][cell_cap]
+    double4* fcells;                           // the same entries, fractional
     int32_t* cell_count;                       // [nb0*nb1*nb2]
     // the k-vectors as rows cut into segments and dealt to 64 lanes in rounds (ceg_rows.h)
     int32_t nrounds, ns;
@@ -97,9 +100,21 @@ struct McCellOps {
     int32_t dst[MC_MAX_CELL_OPS], src[MC_MAX_CELL_OPS], cell[MC_MAX_CELL_OPS], count[MC_MAX_CELL_OPS];
 };
 
+// an atom record into its slot, Cartesian and fractional
+__device__ __forceinline__ void put_atom(const McView& v, int slot, const double4 A)
+{
+    const double* I = v.invmat;
+    v.atoms[slot] = A;
+    v.fatoms[slot] = make_double4(__builtin_fma(I[6], A.z, __builtin_fma(I[3], A.y, I[0] * A.x)), __builtin_fma(I[7], A.z, __builtin_fma(I[4], A.y, I[1] * A.x)),
+                                  __builtin_fma(I[8], A.z, __builtin_fma(I[5], A.y, I[2] * A.x)), A.w);
+}
+
 __device__ __forceinline__ void apply_cell_ops(const McView& v, const McCellOps& ops, int tid)
 {
-    if (tid < ops.nops) v.cells[ops.dst[tid]] = v.atoms[ops.src[tid]];
+    if (tid < ops.nops) {
+        v.cells[ops.dst[tid]] = v.atoms[ops.src[tid]];
+        v.fcells[ops.dst[tid]] = v.fatoms[ops.src[tid]];
+    }
     if (tid < ops.ncnt) v.cell_count[ops.cell[tid]] = ops.count[tid];
 }
 
@@ -405,10 +420,7 @@ __global__ __launch_bounds__(MC_THREADS, MC_TRIAL_WAVES) void k_mc_trial(McView 
 //   k_mcw_pairs  single_contribution_vdw: the rows of the pair table that belong to the kinds of THIS molecule staged in LDS, lanes
 //                stride over the guest atoms (or over the reachable neighbour cells).
 // Row r of `out` (4 doubles) receives columns 0-1 from the first, 3 from the second, 2 from the third.
-struct McFastPair {                // an entry whose rules are at most one Lennard-Jones and one CoulombEwaldDirect term (+ NoInteraction)
-    double c4eps, sigma2, qq, alpha, shift;      // 4 eps, sigma^2, coulombic q1 q2, alpha, sum of the shifts
-    int32_t cls, _pad;                           // 1: this record is the whole entry; 0: walk the rules
-};
+using McFastPair = ceg_pairfrac::PairFast;      // an entry whose rules are at most one Lennard-Jones and one CoulombEwaldDirect term (+ NoInteraction)
 struct McCompact {                 // the pair-table rows of one molecule's kinds: entry (kind1, a) -> rules [off[kind1 * m + a], off[.. + 1])
     const DevRule* rules;
     const int32_t* off;
@@ -742,6 +754,108 @@ __global__ __launch_bounds__(64 * MCW_WAVES, (FAST && CELLS) ? 3 : 4) void k_mcw
     }
 }
 
+// single_contribution_vdw on the fast path (ceg_pairfrac.h: pair tests on fractional coordinates, candidates queued, rules on full waves;
+// round 4, after k_pairs_frac): FAST rules and every perpendicular width of the MC cell above two cutoffs.  MM: exact molecule size 1-4
+// (0: any); TRI: upper-triangular cell.  The guest atoms come from fatoms / fcells (kept beside atoms / cells by every update kernel).
+template <int MM, bool CELLS, bool TRI>
+__global__ __launch_bounds__(64 * MCW_WAVES, 3) void k_mcw_pairs_frac(McView v, ceg_pairfrac::FracTable tab, int32_t molecule, int32_t insert, McMolecule nm,
+                                                                      const double* __restrict__ trial, int64_t nrows, double* __restrict__ out, int per_wave)
+{
+    using ceg_pairfrac::FQCAP;
+    using ceg_pairfrac::FracHit;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    __shared__ double s_mat[12];
+    __shared__ double s_trial[MCW_WAVES][MC_MAX_ATOMS * 3];
+    __shared__ double s_ft[MCW_WAVES][MC_MAX_ATOMS * 3];
+    __shared__ FracHit s_q[MCW_WAVES][FQCAP];
+    __shared__ int s_first[CELLS ? MCW_WAVES : 1][64], s_cell[CELLS ? MCW_WAVES : 1][64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int first = insert ? 0 : v.mol[molecule].x;
+    const int m = MM > 0 ? MM : (insert ? nm.m : v.mol[molecule].y);
+    ceg_pairfrac::FracWave<MM, TRI> w;
+    {
+        ceg_pairfrac::PairFast* fastrec; DevRule* rules; int32_t* offset;
+        ceg_pairfrac::stage(s_raw, tab, v.mat, s_mat, tid, 64 * MCW_WAVES, fastrec, rules, offset);
+        __syncthreads();
+        w.fastrec = fastrec; w.rules = rules; w.offset = offset;
+    }
+    w.s_mat = s_mat; w.t3 = s_trial[wave]; w.ft = s_ft[wave]; w.hq = s_q[wave];
+    w.frac = CELLS ? v.fcells : v.fatoms;
+    w.cart = CELLS ? v.cells : v.atoms;
+    w.geom = v.geom;
+    w.cutoff2 = v.cutoff2; w.band = 1e-9 * v.cutoff2; w.cutoff2_band = w.cutoff2 + w.band; w.coulombic = v.coulombic;
+    w.m = m; w.exclude = insert ? -2 : molecule; w.lane = lane;      // (free slots carry molecule -1: never live)
+    const int64_t p0 = ((int64_t)blockIdx.x * MCW_WAVES + wave) * per_wave;
+    const int64_t p1 = p0 + per_wave < nrows ? p0 + per_wave : nrows;
+    for (int64_t row = p0; row < p1; ++row) {
+        // row 0 of a displacement batch is the molecule where it is now
+        w.load(v.invmat, [&](int i) -> double {
+            if (!insert && row == 0) {
+                const double4 A = v.atoms[first + i / 3];
+                return (i % 3 == 0) ? A.x : ((i % 3 == 1) ? A.y : A.z);
+            }
+            return trial[(size_t)(insert ? row : row - 1) * m * 3 + i];
+        });
+        if (!CELLS) {
+            const int total = v.natoms;
+            auto locate = [&](int l) -> int { return l < total ? l : 0; };
+            for (int l0 = 0; l0 < total;) {
+                l0 = w.scan(locate, total, l0);
+                w.flush(false);
+            }
+        } else {
+            // only the cells the cutoff spheres of the molecule's atoms can reach (ceg_consumers.h): lane ax works out the range of axis ax
+            int first_bin = 0, nbins = 1;
+            if (lane < 3) ceg_consumers::cell_range(v.invmat, w.t3, m, lane, v.nb[lane], v.hfrac[lane], first_bin, nbins);
+            const int b0 = __shfl(first_bin, 0), b1 = __shfl(first_bin, 1), b2 = __shfl(first_bin, 2);
+            const int n1 = __shfl(nbins, 1), n2 = __shfl(nbins, 2);
+            const int ncell = __shfl(nbins, 0) * n1 * n2;
+            int* cfirst = s_first[CELLS ? wave : 0];
+            int* ccell = s_cell[CELLS ? wave : 0];
+            for (int base = 0; base < ncell; base += 64) {
+                const int e = base + lane;
+                int cnt = 0, cell = 0;
+                if (e < ncell) {
+                    const int j2 = e % n2, j1 = (e / n2) % n1, j0 = e / (n2 * n1);
+                    int c0 = b0 + j0, c1 = b1 + j1, c2 = b2 + j2;
+                    if (c0 >= v.nb[0]) c0 -= v.nb[0];
+                    if (c1 >= v.nb[1]) c1 -= v.nb[1];
+                    if (c2 >= v.nb[2]) c2 -= v.nb[2];
+                    cell = (c0 * v.nb[1] + c1) * v.nb[2] + c2;
+                    cnt = v.cell_count[cell];
+                }
+                int incl = cnt;                                            // inclusive scan over the wave
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int up = __shfl_up(incl, o);
+                    if (lane >= o) incl += up;
+                }
+                const int total = __shfl(incl, 63);
+                __builtin_amdgcn_wave_barrier();
+                cfirst[lane] = incl - cnt;
+                ccell[lane] = cell;
+                __builtin_amdgcn_wave_barrier();
+                const int cap = v.cell_cap;
+                auto locate = [&](int l) -> int {                          // entry l of the concatenated cells (0 beyond the end)
+                    int j = 0;                                             // last cell whose first entry is <= l
+#pragma unroll
+                    for (int step = 32; step > 0; step >>= 1)
+                        if (cfirst[j + step] <= l) j += step;
+                    return l < total ? ccell[j] * cap + (l - cfirst[j]) : 0;
+                };
+                for (int l0 = 0; l0 < total;) {
+                    l0 = w.scan(locate, total, l0);
+                    w.flush(false);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        const double sum = w.sum();
+        if (lane == 0) out[4 * (size_t)row + 2] = sum;
+        __builtin_amdgcn_wave_barrier();                           // t3 / ft are rewritten for the next placement
+    }
+}
+
 // update_mc! for a displacement (montecarlo.jl:615-628): positions; sums[:,1] += new - sums[:,ij+1]; sums[:,ij+1] = new
 __global__ __launch_bounds__(MC_THREADS) void k_mc_accept(McView v, int32_t molecule, McPositions np, McCellOps ops, int stride)
 {
@@ -757,7 +871,7 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_accept(McView v, int32_t mole
         unpack(A.w, kind, mol);
         s_q[tid] = v.kind_charge[kind];
         A.x = np.xyz[3 * tid]; A.y = np.xyz[3 * tid + 1]; A.z = np.xyz[3 * tid + 2];
-        v.atoms[first + tid] = A;
+        put_atom(v, first + tid, A);
     }
     __syncthreads();
     if (v.use_cells) apply_cell_ops(v, ops, tid);
@@ -824,7 +938,7 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_insert(McView v, int32_t mole
     if (tid < 3 * m) s_pos[tid] = np.xyz[tid];
     if (tid < m) {
         const long long bits = ((long long)molecule << 32) | (long long)(uint32_t)nm.kinds[tid];
-        v.atoms[first + tid] = make_double4(np.xyz[3 * tid], np.xyz[3 * tid + 1], np.xyz[3 * tid + 2], __longlong_as_double(bits));
+        put_atom(v, first + tid, make_double4(np.xyz[3 * tid], np.xyz[3 * tid + 1], np.xyz[3 * tid + 2], __longlong_as_double(bits)));
         s_q[tid] = v.kind_charge[nm.kinds[tid]];
     }
     if (tid == 0) v.mol[molecule] = make_int2(first, m);
@@ -866,7 +980,7 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_remove(McView v, int32_t mole
         unpack(A.w, kind, mol);
         const long long bits = (long long)(0xffffffff00000000ull | (unsigned long long)(uint32_t)kind);      // molecule id -1: free slot
         A.w = __longlong_as_double(bits);
-        v.atoms[gone.x + tid] = A;
+        put_atom(v, gone.x + tid, A);
     }
     if (last != molecule && tid >= 64 && tid < 64 + moved.y) {
         double4 A = v.atoms[moved.x + tid - 64];
@@ -874,7 +988,7 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_remove(McView v, int32_t mole
         unpack(A.w, kind, mol);
         const long long bits = ((long long)molecule << 32) | (long long)(uint32_t)kind;
         A.w = __longlong_as_double(bits);
-        v.atoms[moved.x + tid - 64] = A;
+        put_atom(v, moved.x + tid - 64, A);
     }
     __syncthreads();
     if (v.use_cells) apply_cell_ops(v, ops, tid);
@@ -885,7 +999,17 @@ __global__ __launch_bounds__(MC_THREADS) void k_mc_remove(McView v, int32_t mole
 __global__ void k_mc_cells_fill(McView v, const int32_t* __restrict__ map, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && map[i] >= 0) v.cells[i] = v.atoms[map[i]];
+    if (i < n && map[i] >= 0) {
+        v.cells[i] = v.atoms[map[i]];
+        v.fcells[i] = v.fatoms[map[i]];
+    }
+}
+
+// fatoms[] from atoms[] for every slot (after an upload, after the arrays grew)
+__global__ void k_mc_frac_fill(McView v, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) put_atom(v, (int)i, v.atoms[i]);
 }
 
 int merr(int code, const char* msg)
@@ -1214,10 +1338,11 @@ int ensure_capacity(ceg_mc* h, int64_t natoms, int64_t nmol)
     if (natoms <= h->atoms_cap && nmol <= h->mol_cap) return CEG_OK;
     if (hipStreamSynchronize(h->stream) != hipSuccess) return merr(CEG_ERR_HIP, "stream synchronisation failed");
     const size_t nk = (size_t)(h->v.nk > 0 ? h->v.nk : 1);
+    const bool regrown = natoms > h->atoms_cap;
     if (natoms > h->atoms_cap) {
         const int64_t cap = natoms + natoms / 2 + 64;
         double4* p = nullptr;
-        if (hipMalloc((void**)&p, sizeof(double4) * (size_t)cap) != hipSuccess) return merr(CEG_ERR_HIP, "could not allocate the guest atoms");
+        if (hipMalloc((void**)&p, 2 * sizeof(double4) * (size_t)cap) != hipSuccess) return merr(CEG_ERR_HIP, "could not allocate the guest atoms");      // Cartesian, then fractional
         if (h->d_atoms && h->v.natoms > 0 &&
             hipMemcpy(p, h->d_atoms, sizeof(double4) * (size_t)h->v.natoms, hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipFree(p); return merr(CEG_ERR_HIP, "device copy failed"); }
         if (h->d_atoms) (void)hipFree(h->d_atoms);
@@ -1242,7 +1367,11 @@ int ensure_capacity(ceg_mc* h, int64_t natoms, int64_t nmol)
         h->d_molidx = pi;
         h->mol_cap = cap;
     }
-    h->v.atoms = h->d_atoms; h->v.mol = h->d_molidx; h->v.sf_mol = h->d_mol;
+    h->v.atoms = h->d_atoms; h->v.fatoms = h->d_atoms + h->atoms_cap; h->v.mol = h->d_molidx; h->v.sf_mol = h->d_mol;
+    if (regrown && h->v.natoms > 0) {
+        hipLaunchKernelGGL(k_mc_frac_fill, dim3((unsigned)((h->v.natoms + 255) / 256)), dim3(256), 0, h->stream, h->v, (int64_t)h->v.natoms);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return merr(CEG_ERR_HIP, "could not convert the guest atoms");
+    }
     return CEG_OK;
 }
 
@@ -1259,7 +1388,7 @@ int rebuild_cells(ceg_mc* h)
     if (cap != cm.cap || !h->d_cells) {
         if (h->d_cells) (void)hipFree(h->d_cells);
         h->d_cells = nullptr;
-        if (hipMalloc((void**)&h->d_cells, sizeof(double4) * (size_t)ncells * cap) != hipSuccess) return merr(CEG_ERR_HIP, "could not allocate the neighbour cells");
+        if (hipMalloc((void**)&h->d_cells, 2 * sizeof(double4) * (size_t)ncells * cap) != hipSuccess) return merr(CEG_ERR_HIP, "could not allocate the neighbour cells");
         cm.cap = cap;
     }
     if (!h->d_cell_count && hipMalloc((void**)&h->d_cell_count, sizeof(int32_t) * (size_t)ncells) != hipSuccess)
@@ -1273,7 +1402,7 @@ int rebuild_cells(ceg_mc* h)
     if (hipMalloc((void**)&d_map, sizeof(int32_t) * map.size()) != hipSuccess) return merr(CEG_ERR_HIP, "hipMalloc failed");
     bool ok = hipMemcpy(d_map, map.data(), sizeof(int32_t) * map.size(), hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(h->d_cell_count, count.data(), sizeof(int32_t) * count.size(), hipMemcpyHostToDevice) == hipSuccess;
-    h->v.cells = h->d_cells; h->v.cell_count = h->d_cell_count; h->v.cell_cap = cm.cap;
+    h->v.cells = h->d_cells; h->v.fcells = h->d_cells + (size_t)ncells * cm.cap; h->v.cell_count = h->d_cell_count; h->v.cell_cap = cm.cap;
     if (ok) {
         const int64_t n = (int64_t)map.size();
         hipLaunchKernelGGL(k_mc_cells_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->v, d_map, n);
@@ -1379,7 +1508,32 @@ int launch_wave_kernels(ceg_mc* h, bool insert, int32_t molecule, const McMolecu
         // no Ewald summation: column 3 is zero
         if (hipMemset2DAsync(d_out + 3, 4 * sizeof(double), 0, sizeof(double), (size_t)rows, h->stream) != hipSuccess) return merr(CEG_ERR_HIP, "memset failed");
     }
-    {   // single_contribution_vdw
+    // single_contribution_vdw
+    bool frac_pairs = v.fast && v.fastwrap >= 1 && v.natoms > 0;
+    if (const char* e = std::getenv("CEG_HIP_MC_FRAC")) frac_pairs = frac_pairs && std::atoi(e) != 0;          // measurement aid: 0 = the Cartesian kernel
+    const int nentries = v.nkinds * m;
+    const size_t ftab_bytes = ceg_pairfrac::frac_table_bytes(nentries, ctab->nrules);
+    if (ftab_bytes + sizeof(ceg_pairfrac::FracHit) * ceg_pairfrac::FQCAP * MCW_WAVES + 4096 > 60 * 1024) frac_pairs = false;
+    if (frac_pairs) {
+        const ceg_pairfrac::FracTable ftab{static_cast<const McFastPair*>(ctab->d_fast), ctab->d_rules, ctab->d_off, ctab->nrules, nentries};
+        const int per_wave = rows_per_wave(rows, MCW_WAVES, 8);
+        const int64_t nb = (rows + (int64_t)MCW_WAVES * per_wave - 1) / ((int64_t)MCW_WAVES * per_wave);
+#define CEG_MCW_F(MMv, CL, TR) hipLaunchKernelGGL((k_mcw_pairs_frac<MMv, CL, TR>), dim3((unsigned)nb), dim3(64 * MCW_WAVES), ftab_bytes, h->stream, v, ftab, molecule, insert ? 1 : 0, nm, d_in, rows, d_out, per_wave)
+#define CEG_MCW_FM(CL, TR)                         \
+    do {                                           \
+        switch (m) {                               \
+            case 1: CEG_MCW_F(1, CL, TR); break;   \
+            case 2: CEG_MCW_F(2, CL, TR); break;   \
+            case 3: CEG_MCW_F(3, CL, TR); break;   \
+            case 4: CEG_MCW_F(4, CL, TR); break;   \
+            default: CEG_MCW_F(0, CL, TR); break;  \
+        }                                          \
+    } while (0)
+        if (v.use_cells) { if (v.fastwrap == 2) CEG_MCW_FM(true, true); else CEG_MCW_FM(true, false); }
+        else { if (v.fastwrap == 2) CEG_MCW_FM(false, true); else CEG_MCW_FM(false, false); }
+#undef CEG_MCW_FM
+#undef CEG_MCW_F
+    } else {
         const size_t ct_full = sizeof(McFastPair) * (size_t)v.nkinds * m + sizeof(DevRule) * (size_t)std::max(ctab->nrules, 1) +
                                sizeof(int32_t) * ((size_t)v.nkinds * m + 1);
         McCompact ct{ctab->d_rules, ctab->d_off, static_cast<const McFastPair*>(ctab->d_fast), ctab->nrules, ct_full <= 32 * 1024 ? 1 : 0};
@@ -1538,6 +1692,10 @@ extern "C" int ceg_mc_set_guests(ceg_mc_t* h, const double* positions, const int
     h->free_runs.assign(MC_MAX_ATOMS + 1, {});
     McView& v = h->v;
     v.natoms = (int32_t)natoms; v.nmol = nmol;
+    if (natoms > 0) {
+        hipLaunchKernelGGL(k_mc_frac_fill, dim3((unsigned)((natoms + 255) / 256)), dim3(256), 0, h->stream, v, (int64_t)natoms);
+        if (hipGetLastError() != hipSuccess) return merr(CEG_ERR_HIP, "could not convert the guest atoms");
+    }
     if (h->cm.on) {
         CellMirror& cm = h->cm;
         cm.members.assign((size_t)cm.ncells(), {});

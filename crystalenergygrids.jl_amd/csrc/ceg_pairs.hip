@@ -24,10 +24,16 @@
 #include "ceg_internal.h"
 #include "ceg_math.h"
 #include "ceg_consumers.h"
+#include "ceg_pairfrac.h"
 
 using ceg::DevRule;
 using ceg_consumers::rule_energy;
 using ceg_consumers::rule_energy_fast;
+using ceg_pairfrac::FQCAP;
+using ceg_pairfrac::FracHit;
+using ceg_pairfrac::FracTable;
+using ceg_pairfrac::PairFast;
+using ceg_pairfrac::frac_table_bytes;
 
 extern "C" void ceg_set_last_error_(const char* msg);
 
@@ -224,41 +230,7 @@ __global__ __launch_bounds__(64 * PAIRS_WAVES, 3) void k_pairs(PairsGeom g, cons
     if (lane == 0) out[p] = e;
 }
 
-// ---- round 4: the pair tests on FRACTIONAL coordinates --------------------------------------------------------------------------
-// For handles on the fast path (rules inside the domain of ceg_math.h, pair table in LDS, every perpendicular width of the cell above
-// two cutoffs) the guest atoms are also kept as f = invmat * pos.  A pair test is then d = f_trial - f_atom; d -= rint(d); v = mat * d;
-// r2 = |v|^2 -- 18 instructions in an upper-triangular cell instead of 27 --, the band within 1e-9 of the cutoff is re-measured in the
-// reference's operation order from the Cartesian positions exactly as before, and the loop has no branch per test: the trial atoms are
-// taken K at a time (independent dependency chains the scheduler interleaves), the hit queue holds 512 entries and is looked at once
-// per block, full batches of 64 only (the remainder stays queued), so the rule arithmetic runs on full waves.
-// MM: the molecule has exactly MM atoms (1-4, fractional coordinates and kinds in registers); 0: any size, four at a time from LDS.
-constexpr int FQCAP = 384;
-
-// a pair-table entry whose rules are at most one Lennard-Jones and one CoulombEwaldDirect term (+ NoInteraction) as one branch-free record
-struct __attribute__((aligned(16))) PairFast {
-    double c4eps, sigma2, qq, alpha, shift;        // 4 eps, sigma^2, coulombic q1 q2, alpha, sum of the shifts
-    int32_t cls, _pad;                             // 1: this record is the whole entry; 0: walk the rules
-};
-
-struct __attribute__((aligned(16))) FracHit {      // a queued candidate pair
-    double r2;
-    int32_t t, ia;                                 // pair-table index; atom index << 4 | trial atom (for the band around the cutoff)
-};
-
-// LDS image of the pair table of k_pairs_frac -- only the entries (kind of a guest atom, trial atom a) the molecule on trial can meet, entry
-// kind * m + a: the PairFast records, then the rules of these entries (for those that are not one record), then their offsets.  The
-// whole table of the fixture force field (20 kinds: 26 KB) left room for two workgroups per CU only.
-struct FracTable {
-    const PairFast* fast;      // [nkinds * m]
-    const DevRule* rules;      // [nrules]
-    const int32_t* off;        // [nkinds * m + 1]
-    int32_t nrules, nentries;
-};
-__host__ __device__ inline size_t frac_table_bytes(int nentries, int nrules)
-{
-    return sizeof(PairFast) * (size_t)nentries + sizeof(DevRule) * (size_t)(nrules > 0 ? nrules : 1) + sizeof(int32_t) * ((size_t)nentries + 1);
-}
-
+// ---- round 4: the pair tests on FRACTIONAL coordinates (ceg_pairfrac.h) ---------------------------------------------------------
 template <int MM, bool CELLS, bool TRI>
 __global__ __launch_bounds__(64 * PAIRS_WAVES, 3) void k_pairs_frac(PairsGeom g, FracTable tab,
                                                                   const double4* __restrict__ frac,     // fx, fy, fz, (kind | molecule) bits
@@ -267,207 +239,34 @@ __global__ __launch_bounds__(64 * PAIRS_WAVES, 3) void k_pairs_frac(PairsGeom g,
                                                                   const double* __restrict__ trial, int64_t n, double* __restrict__ out, int per_wave)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_table[];
-    PairFast* fastrec = reinterpret_cast<PairFast*>(s_table);
-    DevRule* rules = reinterpret_cast<DevRule*>(fastrec + tab.nentries);
-    int32_t* offset = reinterpret_cast<int32_t*>(rules + (tab.nrules > 0 ? tab.nrules : 1));
-    __shared__ double s_mat[12];                                      // the cell matrix, -mat * (1/2, 1/2, 1/2) (read back into VGPRs at the start of every scan)
-    {
-        for (int t = threadIdx.x; t < tab.nentries; t += 64 * PAIRS_WAVES) fastrec[t] = tab.fast[t];
-        for (int t = threadIdx.x; t < tab.nrules; t += 64 * PAIRS_WAVES) rules[t] = tab.rules[t];
-        for (int t = threadIdx.x; t <= tab.nentries; t += 64 * PAIRS_WAVES) offset[t] = tab.off[t];
-        if (threadIdx.x < 9) s_mat[threadIdx.x] = g.mat[threadIdx.x];
-        if (threadIdx.x >= 9 && threadIdx.x < 12) s_mat[threadIdx.x] = -0.5 * (g.mat[threadIdx.x - 9] + g.mat[threadIdx.x - 6] + g.mat[threadIdx.x - 3]);
-        __syncthreads();
-    }
+    __shared__ double s_mat[12];
+    __shared__ double s_trial[PAIRS_WAVES][PAIRS_MAX_ATOMS * 3];
+    __shared__ double s_ft[PAIRS_WAVES][PAIRS_MAX_ATOMS * 3];
+    __shared__ FracHit s_q[PAIRS_WAVES][FQCAP];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // (per_wave consecutive placements per wave: a wave that lives for one placement only is ~40 us of work, and the workgroups did not
-    //  arrive fast enough to keep three per CU resident)
+    ceg_pairfrac::FracWave<MM, TRI> w;
+    {
+        PairFast* fastrec; DevRule* rules; int32_t* offset;
+        ceg_pairfrac::stage(s_table, tab, g.mat, s_mat, threadIdx.x, 64 * PAIRS_WAVES, fastrec, rules, offset);
+        __syncthreads();
+        w.fastrec = fastrec; w.rules = rules; w.offset = offset;
+    }
+    w.s_mat = s_mat; w.t3 = s_trial[wave]; w.ft = s_ft[wave]; w.hq = s_q[wave];
+    w.frac = frac; w.cart = atoms; w.geom = g.geom;
+    w.cutoff2 = g.cutoff2; w.band = 1e-9 * g.cutoff2; w.cutoff2_band = w.cutoff2 + w.band; w.coulombic = g.coulombic;
+    const int m = MM > 0 ? MM : g.m;
+    w.m = m; w.exclude = g.exclude; w.lane = lane;
+    // (per_wave consecutive placements per wave: a wave that lives for one placement only is ~40 us of work)
     const int64_t p_first = ((int64_t)blockIdx.x * PAIRS_WAVES + wave) * per_wave;
     const int64_t p_last = p_first + per_wave < n ? p_first + per_wave : n;
-    __shared__ double s_trial[PAIRS_WAVES][PAIRS_MAX_ATOMS * 3];      // Cartesian (band, cell range)
-    __shared__ double s_ft[PAIRS_WAVES][PAIRS_MAX_ATOMS * 3];         // fractional
-    __shared__ FracHit s_q[PAIRS_WAVES][FQCAP];                       // one 16-byte LDS write per hit
-    double* t3 = s_trial[wave];
-    double* ft = s_ft[wave];
-    FracHit* hq = s_q[wave];
     for (int64_t p = p_first; p < p_last; ++p) {
-        const int m = MM > 0 ? MM : g.m;
-        if (lane < 3 * m) t3[lane] = trial[(size_t)p * m * 3 + lane];
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 3 * m) {
-            const int a = lane / 3, ax = lane - 3 * a;
-            ft[lane] = __builtin_fma(g.invmat[6 + ax], t3[3 * a + 2], __builtin_fma(g.invmat[3 + ax], t3[3 * a + 1], g.invmat[ax] * t3[3 * a])) + 0.5;       // (+ 1/2: see `tests`)
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int exclude = g.exclude;
-        const double cutoff2 = g.cutoff2, band = 1e-9 * g.cutoff2, coulombic = g.coulombic;
-        int qn = 0;                                   // wave-uniform
-        double e = 0.0;
-        // full batches of 64 queued pairs (everything when `all`); the remainder moves to the front
-        auto flush = [&](const bool all) {
-            __builtin_amdgcn_wave_barrier();
-            const int nfull = all ? qn : (qn & ~63);
-            for (int i = lane; i < nfull; i += 64) {
-                const FracHit H = hq[i];
-                double r2 = H.r2;
-                const int t = H.t;
-                if (__builtin_expect(r2 >= cutoff2 - band, 0)) {             // the cutoff decision is the reference's (utils.jl:294-302 as written)
-                    const int ia = H.ia, a = ia & 15;
-                    const double4 A = atoms[ia >> 4];
-                    r2 = ceg_consumers::pair_distance2_literal_call(g.geom, t3[3 * a] - A.x, t3[3 * a + 1] - A.y, t3[3 * a + 2] - A.z);
-                    if (!(r2 < cutoff2)) continue;                           // energy.jl:422
-                }
-                if (r2 >= 0.25) {
-                    double r, rinv;
-                    ceg::fast_sqrt_rsqrt(r2, r, rinv);
-                    const PairFast P = fastrec[t];
-                    if (P.cls) {
-                        const double q2 = P.sigma2 * (rinv * rinv);
-                        const double x6 = q2 * q2 * q2;
-                        double v = __builtin_fma(P.c4eps * x6, x6 - 1.0, -P.shift);
-                        if (P.qq != 0.0) {
-                            const double x = P.alpha * r;
-                            v = __builtin_fma(P.qq * rinv, ceg::fast_exp_neg(-(x * x)) * ceg::erfcx_poly(x), v);
-                        }
-                        e += v;
-                    } else {
-                        for (int q = offset[t]; q < offset[t + 1]; ++q) e += rule_energy_fast(rules[q], r2, r, rinv, coulombic);
-                    }
-                } else {
-                    for (int q = offset[t]; q < offset[t + 1]; ++q) e += pairs_rule_energy_call(&rules[q], r2, coulombic);
-                }
-            }
-            const int rest = qn - nfull;              // < 64
-            FracHit Hm{0.0, 0, 0};
-            if (lane < rest) Hm = hq[nfull + lane];
-            __builtin_amdgcn_wave_barrier();
-            if (lane < rest) hq[lane] = Hm;
-            __builtin_amdgcn_wave_barrier();
-            qn = rest;
-        };
-        const double cutoff2_band = cutoff2 + band;
-        // The scan of the atoms and the rule arithmetic alternate: `scan` tests blocks of 64 atoms until the queue could overflow in the
-        // next block, then the queue is worked off.  Everything the scan keeps in registers (cell matrix, fractional coordinates and kinds of
-        // the trial atoms) is re-read at the start of each scan, so that it is NOT live across the rule arithmetic -- with both sets live the
-        // kernel needs 150-170 VGPRs and spills.
-        constexpr int QROOM = FQCAP - 64 * (MM > 0 ? MM : 4);               // the queue has room for one more step of the scan
-        // fetch(l) -> index into frac / atoms of entry l (l < total), total: number of entries
-        int a_next = 0;
-        auto scan = [&](auto&& locate, const int total, int l0) __attribute__((always_inline)) -> int {
-            asm volatile("" ::: "memory");
-            // the cell matrix in VGPRs (wave-uniform, but the kernel has more uniform values than scalar registers: see k_pairs)
-            double Mv[12];
-#pragma unroll
-            for (int a = 0; a < 12; ++a) Mv[a] = s_mat[a];
-            int exclude_v = exclude;                                        // (in a VGPR: as a scalar it was re-read from the kernel arguments every block)
-            asm volatile("" : "+v"(exclude_v));
-            double ftr[MM > 0 ? MM : 1][3];
-            if (MM > 0) {
-#pragma unroll
-                for (int a = 0; a < MM; ++a) {
-                    ftr[a][0] = ft[3 * a]; ftr[a][1] = ft[3 * a + 1]; ftr[a][2] = ft[3 * a + 2];
-                }
-            }
-            // K trial atoms (a0 ... a0 + K - 1) against the atom of this lane
-            // The wrapped difference d - rint(d) is taken as fract(d + 1/2) - 1/2 (the 1/2 is part of the stored trial coordinates, the
-            // -1/2 is folded into the matrix product as -mat * (1/2, 1/2, 1/2)): two instructions per component instead of three.  Lanes
-            // without an atom (or with an atom of the excluded molecule) carry NaN in F.x and never compare inside.
-            auto tests = [&](auto ktag, const int a0, const double4 F, const int kbase, const int idx) __attribute__((always_inline)) {
-                constexpr int K = decltype(ktag)::value;
-                double r2[K];
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const double f0 = __builtin_amdgcn_fract((MM > 0 ? ftr[k][0] : ft[3 * (a0 + k)]) - F.x);
-                    const double f1 = __builtin_amdgcn_fract((MM > 0 ? ftr[k][1] : ft[3 * (a0 + k) + 1]) - F.y);
-                    const double f2 = __builtin_amdgcn_fract((MM > 0 ? ftr[k][2] : ft[3 * (a0 + k) + 2]) - F.z);
-                    double vx, vy, vz;
-                    if (TRI) {
-                        vx = __builtin_fma(Mv[0], f0, __builtin_fma(Mv[3], f1, __builtin_fma(Mv[6], f2, Mv[9])));
-                        vy = __builtin_fma(Mv[4], f1, __builtin_fma(Mv[7], f2, Mv[10]));
-                        vz = __builtin_fma(Mv[8], f2, Mv[11]);
-                    } else {
-                        vx = __builtin_fma(Mv[0], f0, __builtin_fma(Mv[3], f1, __builtin_fma(Mv[6], f2, Mv[9])));
-                        vy = __builtin_fma(Mv[1], f0, __builtin_fma(Mv[4], f1, __builtin_fma(Mv[7], f2, Mv[10])));
-                        vz = __builtin_fma(Mv[2], f0, __builtin_fma(Mv[5], f1, __builtin_fma(Mv[8], f2, Mv[11])));
-                    }
-                    r2[k] = __builtin_fma(vz, vz, __builtin_fma(vy, vy, vx * vx));
-                }
-                // (all K distances before the first queue entry: K independent chains for the scheduler, not K chains one after the other)
-#pragma unroll
-                for (int k = 0; k < K; ++k) asm volatile("" : "+v"(r2[k]));
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    // candidates: inside the cutoff or in the band around it (those are re-measured when the queue is worked off)
-                    const bool inside = r2[k] <= cutoff2_band;
-                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(inside);        // (the ballot of a compare is its scalar result as it stands)
-                    if (inside) {
-                        const int slot = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                        hq[slot] = FracHit{r2[k], kbase + (a0 + k), (idx << 4) | (a0 + k)};
-                    }
-                    qn += __popcll(mask);
-                }
-            };
-            auto masked = [&](double4 F, const bool live) __attribute__((always_inline)) -> double4 {
-                F.x = live ? F.x : __builtin_nan("");
-                return F;
-            };
-            int a0 = a_next;                                                // (MM == 0: the molecule is taken four atoms at a time)
-            if (MM > 0) {
-                // Three blocks in registers, the loop body written out three times: the block fetched after a step is used two steps later
-                // (a block is ~0.3 us of work, an L2 hit takes longer), and no register is copied -- a copy would wait for its load.
-                int ixa = locate(l0 + lane), ixb = locate(l0 + 64 + lane), ixc = locate(l0 + 128 + lane);
-                double4 Fa = frac[ixa], Fb = frac[ixb], Fc = frac[ixc];
-                auto step = [&](double4& F, int& ix) __attribute__((always_inline)) {
-                    const long long bits = __double_as_longlong(F.w);
-                    const int kind1 = (int)(bits & 0xffffffffll), mol = (int)(bits >> 32);
-                    const bool live = l0 + lane < total && mol != exclude_v;
-                    tests(std::integral_constant<int, (MM > 0 ? MM : 1)>{}, 0, masked(F, live), kind1 * m, ix);
-                    ix = locate(l0 + 192 + lane);
-                    F = frac[ix];
-                    l0 += 64;
-                };
-                while (true) {
-                    if (!(l0 < total && qn <= QROOM)) break;
-                    step(Fa, ixa);
-                    if (!(l0 < total && qn <= QROOM)) break;
-                    step(Fb, ixb);
-                    if (!(l0 < total && qn <= QROOM)) break;
-                    step(Fc, ixc);
-                }
-            } else {
-                int ix = locate(l0 + lane), ix1 = locate(l0 + 64 + lane);
-                double4 F = frac[ix], F1 = frac[ix1];
-                while (l0 < total && qn <= QROOM) {
-                    const long long bits = __double_as_longlong(F.w);
-                    const int kind1 = (int)(bits & 0xffffffffll), mol = (int)(bits >> 32);
-                    const bool live = l0 + lane < total && mol != exclude_v;
-                    const int kbase = kind1 * m;
-                    const double4 Fm = masked(F, live);
-                    switch (m - a0 < 4 ? m - a0 : 4) {
-                        case 4: tests(std::integral_constant<int, 4>{}, a0, Fm, kbase, ix); break;
-                        case 3: tests(std::integral_constant<int, 3>{}, a0, Fm, kbase, ix); break;
-                        case 2: tests(std::integral_constant<int, 2>{}, a0, Fm, kbase, ix); break;
-                        default: tests(std::integral_constant<int, 1>{}, a0, Fm, kbase, ix); break;
-                    }
-                    a0 += 4;
-                    if (a0 >= m) {
-                        a0 = 0;
-                        l0 += 64;
-                        F = F1; ix = ix1;
-                        ix1 = locate(l0 + 64 + lane);
-                        F1 = frac[ix1];
-                    }
-                }
-            }
-            a_next = a0;
-            return l0;
-        };
+        w.load(g.invmat, [&](int i) { return trial[(size_t)p * m * 3 + i]; });
         if (!CELLS) {
             const int total = (int)natoms;
             auto locate = [&](int l) -> int { return l < total ? l : 0; };
             for (int l0 = 0; l0 < total;) {
-                l0 = scan(locate, total, l0);
-                flush(false);
+                l0 = w.scan(locate, total, l0);
+                w.flush(false);
             }
         } else {
             // (the run construction of k_pairs: lane r takes run r of the reachable cells, a wave scan turns run lengths into offsets)
@@ -475,7 +274,7 @@ __global__ __launch_bounds__(64 * PAIRS_WAVES, 3) void k_pairs_frac(PairsGeom g,
             int32_t* run = s_run[wave];
             int32_t* off = s_off[wave];
             int first = 0, nbin = 1;
-            if (lane < 3) ceg_consumers::cell_range(g.invmat, t3, m, lane, g.nb[lane], g.hfrac[lane], first, nbin);
+            if (lane < 3) ceg_consumers::cell_range(g.invmat, w.t3, m, lane, g.nb[lane], g.hfrac[lane], first, nbin);
             const int b0 = __shfl(first, 0), b1 = __shfl(first, 1), b2 = __shfl(first, 2);
             const int n0 = __shfl(nbin, 0), n1 = __shfl(nbin, 1), n2 = __shfl(nbin, 2);
             const int wrapped = b2 + n2 > g.nb[2] ? 1 : 0;
@@ -512,17 +311,15 @@ __global__ __launch_bounds__(64 * PAIRS_WAVES, 3) void k_pairs_frac(PairsGeom g,
                     return l < total ? run[j] + (l - off[j]) : 0;
                 };
                 for (int l0 = 0; l0 < total;) {
-                    l0 = scan(locate, total, l0);
-                    flush(false);
+                    l0 = w.scan(locate, total, l0);
+                    w.flush(false);
                 }
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        flush(true);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
-        if (lane == 0) out[p] = e;
-    __builtin_amdgcn_wave_barrier();                             // t3 / ft / tk are rewritten for the next placement
+        const double s = w.sum();
+        if (lane == 0) out[p] = s;
+        __builtin_amdgcn_wave_barrier();                             // t3 / ft are rewritten for the next placement
     }
 }
 
@@ -701,17 +498,8 @@ const ceg_pairs::Compact* pairs_compact_table(ceg_pairs* h, const int32_t* kinds
     for (int k1 = 0; k1 < nkinds; ++k1)
         for (int a = 0; a < m; ++a) {
             const size_t t = (size_t)k1 * nkinds + kinds[a];
-            // (v - shift summed in another order than the rule loop: inside the 1e-9 of the pair sum, like the rest of the fast path)
-            PairFast P{0.0, 0.0, 0.0, 0.0, 0.0, 1, 0};
-            int nlj = 0, nced = 0;
-            for (int32_t q = h->h_offset[t]; q < h->h_offset[t + 1]; ++q) {
-                const DevRule& R = h->h_rules[(size_t)q];
-                rules.push_back(R);
-                if (R.kind == CEG_LENNARDJONES && nlj == 0) { P.c4eps = 4.0 * R.p0; P.sigma2 = R.p1 * R.p1; P.shift += R.shift; ++nlj; }
-                else if (R.kind == CEG_COULOMB_EWALD_DIRECT && nced == 0) { P.alpha = R.p0; P.qq = h->coulombic * R.p1 * R.p2; P.shift += R.shift; ++nced; }
-                else if (R.kind == CEG_NOINTERACTION) P.shift += R.shift;
-                else P.cls = 0;
-            }
+            for (int32_t q = h->h_offset[t]; q < h->h_offset[t + 1]; ++q) rules.push_back(h->h_rules[(size_t)q]);
+            const PairFast P = ceg_pairfrac::make_pair_fast(h->h_rules.data(), h->h_offset[t], h->h_offset[t + 1], h->coulombic);
             fast[(size_t)k1 * m + a] = P;
             off[(size_t)k1 * m + a + 1] = (int32_t)rules.size();
         }

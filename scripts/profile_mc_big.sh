@@ -19,7 +19,7 @@ for f in glob.glob(f"{out}/mc_big_trace/**/*kernel_trace.csv", recursive=True):
 pmc = collections.defaultdict(list)
 lines = open(f"{out}/mc_big_pmc.log").read().splitlines()
 # pmc_kernel.sh prints the launches in dispatch order: frame, ewald, pairs, frame, ...
-order = ["k_mcw_frame", "k_mcw_ewald", "k_mcw_pairs"]
+order = ["k_mcw_frame", "k_mcw_ewald", "k_mcw_pairs_frac" if "k_mcw_pairs_frac" in spans else "k_mcw_pairs"]
 k = 0
 for i, l in enumerate(lines):
     if l.startswith("launch "):

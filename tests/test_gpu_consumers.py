@@ -657,7 +657,7 @@ def test_mc_neighbour_cells(hip_lib, oracle, forcefield, monkeypatch):
         worst = worst_oracle = 0.0
         noracle = 0
 
-        def compare(rows, what):
+        def compare(rows, what, tol=1e-10):
             nonlocal worst
             ref = rows["exhaustive"]
             for name, got in rows.items():
@@ -666,7 +666,7 @@ def test_mc_neighbour_cells(hip_lib, oracle, forcefield, monkeypatch):
                 assert np.array_equal(got[~fin], ref[~fin]), (what, name)
                 err = np.abs(got[fin] - ref[fin]) / (np.abs(ref[fin]) + 1e-3)
                 worst = max(worst, float(err.max()) if fin.any() else 0.0)
-                assert (err <= 1e-10).all(), (what, name, float(err.max()))
+                assert (err <= tol).all(), (what, name, float(err.max()))
 
         for step in range(360):
             op = step % 6
@@ -720,6 +720,17 @@ def test_mc_neighbour_cells(hip_lib, oracle, forcefield, monkeypatch):
         compare(rows, "batch")
         ref = oracle.single_contribution_vdw_raw(mat, inv, *table[1:], pos, kinds, mol, trial[::64], ks, j)
         _assert_energies(rows["cells 4 A"][1::64], ref, "cells vs oracle, batch")
+        # the same batch through the Cartesian wave kernel (k_mcw_pairs; the default above is k_mcw_pairs_frac), and an insertion batch
+        monkeypatch.setenv("CEG_HIP_MC_FRAC", "0")
+        compare({"exhaustive": rows["exhaustive"], **{name + ", Cartesian kernel": h.trial(j, trial) for name, h in handles.items()}}, "batch, Cartesian kernel",
+                tol=1e-9)                                          # (another arithmetic, not only another order: the parity tolerance)
+        monkeypatch.delenv("CEG_HIP_MC_FRAC")
+        trial_i = (rng.uniform(0, 1, (6000, 3)) @ mat.T)[:, None, :] + (cur - cur[1])[None]
+        trial_i[:500] = (hot + rng.uniform(-3.0, 3.0, (500, 3)))[:, None, :] + (cur - cur[1])[None]          # into the crowded spot
+        rows_i = {name: h.trial_insert(ks, trial_i) for name, h in handles.items()}
+        compare(rows_i, "insertion batch")
+        ref_i = oracle.single_contribution_vdw_raw(mat, inv, *table[1:], pos, kinds, mol, trial_i[::32], ks, -1)
+        _assert_energies(rows_i["cells 4 A"][::32], ref_i, "cells vs oracle, insertion batch")
         print(f"neighbour cells: worst deviation from the exhaustive loop {worst:.1e}, from the oracle {worst_oracle:.1e}; capacity {cap0} -> {cap1}")
     finally:
         for h in handles.values():
