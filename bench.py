@@ -82,7 +82,19 @@ def csrc_sha256() -> str:
     csrc = ROOT / "crystalenergygrids.jl_amd" / "csrc"
     for fn in GRID_KERNEL_SOURCES:
         h.update(fn.encode())
-        h.update((csrc / fn).read_bytes())
+        data = (csrc / fn).read_bytes()
+        if fn == "Makefile":
+            # only what reaches the compiler (ARCH / HIPCC / CXXFLAGS with its continuation lines): the lists of sources and headers
+            # change whenever a consumer kernel gains a file
+            keep, cont = [], False
+            for line in data.decode().splitlines():
+                if cont or line.split("=")[0].strip() in ("ARCH", "HIPCC", "CXXFLAGS"):
+                    keep.append(line)
+                    cont = line.rstrip().endswith("\\")
+                else:
+                    cont = False
+            data = "\n".join(keep).encode()
+        h.update(data)
     return h.hexdigest()
 
 

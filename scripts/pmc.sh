@@ -75,11 +75,9 @@ if all(v is not None for v in f64) and "lane_util" in summ:
     summ["fma_share_of_fp64_insts"] = fma / max(1.0, add + mul + fma + trans)
     print("fp64 instructions per launch", summ["fp64_insts_per_launch"], " executed flops (x lane_util)", summ["fp64_flops_per_launch"])
 root = os.environ.get("GRAFT_REPO_ROOT", ".")
-h = hashlib.sha256()
-csrc = os.path.join(root, "crystalenergygrids.jl_amd", "csrc")
-for fn in ("Makefile", "ceg_api.hip", "ceg_internal.h", "ceg_kernels.hip", "ceg_math.h", "ceg_minimage.h"):     # = bench.py GRID_KERNEL_SOURCES
-    h.update(fn.encode()); h.update(open(os.path.join(csrc, fn), "rb").read())
-summ["csrc_sha256"] = h.hexdigest()
+sys.path.insert(0, root)
+import bench                                              # the recipe lives in one place: bench.csrc_sha256 (GRID_KERNEL_SOURCES)
+summ["csrc_sha256"] = bench.csrc_sha256()
 summ["host"] = socket.gethostname()
 summ["timed_launches_per_pass"] = steps
 summ["key"] = key
