@@ -1509,7 +1509,8 @@ int launch_wave_kernels(ceg_mc* h, bool insert, int32_t molecule, const McMolecu
         if (hipMemset2DAsync(d_out + 3, 4 * sizeof(double), 0, sizeof(double), (size_t)rows, h->stream) != hipSuccess) return merr(CEG_ERR_HIP, "memset failed");
     }
     // single_contribution_vdw
-    bool frac_pairs = v.fast && v.fastwrap >= 1 && v.natoms > 0;
+    bool frac_pairs = v.fast && v.fastwrap >= 1 && v.natoms > 0 && v.natoms < (1 << 27) &&
+                      (!v.use_cells || (int64_t)v.nb[0] * v.nb[1] * v.nb[2] * v.cell_cap < (1 << 27));      // (atom index << 4 | trial atom in 32 bits)
     if (const char* e = std::getenv("CEG_HIP_MC_FRAC")) frac_pairs = frac_pairs && std::atoi(e) != 0;          // measurement aid: 0 = the Cartesian kernel
     const int nentries = v.nkinds * m;
     const size_t ftab_bytes = ceg_pairfrac::frac_table_bytes(nentries, ctab->nrules);

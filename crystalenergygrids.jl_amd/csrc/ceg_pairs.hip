@@ -549,7 +549,7 @@ extern "C" int ceg_pairs_energy_device(ceg_pairs_t* h, const double* d_trial, co
     hipStream_t st = (hipStream_t)stream;
     int wrap = ceg_consumers::wrap_mode(h->mat, h->invmat, h->bins.hfrac);
     if (const char* env = getenv("CEG_HIP_PAIRS_WRAP")) wrap = std::min(wrap, std::max(0, atoi(env)));      // measurement aid: 0 forces the literal form
-    bool use_frac = h->fast && wrap >= 1 && h->natoms > 0;
+    bool use_frac = h->fast && wrap >= 1 && h->natoms > 0 && h->natoms < (1 << 27);       // (a queued candidate carries atom index << 4 | trial atom in 32 bits)
     if (const char* env = getenv("CEG_HIP_PAIRS_FRAC")) use_frac = use_frac && atoi(env) != 0;               // measurement aid: 0 = the Cartesian kernel
     const ceg_pairs::Compact* ctab = use_frac ? pairs_compact_table(h, g.kinds, m) : nullptr;
     if (use_frac && !ctab) {
