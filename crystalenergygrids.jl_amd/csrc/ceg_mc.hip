@@ -758,7 +758,7 @@ __global__ __launch_bounds__(64 * MCW_WAVES, (FAST && CELLS) ? 3 : 4) void k_mcw
 // round 4, after k_pairs_frac): FAST rules and every perpendicular width of the MC cell above two cutoffs.  MM: exact molecule size 1-4
 // (0: any); TRI: upper-triangular cell.  The guest atoms come from fatoms / fcells (kept beside atoms / cells by every update kernel).
 template <int MM, bool CELLS, bool TRI>
-__global__ __launch_bounds__(64 * MCW_WAVES, 3) void k_mcw_pairs_frac(McView v, ceg_pairfrac::FracTable tab, int32_t molecule, int32_t insert, McMolecule nm,
+__global__ __launch_bounds__(64 * MCW_WAVES, CEG_PAIRFRAC_WAVES) void k_mcw_pairs_frac(McView v, ceg_pairfrac::FracTable tab, int32_t molecule, int32_t insert, McMolecule nm,
                                                                       const double* __restrict__ trial, int64_t nrows, double* __restrict__ out, int per_wave)
 {
     using ceg_pairfrac::FQCAP;

@@ -28,6 +28,11 @@ using ceg::DevRule;
 
 constexpr int FQCAP = 384;
 
+// waves per SIMD asked of the kernels built on this header (3: 168 VGPRs, no scratch; 4 measured: see profiles/r04_consumers_pairs.txt)
+#ifndef CEG_PAIRFRAC_WAVES
+#define CEG_PAIRFRAC_WAVES 3
+#endif
+
 // a pair-table entry whose rules are at most one Lennard-Jones and one CoulombEwaldDirect term (+ NoInteraction) as one branch-free record
 struct __attribute__((aligned(16))) PairFast {
     double c4eps, sigma2, qq, alpha, shift;        // 4 eps, sigma^2, coulombic q1 q2, alpha, sum of the shifts

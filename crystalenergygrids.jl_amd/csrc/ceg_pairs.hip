@@ -232,7 +232,7 @@ __global__ __launch_bounds__(64 * PAIRS_WAVES, 3) void k_pairs(PairsGeom g, cons
 
 // ---- round 4: the pair tests on FRACTIONAL coordinates (ceg_pairfrac.h) ---------------------------------------------------------
 template <int MM, bool CELLS, bool TRI>
-__global__ __launch_bounds__(64 * PAIRS_WAVES, 3) void k_pairs_frac(PairsGeom g, FracTable tab,
+__global__ __launch_bounds__(64 * PAIRS_WAVES, CEG_PAIRFRAC_WAVES) void k_pairs_frac(PairsGeom g, FracTable tab,
                                                                   const double4* __restrict__ frac,     // fx, fy, fz, (kind | molecule) bits
                                                                   const double4* __restrict__ atoms,                    // Cartesian, same order (band only)
                                                                   const int32_t* __restrict__ cell_start, int64_t natoms,
