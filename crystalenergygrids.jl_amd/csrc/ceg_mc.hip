@@ -232,12 +232,16 @@ __global__ __launch_bounds__(MC_THREADS, MC_TRIAL_WAVES) void k_mc_trial(McView 
     __shared__ double s_red[MC_THREADS / 64][5];
     __shared__ int s_bin0[3], s_nbin[3], s_wtot[MC_THREADS / 64], s_first[MC_THREADS], s_cell[MC_THREADS];
     const int tid = threadIdx.x;
+    // gridDim.y == 3: the three terms of a row on three workgroups (blockIdx.y = 0 framework grids, 1 reciprocal sum, 2 guest-guest pairs) --
+    // the latency of a small batch is the longest term, not their sum; gridDim.y == 1: one workgroup does all three
+    const int term = gridDim.y == 1 ? -1 : (int)blockIdx.y;
+    const bool do_frame = term < 0 || term == 0, do_ewald = term < 0 || term == 1, do_pairs = term < 0 || term == 2;
     const int64_t b = INSERT ? (int64_t)blockIdx.x + 1 : (int64_t)blockIdx.x;     // 0: where the molecule is now; b >= 1: trial b - 1
     const int first = INSERT ? 0 : v.mol[molecule].x, m = INSERT ? nm.m : v.mol[molecule].y;
     double2* tab = reinterpret_cast<double2*>(s_raw);
     const DevRule* rules = v.rules;
     const int32_t* offset = v.rule_offset;
-    if (v.table_in_lds) {
+    if (v.table_in_lds && do_pairs) {
         DevRule* lr = reinterpret_cast<DevRule*>(s_raw + sizeof(double2) * (size_t)m * stride);
         int32_t* lo = reinterpret_cast<int32_t*>(lr + (v.nrules > 0 ? v.nrules : 1));
         for (int t = tid; t < v.nrules; t += MC_THREADS) lr[t] = v.rules[t];
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(MC_THREADS, MC_TRIAL_WAVES) void k_mc_trial(McView 
 
     double fv = 0.0, fd = 0.0, inter = 0.0, rs = 0.0, ss = 0.0;
     // ---- framework_interactions (montecarlo.jl:490-504): thread 2a -> VdW grid of atom a, thread 2a+1 -> Coulomb grid
-    if (tid < 2 * m) {
+    if (do_frame && tid < 2 * m) {
         const int a = tid >> 1;
         const double px = s_pos[3 * a], py = s_pos[3 * a + 1], pz = s_pos[3 * a + 2];
         if ((tid & 1) == 0) {
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(MC_THREADS, MC_TRIAL_WAVES) void k_mc_trial(McView 
         }
     }
     // ---- single_contribution_ewald (ewald.jl:704-738)
-    if (v.nk > 0) {
+    if (v.nk > 0 && do_ewald) {
         if (b != 0) fill_tables(v, s_pos, m, tab, stride, tid, MC_THREADS);
         __syncthreads();
         const double2* mine = v.sf_mol + (size_t)(INSERT ? 0 : molecule) * v.nk;
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(MC_THREADS, MC_TRIAL_WAVES) void k_mc_trial(McView 
     }
     // ---- single_contribution_vdw (energy.jl:407-427)
     if (v.table_in_lds) __syncthreads();
-    {
+    if (do_pairs) {
         const double* M = v.mat;
         const double* I = v.invmat;
         auto pairs_with = [&](const double4 A) __attribute__((always_inline)) {
@@ -390,15 +394,14 @@ __global__ __launch_bounds__(MC_THREADS, MC_TRIAL_WAVES) void k_mc_trial(McView 
         for (int w = 0; w < MC_THREADS / 64; ++w)
             for (int c = 0; c < 5; ++c) tot[c] += s_red[w][c];
         double* o = out + 4 * (size_t)blockIdx.x;
-        o[0] = tot[0];
-        o[1] = tot[1];
-        o[2] = tot[2];
-        o[3] = 2.0 * tot[3] + tot[4];
+        if (do_frame) { o[0] = tot[0]; o[1] = tot[1]; }
+        if (do_pairs) o[2] = tot[2];
+        if (do_ewald) o[3] = 2.0 * tot[3] + tot[4];
         // small batches: the rows sit in mapped host memory and the host polls `flag` instead of going through
         // hipStreamSynchronize (whose wake-up costs about as much as this kernel); the last workgroup to finish raises it
         if (flag) {
             __threadfence_system();
-            if (atomicAdd(done, 1u) == gridDim.x - 1) {
+            if (atomicAdd(done, 1u) == gridDim.x * gridDim.y - 1) {
                 *done = 0u;
                 __threadfence_system();
                 __atomic_store_n(flag, seq, __ATOMIC_RELEASE);
@@ -1460,7 +1463,7 @@ const ceg_mc::Compact* compact_table(ceg_mc* h, const int32_t* kinds, int m)
 int64_t wave_kernel_min_rows()
 {
     if (const char* e = std::getenv("CEG_HIP_MC_WAVE_MIN")) return std::atoll(e);
-    return 2048;        // measured cross-over (64 CO2 in CHA, 1368 k-vectors): 1024 rows 56 vs 60 us, 2048 rows 80 vs 74 us, 65 536 rows 1520 vs 690 us
+    return 1024;        // measured cross-over (64 CO2 in CHA, 1368 k-vectors): 512 rows 40 vs 47 us, 1024 rows 55 vs 50 us, 2048 rows 77 vs 62 us, 65 536 rows 1520 vs 545 us
 }
 
 // placements per wave: amortise what a workgroup stages, but keep every CU busy (>= ~2048 workgroups when the batch allows it)
@@ -1606,7 +1609,10 @@ int run_trial(ceg_mc* h, bool insert, int32_t molecule, const McMolecule& nm, in
     size_t table_bytes = v.table_in_lds ? sizeof(DevRule) * (size_t)(v.nrules > 0 ? v.nrules : 1) + sizeof(int32_t) * ((size_t)v.nkinds * v.nkinds + 1) : 0;
     if (tables_bytes(h, m) + table_bytes > 64 * 1024) { v.table_in_lds = 0; table_bytes = 0; }   // pair table from global memory then
     const size_t lds = tables_bytes(h, m) + table_bytes;
-    const dim3 grid((unsigned)rows), block(MC_THREADS);
+    // small batches: the three terms of a row on three workgroups (latency = the longest term); CEG_HIP_MC_SPLIT_MAX moves the limit (0: never)
+    int64_t split_max = 256;           // measured (64 CO2 in CHA): 1 row 32 -> 24 us per call, 64 rows 36 -> 29, 256 rows 38 = 38, 512 rows 40 -> 46
+    if (const char* e = std::getenv("CEG_HIP_MC_SPLIT_MAX")) split_max = std::atoll(e);
+    const dim3 grid((unsigned)rows, rows <= split_max ? 3u : 1u), block(MC_THREADS);
     unsigned long long* flag = nullptr;
     // (only for the latency-bound small batches: with ~1000 workgroups the fences and the shared counter cost more than the wake-up)
     if (mapped && rows <= 64 && !getenv("CEG_HIP_MC_NO_POLL")) { flag = h->dm_flag; ++h->seq; }

@@ -413,7 +413,7 @@ def test_mc_insertions_and_removals(hip_lib, tmp_path):
 
 
 def test_mc_large_batches_take_the_wave_kernels(hip_lib, tmp_path, monkeypatch):
-    """From 2048 rows on a trial batch runs as three wave-per-placement launches (k_mcw_frame / k_mcw_ewald / k_mcw_pairs: one grid
+    """From 1024 rows on a trial batch runs as three wave-per-placement launches (k_mcw_frame / k_mcw_ewald / k_mcw_pairs: one grid
     corner per lane, k-space constants staged once per workgroup + row-wise k-vector walk, the pair-table rows of the molecule's
     kinds in LDS) instead of one workgroup per placement.  Displacement batches (row 0 = the molecule where it is, with its STORED
     structure factor) and insertion batches of both species, after some accepted moves and an insertion, sampled against the ORACLE's
@@ -447,8 +447,12 @@ def test_mc_large_batches_take_the_wave_kernels(hip_lib, tmp_path, monkeypatch):
             monkeypatch.setenv("CEG_HIP_MC_WAVE_MIN", "0")
             wave = call()
             monkeypatch.setenv("CEG_HIP_MC_WAVE_MIN", "1000000000")
-            group = call()
+            group = call()                                         # one workgroup per row (more than 256 rows)
+            monkeypatch.setenv("CEG_HIP_MC_SPLIT_MAX", "1000000000")
+            split = call()                                         # the three terms of a row on three workgroups, as for small batches
+            monkeypatch.delenv("CEG_HIP_MC_SPLIT_MAX")
             monkeypatch.delenv("CEG_HIP_MC_WAVE_MIN")
+            assert np.array_equal(split, group, equal_nan=True)    # the same arithmetic in the same order
             assert np.array_equal(np.abs(wave) >= 1e90, np.abs(group) >= 1e90)
             for c in range(4):            # same terms in another order: 1e-10 of the value, floored at 1e-13 of the column's upper quartile
                 ok = (np.abs(group[:, c]) < 1e90) & np.isfinite(group[:, c])
