@@ -123,6 +123,9 @@ struct McMolecule { int32_t m; int32_t kinds[MC_MAX_ATOMS]; };
 
 struct McPositions { double xyz[MC_MAX_ATOMS * 3]; };
 
+// the molecule on trial as the host knows it (k_mc_trial: no dependent loads of slot, kinds and charges in front of a batch-1 call)
+struct McLocal { int32_t first, m; int32_t kinds[MC_MAX_ATOMS]; double q[MC_MAX_ATOMS]; };
+
 __device__ __forceinline__ void unpack(double w, int& kind, int& mol)
 {
     const long long bits = __double_as_longlong(w);
@@ -220,7 +223,7 @@ __device__ __forceinline__ double2 molecule_sf(const McView& v, const double2* t
 // INSERT: the molecule is described by `nm` and is not in the system -- no current-position row, nothing excluded from the
 // pair sum, rest = framework + sums[:, 1]
 template <bool FAST, bool INSERT, bool CELLS>
-__global__ __launch_bounds__(MC_THREADS, MC_TRIAL_WAVES) void k_mc_trial(McView v, int32_t molecule, McMolecule nm, const double* __restrict__ trial, int64_t n,
+__global__ __launch_bounds__(MC_THREADS, MC_TRIAL_WAVES) void k_mc_trial(McView v, int32_t molecule, McLocal L, const double* __restrict__ trial, int64_t n,
                                                           double* __restrict__ out, int stride, unsigned* done, unsigned long long* flag,
                                                           unsigned long long seq)
 {
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(MC_THREADS, MC_TRIAL_WAVES) void k_mc_trial(McView 
     const int term = gridDim.y == 1 ? -1 : (int)blockIdx.y;
     const bool do_frame = term < 0 || term == 0, do_ewald = term < 0 || term == 1, do_pairs = term < 0 || term == 2;
     const int64_t b = INSERT ? (int64_t)blockIdx.x + 1 : (int64_t)blockIdx.x;     // 0: where the molecule is now; b >= 1: trial b - 1
-    const int first = INSERT ? 0 : v.mol[molecule].x, m = INSERT ? nm.m : v.mol[molecule].y;
+    const int first = L.first, m = L.m;
     double2* tab = reinterpret_cast<double2*>(s_raw);
     const DevRule* rules = v.rules;
     const int32_t* offset = v.rule_offset;
@@ -258,40 +261,81 @@ __global__ __launch_bounds__(MC_THREADS, MC_TRIAL_WAVES) void k_mc_trial(McView 
         }
     }
     if (tid < m) {
-        int kind, mol;
-        if (INSERT) kind = nm.kinds[tid];
-        else unpack(v.atoms[first + tid].w, kind, mol);
-        s_kind[tid] = kind;
-        s_q[tid] = v.kind_charge[kind];
+        s_kind[tid] = L.kinds[tid];
+        s_q[tid] = L.q[tid];
     }
+    // the k-space constants of the first k-vectors of this thread do not depend on the positions: fetched before anything else
+    constexpr int R = 3;
+    const double2* mine = v.sf_mol + (size_t)(INSERT ? 0 : molecule) * v.nk;
+    struct KChunk { double2 old[R], f[R], t[R]; double kf[R]; };
+    auto load_chunk = [&](const int64_t q0, KChunk& c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t q = q0 + (int64_t)r * MC_THREADS;
+            const bool in = q < v.nk;
+            const int64_t qq = in ? q : 0;
+            c.old[r] = (INSERT || !in) ? make_double2(0.0, 0.0) : mine[qq];
+            c.f[r] = in ? v.sf_fw[qq] : make_double2(0.0, 0.0);
+            c.t[r] = in ? v.sf_tot[qq] : make_double2(0.0, 0.0);
+            c.kf[r] = in ? v.kf[qq] : 0.0;
+        }
+    };
+    KChunk cur;
+    if (v.nk > 0 && do_ewald) load_chunk(tid, cur);
+    double4 A_first = make_double4(0.0, 0.0, 0.0, 0.0);             // likewise the first guest atom of this thread
+    if (do_pairs && !CELLS) A_first = v.atoms[tid < v.natoms ? tid : 0];
     __syncthreads();
 
     double fv = 0.0, fd = 0.0, inter = 0.0, rs = 0.0, ss = 0.0;
-    // ---- framework_interactions (montecarlo.jl:490-504): thread 2a -> VdW grid of atom a, thread 2a+1 -> Coulomb grid
-    if (do_frame && tid < 2 * m) {
-        const int a = tid >> 1;
-        const double px = s_pos[3 * a], py = s_pos[3 * a + 1], pz = s_pos[3 * a + 2];
-        if ((tid & 1) == 0) {
-            const McGrid G = v.vdw[s_kind[a]];
-            if (G.grid) fv = interp_point(G.g, G.grid, px, py, pz);
-        } else if (v.coulomb.grid) {
-            const double c = interp_point(v.coulomb.g, v.coulomb.grid, px, py, pz);
-            fd = (c == 1e100) ? c : s_q[a] * c;                       // :500
+    // ---- framework_interactions (montecarlo.jl:490-504): thread 16a + 8g + corner, g = 0 the VdW grid of atom a, g = 1 the Coulomb grid --
+    // one grid CORNER per thread, three shuffles per sum (the 64-term polynomial on one thread was the longest chain of a batch-1 call)
+    if (do_frame) {
+        static_assert(16 * MC_MAX_ATOMS <= MC_THREADS, "one thread per corner");
+        const int a = tid >> 4, gsel = (tid >> 3) & 1, corner = tid & 7;
+        double part = 0.0;
+        bool blocked = false, have = false, isvdw = false;
+        if (tid < 16 * m) {
+            const double px = s_pos[3 * a], py = s_pos[3 * a + 1], pz = s_pos[3 * a + 2];
+            if (gsel == 0) {
+                const McGrid* G = v.vdw + s_kind[a];
+                if (G->grid) { part = ceg_consumers::interp_corner(G->g, G->grid, px, py, pz, corner, blocked); have = true; isvdw = G->g.is_vdw != 0; }
+            } else if (v.coulomb.grid) {
+                part = ceg_consumers::interp_corner(v.coulomb.g, v.coulomb.grid, px, py, pz, corner, blocked);
+                have = true;
+                isvdw = v.coulomb.g.is_vdw != 0;
+            }
+        }
+        int blk = blocked ? 1 : 0;
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            part += __shfl_xor(part, o);
+            blk |= __shfl_xor(blk, o);
+        }
+        if (have && corner == 0) {
+            const double val = (isvdw && blk) ? 1e100 : part;         // grids.jl:245-248
+            if (gsel == 0) fv = val;
+            else fd = (val == 1e100) ? val : s_q[a] * val;            // montecarlo.jl:500
         }
     }
     // ---- single_contribution_ewald (ewald.jl:704-738)
     if (v.nk > 0 && do_ewald) {
         if (b != 0) fill_tables(v, s_pos, m, tab, stride, tid, MC_THREADS);
         __syncthreads();
-        const double2* mine = v.sf_mol + (size_t)(INSERT ? 0 : molecule) * v.nk;
-        for (int64_t q = tid; q < v.nk; q += MC_THREADS) {
-            const double2 old = INSERT ? make_double2(0.0, 0.0) : mine[q];
-            const double2 S = (b == 0) ? old : molecule_sf(v, tab, stride, s_q, m, q);
-            const double2 f = v.sf_fw[q], t = v.sf_tot[q];
-            const double rr = f.x + (t.x - old.x), ri = f.y + (t.y - old.y);      // rest = framework + (sums[:,1] - sums[:,ij+1])
-            const double kf = v.kf[q];
-            rs += kf * (rr * S.x + ri * S.y);
-            ss += kf * (S.x * S.x + S.y * S.y);
+        // three k-vectors per thread at a time, the constants of the next three fetched while these are worked on: one L2 round trip for
+        // the whole walk where a plain loop pays one per round (5-6 rounds of 256 k-vectors; the latency of a small batch was this loop)
+        for (int64_t q0 = tid; q0 < v.nk; q0 += (int64_t)R * MC_THREADS) {
+            KChunk nxt;
+            load_chunk(q0 + (int64_t)R * MC_THREADS, nxt);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int64_t q = q0 + (int64_t)r * MC_THREADS;
+                const int64_t qq = q < v.nk ? q : q0;
+                const double2 S = (b == 0) ? cur.old[r] : molecule_sf(v, tab, stride, s_q, m, qq);
+                const double rr = cur.f[r].x + (cur.t[r].x - cur.old[r].x), ri = cur.f[r].y + (cur.t[r].y - cur.old[r].y);      // rest = framework + (sums[:,1] - sums[:,ij+1])
+                rs += cur.kf[r] * (rr * S.x + ri * S.y);
+                ss += cur.kf[r] * (S.x * S.x + S.y * S.y);
+            }
+            cur = nxt;
         }
     }
     // ---- single_contribution_vdw (energy.jl:407-427)
@@ -331,7 +375,7 @@ __global__ __launch_bounds__(MC_THREADS, MC_TRIAL_WAVES) void k_mc_trial(McView 
             }
         };
         if (!CELLS) {
-            for (int l = tid; l < v.natoms; l += MC_THREADS) pairs_with(v.atoms[l]);
+            for (int l = tid; l < v.natoms; l += MC_THREADS) pairs_with(l == tid ? A_first : v.atoms[l]);
         } else {
             // only the cells the cutoff spheres of the molecule's atoms can reach (ceg_consumers.h)
             if (tid < 3) ceg_consumers::cell_range(I, s_pos, m, tid, v.nb[tid], v.hfrac[tid], s_bin0[tid], s_nbin[tid]);
@@ -1154,6 +1198,7 @@ struct ceg_mc {
     std::vector<DevRule> h_rules;
     std::vector<int32_t> h_offset;
     std::vector<int32_t> h_kind;                 // kind per atom slot (host copy)
+    std::vector<double> h_charge;                // charge per kind (host copy)
     struct Compact { DevRule* d_rules = nullptr; int32_t* d_off = nullptr; void* d_fast = nullptr; int32_t nrules = 0; };
     std::map<std::vector<int32_t>, Compact> compact;
     // pinned, device-mapped staging for small batches; device scratch for large ones
@@ -1255,6 +1300,7 @@ extern "C" int ceg_mc_create(ceg_mc_t** handle, int32_t device, ceg_interp_t* co
     for (int64_t q = 0; q < nk; ++q) fw[q] = make_double2(sf_re[q], sf_im[q]);
     const size_t table_bytes = sizeof(DevRule) * dr.size() + sizeof(int32_t) * (size_t)(nt + 1);
     v.table_in_lds = table_bytes <= 32 * 1024 ? 1 : 0;
+    h->h_charge.assign(kind_charge, kind_charge + nkinds);
     bool ok = upload(&h->d_vdw, grids.data(), grids.size()) && upload(&h->d_charge, kind_charge, (size_t)nkinds) &&
               upload(&h->d_rules, dr.data(), dr.size()) && upload(&h->d_offset, rule_offset, (size_t)(nt + 1)) &&
               upload(&h->d_ijk, kvec_ijk, (size_t)(3 * nk)) && upload(&h->d_kf, kfactors, (size_t)nk) &&
@@ -1616,7 +1662,14 @@ int run_trial(ceg_mc* h, bool insert, int32_t molecule, const McMolecule& nm, in
     unsigned long long* flag = nullptr;
     // (only for the latency-bound small batches: with ~1000 workgroups the fences and the shared counter cost more than the wake-up)
     if (mapped && rows <= 64 && !getenv("CEG_HIP_MC_NO_POLL")) { flag = h->dm_flag; ++h->seq; }
-#define CEG_MC_LAUNCH(F, I, CL) hipLaunchKernelGGL((k_mc_trial<F, I, CL>), grid, block, lds, h->stream, v, molecule, nm, d_in, n, d_out, h->stride, h->d_done, flag, h->seq)
+    McLocal L{};
+    L.first = insert ? 0 : h->h_mol[molecule].x;
+    L.m = m;
+    for (int a = 0; a < m; ++a) {
+        L.kinds[a] = insert ? nm.kinds[a] : h->h_kind[(size_t)L.first + a];
+        L.q[a] = h->h_charge[(size_t)L.kinds[a]];
+    }
+#define CEG_MC_LAUNCH(F, I, CL) hipLaunchKernelGGL((k_mc_trial<F, I, CL>), grid, block, lds, h->stream, v, molecule, L, d_in, n, d_out, h->stride, h->d_done, flag, h->seq)
 #define CEG_MC_PICK(CL)                                                                       \
     do {                                                                                      \
         if (insert) { if (v.fast) CEG_MC_LAUNCH(true, true, CL); else CEG_MC_LAUNCH(false, true, CL); }   \
