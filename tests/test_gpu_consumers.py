@@ -710,6 +710,17 @@ def test_mc_neighbour_cells(hip_lib, oracle, forcefield, monkeypatch):
                 assert moved == {len(mols) - 1}
                 mols[j] = mols[-1]
                 mols.pop()
+            if step % 45 == 44:
+                # a batch large enough for the wave kernels (k_mcw_pairs_frac reads the FRACTIONAL copies of the atom and cell records that
+                # every update above must have kept current): against the Cartesian wave kernel on the same state
+                j = int(rng.integers(len(mols)))
+                ks, cur = mols[j]
+                trial = (rng.uniform(0, 1, (1500, 3)) @ mat.T)[:, None, :] + (cur - cur[0])[None]
+                rows = {name: h.trial(j, trial) for name, h in handles.items()}
+                compare(rows, ("wave batch", step))
+                monkeypatch.setenv("CEG_HIP_MC_FRAC", "0")
+                compare({"exhaustive": rows["exhaustive"], **{name + ", Cartesian": h.trial(j, trial) for name, h in handles.items()}}, ("wave batch, Cartesian", step), tol=1e-9)
+                monkeypatch.delenv("CEG_HIP_MC_FRAC")
         assert noracle >= 8
         _nb, cap1 = handles["cells 4 A"].cells()
         assert cap1 > cap0, (cap0, cap1)                               # the crowded spot outgrew the first capacity
