@@ -155,6 +155,9 @@ constexpr double CEG_R_EXACT2 = CEG_R_EXACT2_VALUE;     // pairs closer than thi
 constexpr int CEG_EW2_LOGM = 5;
 constexpr int CEG_EW2_SHIFT = 20 - CEG_EW2_LOGM;               // bits of the high word below the interval key
 constexpr int CEG_EW2_STRIDE = 14;                             // doubles per interval record
+#ifndef CEG_EW2_LDS_STRIDE
+#define CEG_EW2_LDS_STRIDE 14                                   // LDS stride of the record in the single-probe kernels (15: see k_culled)
+#endif
 constexpr int CEG_EW2_NI_MAX = 176;                            // cutoff 12 A from r_exact 2 A: 165 intervals
 // Single Buckingham class: G0(s)/C = (A/C) exp(-B sqrt(s)) on the SAME intervals as the Ewald pair (one key and one t per
 // candidate serve both tables), one degree-7 polynomial per interval (64 B).  Round 2 used degree 5 on 64 intervals per octave

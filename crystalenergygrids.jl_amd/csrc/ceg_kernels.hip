@@ -592,7 +592,12 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK, NP), culled_waves(M
     __shared__ int32_t s_rowprefix_all[NW][66];
     __shared__ unsigned long long s_odd_all[NW][64];
     __shared__ __attribute__((aligned(16))) double s_erfcx[EW2 ? 2 : ERFCX_TAB_N * 6];
-    __shared__ __attribute__((aligned(16))) double s_ew2[EW2 ? CEG_EW2_NI_MAX * CEG_EW2_STRIDE : 2];
+    // LDS stride of an Ewald interval record, in doubles: the 14 of the table as it is built (112 B = 28 banks: lanes whose intervals are 16
+    // apart meet in the same banks, and a wave spans 10-40 intervals -- 30 % of the LDS-active cycles of the fused kernel were conflict
+    // cycles) or 15 (120 B = 30 banks: 32 intervals apart; the record is then read as 8-byte pairs).  Single-probe
+    // variants only: the multi-probe variants have no 1.4 KB of LDS to spare.
+    constexpr int EW2_LS = (NP == 1) ? CEG_EW2_LDS_STRIDE : CEG_EW2_STRIDE;
+    __shared__ __attribute__((aligned(16))) double s_ew2[EW2 ? CEG_EW2_NI_MAX * EW2_LS : 2];
     __shared__ __attribute__((aligned(16))) double s_bk2[BK2 ? CEG_BK2_NI_MAX * CEG_BK2_STRIDE : 2];
     __shared__ double s_exp2[64];
     __shared__ int32_t s_org[NW][4];             // tile origins for the output transpose (grid mode)
@@ -606,7 +611,7 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK, NP), culled_waves(M
     constexpr bool FASTVDW = VDWK != 0;
     if (EW2) {
         const int nt = pc->ew2_ni * CEG_EW2_STRIDE;
-        for (int t = threadIdx.x; t < nt; t += WG) s_ew2[t] = pc->ew2_tab[t];
+        for (int t = threadIdx.x; t < nt; t += WG) s_ew2[(t / CEG_EW2_STRIDE) * EW2_LS + t % CEG_EW2_STRIDE] = pc->ew2_tab[t];
     } else if (FASTEW && MODE != MODE_VDW) {
         for (int t = threadIdx.x; t < ERFCX_TAB_N * 6; t += WG) s_erfcx[t] = pc->erfcx_tab[t];
     }
@@ -716,8 +721,8 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK, NP), culled_waves(M
     const int hi_cut = __builtin_amdgcn_readfirstlane(__double2hiint(cut_hi));
     const double int_lo = uniform(r_exact2 * (1.0 + 4e-6)), int_hi = uniform(reg_hi * (1.0 - 4e-6));
     // r^2-indexed tables: record of the interval with key k starts at s_ew2 + (k - ew2_base) * STRIDE
-    const int ew2_off = EW2 ? __builtin_amdgcn_readfirstlane(-pc->ew2_base * (CEG_EW2_STRIDE * 8)) : 0;
-    int ew2_stride = CEG_EW2_STRIDE * 8;              // kept in a VGPR: v_mad_u32_u24 reads one scalar operand (ew2_off)
+    const int ew2_off = EW2 ? __builtin_amdgcn_readfirstlane(-pc->ew2_base * (EW2_LS * 8)) : 0;
+    int ew2_stride = EW2_LS * 8;              // kept in a VGPR: v_mad_u32_u24 reads one scalar operand (ew2_off)
     asm volatile("" : "+v"(ew2_stride));
     const double ew_k3 = pc->ew_k3, ew_k15 = pc->ew_k15;       // 2 alpha^2 / 3, 4 alpha^4 / 15
     const bool all_simple = __builtin_amdgcn_readfirstlane(pc->all_simple) != 0;
@@ -1028,9 +1033,17 @@ __global__ __launch_bounds__(64 * culled_nw(MODE, VDWK, EWK, NP), culled_waves(M
                         //   B0 = erfc(alpha r)/r,  C = (2 alpha/sqrt(pi)) exp(-alpha^2 s),
                         //   B1 = (B0 + C)/s,  B2 = (3 B1 + 2 alpha^2 C)/s,  B3 = (5 B2 + 4 alpha^4 C)/s
                         //   v = q B0,  p1 = -q B1,  p2 = q B2,  p3 = -q B3
-                        const double2* rec = reinterpret_cast<const double2*>(
-                            reinterpret_cast<const char*>(s_ew2) + mad_u24(key, ew2_stride, ew2_off));
-                        const double2 a01 = rec[0], a23 = rec[1], a45 = rec[2], a6c0 = rec[3], c12 = rec[4], c34 = rec[5], c56 = rec[6];
+                        const char* recp = reinterpret_cast<const char*>(s_ew2) + mad_u24(key, ew2_stride, ew2_off);
+                        double2 a01, a23, a45, a6c0, c12, c34, c56;
+                        if (EW2_LS % 2 == 0) {
+                            const double2* rec = reinterpret_cast<const double2*>(recp);
+                            a01 = rec[0]; a23 = rec[1]; a45 = rec[2]; a6c0 = rec[3]; c12 = rec[4]; c34 = rec[5]; c56 = rec[6];
+                        } else {                                            // 8-byte aligned records
+                            const double* rec = reinterpret_cast<const double*>(recp);
+                            a01 = make_double2(rec[0], rec[1]); a23 = make_double2(rec[2], rec[3]); a45 = make_double2(rec[4], rec[5]);
+                            a6c0 = make_double2(rec[6], rec[7]); c12 = make_double2(rec[8], rec[9]); c34 = make_double2(rec[10], rec[11]);
+                            c56 = make_double2(rec[12], rec[13]);
+                        }
                         double b0 = __builtin_fma(a6c0.x, t, a45.y);
                         double cc = __builtin_fma(c56.y, t, c56.x);
                         b0 = __builtin_fma(b0, t, a45.x);
