@@ -821,10 +821,10 @@ __global__ __launch_bounds__(64 * MCW_WAVES, CEG_PAIRFRAC_WAVES) void k_mcw_pair
     const int m = MM > 0 ? MM : (insert ? nm.m : v.mol[molecule].y);
     ceg_pairfrac::FracWave<MM, TRI> w;
     {
-        ceg_pairfrac::PairFast* fastrec; DevRule* rules; int32_t* offset;
-        ceg_pairfrac::stage(s_raw, tab, v.mat, s_mat, tid, 64 * MCW_WAVES, fastrec, rules, offset);
+        ceg_pairfrac::PairFast* fastrec; DevRule* rules; int32_t* offset; const double* etab;
+        ceg_pairfrac::stage(s_raw, tab, v.mat, s_mat, tid, 64 * MCW_WAVES, fastrec, rules, offset, etab);
         __syncthreads();
-        w.fastrec = fastrec; w.rules = rules; w.offset = offset;
+        w.fastrec = fastrec; w.rules = rules; w.offset = offset; w.etab = etab; w.ebase = tab.ebase; w.eni = tab.eni;
     }
     w.s_mat = s_mat; w.t3 = s_trial[wave]; w.ft = s_ft[wave]; w.hq = s_q[wave];
     w.frac = CELLS ? v.fcells : v.fatoms;
@@ -1199,6 +1199,8 @@ struct ceg_mc {
     std::vector<int32_t> h_offset;
     std::vector<int32_t> h_kind;                 // kind per atom slot (host copy)
     std::vector<double> h_charge;                // charge per kind (host copy)
+    double* d_etab = nullptr;                    // erfc(alpha r)/r records of ceg_pairfrac.h (CoulombEwaldDirect rules sharing one alpha)
+    int32_t ebase = 0, eni = 0;
     struct Compact { DevRule* d_rules = nullptr; int32_t* d_off = nullptr; void* d_fast = nullptr; int32_t nrules = 0; };
     std::map<std::vector<int32_t>, Compact> compact;
     // pinned, device-mapped staging for small batches; device scratch for large ones
@@ -1306,6 +1308,19 @@ extern "C" int ceg_mc_create(ceg_mc_t** handle, int32_t device, ceg_interp_t* co
               upload(&h->d_ijk, kvec_ijk, (size_t)(3 * nk)) && upload(&h->d_kf, kfactors, (size_t)nk) &&
               upload(&h->d_fw, fw.data(), (size_t)nk) && upload(&h->d_tot, fw.data(), (size_t)nk);
     ok = ok && hipMemset(h->d_tot, 0, sizeof(double2) * (size_t)(nk > 0 ? nk : 1)) == hipSuccess;
+    if (ok && v.fast) {   // the r^2-indexed erfc(alpha r)/r records of the fractional-coordinate pair kernel (ceg_pairfrac.h)
+        double alpha = 0.0;
+        bool shared = true;
+        for (const DevRule& R : dr)
+            if (R.kind == CEG_COULOMB_EWALD_DIRECT) {
+                if (alpha == 0.0) alpha = R.p0;
+                else if (alpha != R.p0) shared = false;
+            }
+        ceg_pairfrac::ErfcTable et;
+        if (shared && alpha > 0.0 && cutoff2 > 1.0 && ceg_pairfrac::build_erfc_table(alpha, 1.0, cutoff2, et) && upload(&h->d_etab, et.rec.data(), et.rec.size())) {
+            h->ebase = et.base; h->eni = et.ni;
+        }
+    }
     {
         const ceg_rows::Layout lay = ceg_rows::choose_layout(kvec_ijk, nk, nk > 0 ? ks : v.ks);
         std::vector<int32_t> qof((size_t)std::max(lay.ns, 1) * 64, -1);
@@ -1360,7 +1375,7 @@ extern "C" int ceg_mc_destroy(ceg_mc_t* h)
     if (guard.ok) {
         if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
         for (void* p : {(void*)h->d_vdw, (void*)h->d_charge, (void*)h->d_rules, (void*)h->d_offset, (void*)h->d_ijk, (void*)h->d_kf,
-                        (void*)h->d_fw, (void*)h->d_tot, (void*)h->d_mol, (void*)h->d_atoms, (void*)h->d_molidx, (void*)h->d_in, (void*)h->d_out, (void*)h->d_cells, (void*)h->d_cell_count})
+                        (void*)h->d_fw, (void*)h->d_tot, (void*)h->d_mol, (void*)h->d_atoms, (void*)h->d_molidx, (void*)h->d_in, (void*)h->d_out, (void*)h->d_cells, (void*)h->d_cell_count, (void*)h->d_etab})
             if (p) (void)hipFree(p);
         if (h->h_in) (void)hipHostFree(h->h_in);
         if (h->h_out) (void)hipHostFree(h->h_out);
@@ -1562,10 +1577,10 @@ int launch_wave_kernels(ceg_mc* h, bool insert, int32_t molecule, const McMolecu
                       (!v.use_cells || (int64_t)v.nb[0] * v.nb[1] * v.nb[2] * v.cell_cap < (1 << 27));      // (atom index << 4 | trial atom in 32 bits)
     if (const char* e = std::getenv("CEG_HIP_MC_FRAC")) frac_pairs = frac_pairs && std::atoi(e) != 0;          // measurement aid: 0 = the Cartesian kernel
     const int nentries = v.nkinds * m;
-    const size_t ftab_bytes = ceg_pairfrac::frac_table_bytes(nentries, ctab->nrules);
+    const size_t ftab_bytes = ceg_pairfrac::frac_table_bytes(nentries, ctab->nrules, h->eni);
     if (ftab_bytes + sizeof(ceg_pairfrac::FracHit) * ceg_pairfrac::FQCAP * MCW_WAVES + 4096 > 60 * 1024) frac_pairs = false;
     if (frac_pairs) {
-        const ceg_pairfrac::FracTable ftab{static_cast<const McFastPair*>(ctab->d_fast), ctab->d_rules, ctab->d_off, ctab->nrules, nentries};
+        const ceg_pairfrac::FracTable ftab{static_cast<const McFastPair*>(ctab->d_fast), ctab->d_rules, ctab->d_off, ctab->nrules, nentries, h->d_etab, h->ebase, h->eni};
         const int per_wave = rows_per_wave(rows, MCW_WAVES, 8);
         const int64_t nb = (rows + (int64_t)MCW_WAVES * per_wave - 1) / ((int64_t)MCW_WAVES * per_wave);
 #define CEG_MCW_F(MMv, CL, TR) hipLaunchKernelGGL((k_mcw_pairs_frac<MMv, CL, TR>), dim3((unsigned)nb), dim3(64 * MCW_WAVES), ftab_bytes, h->stream, v, ftab, molecule, insert ? 1 : 0, nm, d_in, rows, d_out, per_wave)

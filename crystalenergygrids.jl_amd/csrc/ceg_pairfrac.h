@@ -15,8 +15,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <type_traits>
+#include <vector>
 
 #include "ceg_internal.h"
 #include "ceg_math.h"
@@ -52,10 +55,104 @@ struct FracTable {
     const DevRule* rules;      // [nrules]
     const int32_t* off;        // [nkinds * m + 1]
     int32_t nrules, nentries;
+    // erfc(alpha r)/r of the CoulombEwaldDirect terms as a function of s = r^2 (ErfcTable below): [eni][8] doubles, nullptr / 0 when the
+    // entries do not share one alpha (the records then take exp(-x^2) erfcx(x) by the polynomials of ceg_math.h)
+    const double* etab;
+    int32_t ebase, eni;
 };
-__host__ __device__ inline size_t frac_table_bytes(int nentries, int nrules)
+__host__ __device__ inline size_t frac_table_bytes(int nentries, int nrules, int eni = 0)
 {
-    return sizeof(PairFast) * (size_t)nentries + sizeof(DevRule) * (size_t)(nrules > 0 ? nrules : 1) + sizeof(int32_t) * ((size_t)nentries + 1);
+    const size_t b = sizeof(PairFast) * (size_t)nentries + sizeof(DevRule) * (size_t)(nrules > 0 ? nrules : 1) + sizeof(int32_t) * ((size_t)nentries + 1);
+    return ((b + 15) & ~(size_t)15) + sizeof(double) * 8 * (size_t)eni;
+}
+
+// ---- erfc(alpha sqrt(s))/sqrt(s) on [s_min, s_max] for the rule arithmetic of the queue: intervals whose key is the exponent and the top
+// five mantissa bits of s (32 per octave: clearing the low bits of s gives the interval's lower end), per interval the degree-6 interpolant
+// at the Chebyshev nodes in t = s - s_lo, fitted in long double (the construction of the grid kernels' r^2-indexed tables, csrc/ceg_api.hip).
+// One record = 8 doubles (a0 ... a6, pad): four 16-byte LDS reads and six FMAs replace square root, reciprocal square root, exp and the
+// erfcx polynomial (~60 instructions per queued pair).  Checked here against erfcl at 17 points per interval with the kernel's Horner
+// form: used only if every error is below 1e-13 of the value + 1e-15 of the function at s_min (towards the cutoff erfc has decayed by
+// five and more decades and the degree-6 fit holds ~1e-11 of those values: 1e-16 of the terms that make up the sum).
+constexpr int ERFC_SHIFT = 15;                  // bits of the high word below the interval key
+struct ErfcTable {
+    std::vector<double> rec;                    // [ni][8]
+    int32_t base = 0, ni = 0;
+    double worst = 0.0;
+};
+inline bool build_erfc_table(double alpha, double s_min, double s_max, ErfcTable& out)
+{
+    auto key_of = [](double s) { uint64_t b; memcpy(&b, &s, 8); return (int32_t)((uint32_t)(b >> 32) >> ERFC_SHIFT); };
+    out = ErfcTable{};
+    if (!(alpha > 0.0) || !(s_min > 0.0) || !(s_max > s_min) || !std::isfinite(s_max)) return false;
+    const int32_t base = key_of(s_min), last = key_of(s_max * (1.0 + 4e-9));
+    const int32_t ni = last - base + 1;
+    if (ni < 1 || ni > 512) return false;
+    constexpr int ND = 7;
+    const long double PI = 3.14159265358979323846264338327950288L, a = alpha;
+    long double node[ND];
+    for (int k = 0; k < ND; ++k) node[k] = cosl(PI * (k + 0.5L) / (long double)ND);
+    auto B0 = [&](long double s) { const long double r = sqrtl(s); return erfcl(a * r) / r; };
+    out.rec.assign((size_t)ni * 8, 0.0);
+    const long double top = B0((long double)s_min);
+    double worst = 0.0;
+    for (int32_t i = 0; i < ni; ++i) {
+        const uint64_t lo_bits = (uint64_t)(uint32_t)((base + i) << ERFC_SHIFT) << 32;
+        const uint64_t hi_bits = (uint64_t)(uint32_t)((base + i + 1) << ERFC_SHIFT) << 32;
+        double s_lo, s_hi;
+        memcpy(&s_lo, &lo_bits, 8); memcpy(&s_hi, &hi_bits, 8);
+        const long double hh = 0.5L * ((long double)s_hi - (long double)s_lo), s_mid = (long double)s_lo + hh;
+        long double V[ND][ND + 1];
+        for (int r = 0; r < ND; ++r) {
+            long double pw = 1.0L;
+            for (int c = 0; c < ND; ++c) { V[r][c] = pw; pw *= node[r]; }
+            V[r][ND] = B0(s_mid + node[r] * hh);
+        }
+        for (int c = 0; c < ND; ++c) {                      // Gauss-Jordan with partial pivoting
+            int piv = c;
+            for (int r = c + 1; r < ND; ++r) if (fabsl(V[r][c]) > fabsl(V[piv][c])) piv = r;
+            for (int q = 0; q <= ND; ++q) { const long double tmp = V[c][q]; V[c][q] = V[piv][q]; V[piv][q] = tmp; }
+            const long double d = V[c][c];
+            for (int q = 0; q <= ND; ++q) V[c][q] /= d;
+            for (int r = 0; r < ND; ++r) if (r != c) {
+                const long double g = V[r][c];
+                for (int q = 0; q <= ND; ++q) V[r][q] -= g * V[c][q];
+            }
+        }
+        // P(u), u = (t - hh)/hh with t = s - s_lo  ->  coefficients in t
+        long double cu[ND], ct[ND] = {0, 0, 0, 0, 0, 0, 0};
+        long double sc = 1.0L;
+        for (int c = 0; c < ND; ++c) { cu[c] = V[c][ND] * sc; sc /= hh; }
+        for (int c = 0; c < ND; ++c) {
+            long double binom = 1.0L;
+            for (int k = 0; k <= c; ++k) {
+                ct[k] += cu[c] * binom * powl(-hh, c - k);
+                binom = binom * (c - k) / (k + 1);
+            }
+        }
+        double* co = &out.rec[(size_t)i * 8];
+        for (int c = 0; c < ND; ++c) co[c] = (double)ct[c];
+        for (int q = 0; q <= 16; ++q) {
+            const double t = (double)(((long double)q / 16.0L) * 2.0L * hh * (1.0L - 1e-12L));
+            double pv = co[ND - 1];
+            for (int c = ND - 2; c >= 0; --c) pv = std::fma(pv, t, co[c]);
+            const long double ref = B0((long double)s_lo + (long double)t);
+            worst = std::fmax(worst, (double)(fabsl((long double)pv - ref) / (fabsl(ref) + 1e-2L * top)));
+        }
+    }
+    out.base = base; out.ni = ni; out.worst = worst;
+    if (!(worst < 1e-13)) { out.rec.clear(); out.ni = 0; return false; }
+    return true;
+}
+// the alpha the CoulombEwaldDirect terms of the records share (0: none or several)
+inline double shared_alpha(const PairFast* fast, size_t n)
+{
+    double alpha = 0.0;
+    for (size_t i = 0; i < n; ++i)
+        if (fast[i].cls && fast[i].qq != 0.0) {
+            if (alpha == 0.0) alpha = fast[i].alpha;
+            else if (alpha != fast[i].alpha) return 0.0;
+        }
+    return alpha;
 }
 
 // host: the record of one pair-table entry (rules [q0, q1) of `rules`); `walked` rules of other kinds make it cls = 0
@@ -83,11 +180,14 @@ __device__ __attribute__((noinline)) inline double rule_energy_call(const DevRul
 
 // the workgroup copies the table into LDS (the caller synchronises); mat12 <- mat[9], -mat * (1/2, 1/2, 1/2)
 __device__ __forceinline__ void stage(unsigned char* s_table, const FracTable& tab, const double* mat, double* mat12, int tid, int nthreads,
-                                      PairFast*& fastrec, DevRule*& rules, int32_t*& offset)
+                                      PairFast*& fastrec, DevRule*& rules, int32_t*& offset, const double*& etab)
 {
     fastrec = reinterpret_cast<PairFast*>(s_table);
     rules = reinterpret_cast<DevRule*>(fastrec + tab.nentries);
     offset = reinterpret_cast<int32_t*>(rules + (tab.nrules > 0 ? tab.nrules : 1));
+    double* et = reinterpret_cast<double*>(s_table + frac_table_bytes(tab.nentries, tab.nrules, 0));
+    etab = et;
+    for (int t = tid; t < 8 * tab.eni; t += nthreads) et[t] = tab.etab[t];
     for (int t = tid; t < tab.nentries; t += nthreads) fastrec[t] = tab.fast[t];
     for (int t = tid; t < tab.nrules; t += nthreads) rules[t] = tab.rules[t];
     for (int t = tid; t <= tab.nentries; t += nthreads) offset[t] = tab.off[t];
@@ -101,6 +201,8 @@ struct FracWave {
     const PairFast* fastrec;       // LDS: the staged table
     const DevRule* rules;
     const int32_t* offset;
+    const double* etab;            // LDS: erfc(alpha r)/r records (eni > 0), key of the first one
+    int32_t ebase, eni;
     const double* s_mat;           // LDS: stage()'s mat12
     double* t3;                    // LDS of this wave: Cartesian positions of the trial atoms [3 m] (band, cell range)
     double* ft;                    // LDS of this wave: their fractional coordinates + 1/2
@@ -145,7 +247,25 @@ struct FracWave {
                 r2 = ceg_consumers::pair_distance2_literal_call(geom, t3[3 * a] - A.x, t3[3 * a + 1] - A.y, t3[3 * a + 2] - A.z);
                 if (!(r2 < cutoff2)) continue;                           // energy.jl:422
             }
-            if (r2 >= 0.25) {
+            if (eni > 0 && r2 >= 1.0 && fastrec[t].cls) {
+                // Lennard-Jones + erfc(alpha r)/r from the r^2-indexed records: no square root, no exp, no erfcx
+                const PairFast P = fastrec[t];
+                const int hi = __double2hiint(r2);
+                const double tt = r2 - __hiloint2double(hi & (int)(0xffffffffu << ERFC_SHIFT), 0);
+                const double2* rec = reinterpret_cast<const double2*>(etab + 8 * (size_t)(((unsigned)hi >> ERFC_SHIFT) - (unsigned)ebase));
+                const double2 a01 = rec[0], a23 = rec[1], a45 = rec[2], a6 = rec[3];
+                double b0 = __builtin_fma(a6.x, tt, a45.y);
+                b0 = __builtin_fma(b0, tt, a45.x);
+                b0 = __builtin_fma(b0, tt, a23.y);
+                b0 = __builtin_fma(b0, tt, a23.x);
+                b0 = __builtin_fma(b0, tt, a01.y);
+                b0 = __builtin_fma(b0, tt, a01.x);
+                const double q2 = P.sigma2 * ceg::fast_rcp(r2);
+                const double x6 = q2 * q2 * q2;
+                double v = __builtin_fma(P.c4eps * x6, x6 - 1.0, -P.shift);
+                v = __builtin_fma(P.qq, b0, v);
+                e += v;
+            } else if (r2 >= 0.25) {
                 double r, rinv;
                 ceg::fast_sqrt_rsqrt(r2, r, rinv);
                 const PairFast P = fastrec[t];

@@ -246,10 +246,10 @@ __global__ __launch_bounds__(64 * PAIRS_WAVES, CEG_PAIRFRAC_WAVES) void k_pairs_
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     ceg_pairfrac::FracWave<MM, TRI> w;
     {
-        PairFast* fastrec; DevRule* rules; int32_t* offset;
-        ceg_pairfrac::stage(s_table, tab, g.mat, s_mat, threadIdx.x, 64 * PAIRS_WAVES, fastrec, rules, offset);
+        PairFast* fastrec; DevRule* rules; int32_t* offset; const double* etab;
+        ceg_pairfrac::stage(s_table, tab, g.mat, s_mat, threadIdx.x, 64 * PAIRS_WAVES, fastrec, rules, offset, etab);
         __syncthreads();
-        w.fastrec = fastrec; w.rules = rules; w.offset = offset;
+        w.fastrec = fastrec; w.rules = rules; w.offset = offset; w.etab = etab; w.ebase = tab.ebase; w.eni = tab.eni;
     }
     w.s_mat = s_mat; w.t3 = s_trial[wave]; w.ft = s_ft[wave]; w.hq = s_q[wave];
     w.frac = frac; w.cart = atoms; w.geom = g.geom;
@@ -344,6 +344,8 @@ struct ceg_pairs {
     std::vector<int32_t> h_offset;
     struct Compact { PairFast* d_fast = nullptr; DevRule* d_rules = nullptr; int32_t* d_off = nullptr; int32_t nrules = 0, nentries = 0; };
     std::map<std::vector<int32_t>, Compact> compact;      // by the kinds of the molecule on trial
+    double* d_etab = nullptr;           // erfc(alpha r)/r records of ceg_pairfrac.h (when the CoulombEwaldDirect rules share one alpha)
+    int32_t ebase = 0, eni = 0;
     double4* d_atoms = nullptr;
     double4* d_frac = nullptr;          // invmat * position of the same atoms in the same order (k_pairs_frac)
     int64_t natoms = 0, cap = 0;
@@ -390,6 +392,25 @@ extern "C" int ceg_pairs_create(ceg_pairs_t** handle, int32_t device, const doub
     for (int a = 0; a < 9; ++a) { geom[a] = mat[a]; geom[9 + a] = invmat[a]; }
     h->h_rules = dr;
     h->h_offset.assign(rule_offset, rule_offset + nt + 1);
+    {   // the r^2-indexed erfc(alpha r)/r records of the fractional-coordinate kernel
+        double alpha = 0.0;
+        bool shared = true;
+        for (int32_t q = 0; q < nr; ++q)
+            if (dr[q].kind == CEG_COULOMB_EWALD_DIRECT) {
+                if (alpha == 0.0) alpha = dr[q].p0;
+                else if (alpha != dr[q].p0) shared = false;
+            }
+        ceg_pairfrac::ErfcTable et;
+        if (fast && shared && alpha > 0.0 && cutoff2 > 1.0 && ceg_pairfrac::build_erfc_table(alpha, 1.0, cutoff2, et)) {
+            if (hipMalloc((void**)&h->d_etab, et.rec.size() * sizeof(double)) == hipSuccess &&
+                hipMemcpy(h->d_etab, et.rec.data(), et.rec.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess) {
+                h->ebase = et.base; h->eni = et.ni;
+            } else {
+                (void)hipFree(h->d_etab);
+                h->d_etab = nullptr;
+            }
+        }
+    }
     bool ok = hipMalloc((void**)&h->d_rules, dr.size() * sizeof(DevRule)) == hipSuccess &&
               hipMalloc((void**)&h->d_offset, (size_t)(nt + 1) * sizeof(int32_t)) == hipSuccess &&
               hipMalloc((void**)&h->d_geom, sizeof geom) == hipSuccess &&
@@ -418,6 +439,7 @@ extern "C" int ceg_pairs_destroy(ceg_pairs_t* h)
         (void)hipFree(h->d_frac);
         (void)hipFree(h->d_cell_start);
         (void)hipFree(h->d_geom);
+        (void)hipFree(h->d_etab);
     }
     if (prev >= 0) (void)hipSetDevice(prev);
     delete h;
@@ -556,10 +578,10 @@ extern "C" int ceg_pairs_energy_device(ceg_pairs_t* h, const double* d_trial, co
         if (prev >= 0) (void)hipSetDevice(prev);
         return perr(CEG_ERR_HIP, "could not upload the pair-table rows of the molecule");
     }
-    const size_t ftab_bytes = ctab ? frac_table_bytes(ctab->nentries, ctab->nrules) : 0;
+    const size_t ftab_bytes = ctab ? frac_table_bytes(ctab->nentries, ctab->nrules, h->eni) : 0;
     use_frac = use_frac && ftab_bytes + sizeof(FracHit) * FQCAP * PAIRS_WAVES + 4096 <= 60 * 1024;
     if (use_frac) {
-        const FracTable ftab{ctab->d_fast, ctab->d_rules, ctab->d_off, ctab->nrules, ctab->nentries};
+        const FracTable ftab{ctab->d_fast, ctab->d_rules, ctab->d_off, ctab->nrules, ctab->nentries, h->d_etab, h->ebase, h->eni};
         // placements per wave: as many as leave >= 16 workgroups per CU (4096 on the chip)
         int per_wave = 1;
         if (const char* env = getenv("CEG_HIP_PAIRS_PER_WAVE")) per_wave = std::max(1, std::min(64, atoi(env)));

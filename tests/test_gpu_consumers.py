@@ -454,11 +454,13 @@ def test_mc_large_batches_take_the_wave_kernels(hip_lib, tmp_path, monkeypatch):
             monkeypatch.delenv("CEG_HIP_MC_WAVE_MIN")
             assert np.array_equal(split, group, equal_nan=True)    # the same arithmetic in the same order
             assert np.array_equal(np.abs(wave) >= 1e90, np.abs(group) >= 1e90)
-            for c in range(4):            # same terms in another order: 1e-10 of the value, floored at 1e-13 of the column's upper quartile
+            for c in range(4):            # same terms, another order (columns 0, 1, 3) / another arithmetic (column 2: fractional coordinates, tabulated
+                                          # erfc): 1e-10 of the value, floored at 1e-11 of the column's upper quartile
                 ok = (np.abs(group[:, c]) < 1e90) & np.isfinite(group[:, c])
                 scale = float(np.percentile(np.abs(group[ok, c]), 75)) if ok.any() else 0.0
                 err = np.abs(wave[ok, c] - group[ok, c])
-                assert (err <= 1e-10 * np.abs(group[ok, c]) + 1e-13 * scale + 1e-300).all(), (c, float(err.max()), scale)
+                bad = err > 1e-10 * np.abs(group[ok, c]) + 1e-11 * scale + 1e-300
+                assert not bad.any(), (c, float(err.max()), scale, wave[ok, c][bad][:4], group[ok, c][bad][:4])
             return wave
 
         n = 3000
