@@ -47,6 +47,11 @@ struct __attribute__((aligned(16))) FracHit {      // a queued candidate pair
     int32_t t, ia;                                 // pair-table index; atom index << 4 | trial atom (for the band around the cutoff)
 };
 
+// (erfc(alpha r)/r records, see ErfcTable below)
+constexpr int ERFC_SHIFT = 15;                  // bits of the high word below the interval key
+constexpr int ERFC_REC = 10;                    // doubles per record: a0 ... a6 + padding to 80 B = 5 x 16 B (an odd multiple of 16 B sends 16
+                                                // consecutive intervals to 16 different bank groups; at 64 B only four groups were in use)
+
 // The pair table as the kernels stage it in LDS -- only the entries (kind of a guest atom, trial atom a) the molecule on trial can meet,
 // entry kind * m + a: the PairFast records, then the rules of these entries (for those that are not one record), then their offsets.
 // (The whole table of the fixture force field -- 20 kinds: 26 KB -- beside the queue left room for two workgroups per CU only.)
@@ -55,27 +60,26 @@ struct FracTable {
     const DevRule* rules;      // [nrules]
     const int32_t* off;        // [nkinds * m + 1]
     int32_t nrules, nentries;
-    // erfc(alpha r)/r of the CoulombEwaldDirect terms as a function of s = r^2 (ErfcTable below): [eni][8] doubles, nullptr / 0 when the
+    // erfc(alpha r)/r of the CoulombEwaldDirect terms as a function of s = r^2 (ErfcTable below): [eni][ERFC_REC] doubles, nullptr / 0 when the
     // entries do not share one alpha (the records then take exp(-x^2) erfcx(x) by the polynomials of ceg_math.h)
-    const double* etab;
+    const double* etab;        // [eni][ERFC_REC]
     int32_t ebase, eni;
 };
 __host__ __device__ inline size_t frac_table_bytes(int nentries, int nrules, int eni = 0)
 {
     const size_t b = sizeof(PairFast) * (size_t)nentries + sizeof(DevRule) * (size_t)(nrules > 0 ? nrules : 1) + sizeof(int32_t) * ((size_t)nentries + 1);
-    return ((b + 15) & ~(size_t)15) + sizeof(double) * 8 * (size_t)eni;
+    return ((b + 15) & ~(size_t)15) + sizeof(double) * ERFC_REC * (size_t)eni;
 }
 
 // ---- erfc(alpha sqrt(s))/sqrt(s) on [s_min, s_max] for the rule arithmetic of the queue: intervals whose key is the exponent and the top
 // five mantissa bits of s (32 per octave: clearing the low bits of s gives the interval's lower end), per interval the degree-6 interpolant
 // at the Chebyshev nodes in t = s - s_lo, fitted in long double (the construction of the grid kernels' r^2-indexed tables, csrc/ceg_api.hip).
-// One record = 8 doubles (a0 ... a6, pad): four 16-byte LDS reads and six FMAs replace square root, reciprocal square root, exp and the
+// One record = ERFC_REC doubles (a0 ... a6, padding): four 16-byte LDS reads and six FMAs replace square root, reciprocal square root, exp and the
 // erfcx polynomial (~60 instructions per queued pair).  Checked here against erfcl at 17 points per interval with the kernel's Horner
 // form: used only if every error is below 1e-13 of the value + 1e-15 of the function at s_min (towards the cutoff erfc has decayed by
 // five and more decades and the degree-6 fit holds ~1e-11 of those values: 1e-16 of the terms that make up the sum).
-constexpr int ERFC_SHIFT = 15;                  // bits of the high word below the interval key
 struct ErfcTable {
-    std::vector<double> rec;                    // [ni][8]
+    std::vector<double> rec;                    // [ni][ERFC_REC]
     int32_t base = 0, ni = 0;
     double worst = 0.0;
 };
@@ -92,7 +96,7 @@ inline bool build_erfc_table(double alpha, double s_min, double s_max, ErfcTable
     long double node[ND];
     for (int k = 0; k < ND; ++k) node[k] = cosl(PI * (k + 0.5L) / (long double)ND);
     auto B0 = [&](long double s) { const long double r = sqrtl(s); return erfcl(a * r) / r; };
-    out.rec.assign((size_t)ni * 8, 0.0);
+    out.rec.assign((size_t)ni * ERFC_REC, 0.0);
     const long double top = B0((long double)s_min);
     double worst = 0.0;
     for (int32_t i = 0; i < ni; ++i) {
@@ -129,7 +133,7 @@ inline bool build_erfc_table(double alpha, double s_min, double s_max, ErfcTable
                 binom = binom * (c - k) / (k + 1);
             }
         }
-        double* co = &out.rec[(size_t)i * 8];
+        double* co = &out.rec[(size_t)i * ERFC_REC];
         for (int c = 0; c < ND; ++c) co[c] = (double)ct[c];
         for (int q = 0; q <= 16; ++q) {
             const double t = (double)(((long double)q / 16.0L) * 2.0L * hh * (1.0L - 1e-12L));
@@ -187,7 +191,7 @@ __device__ __forceinline__ void stage(unsigned char* s_table, const FracTable& t
     offset = reinterpret_cast<int32_t*>(rules + (tab.nrules > 0 ? tab.nrules : 1));
     double* et = reinterpret_cast<double*>(s_table + frac_table_bytes(tab.nentries, tab.nrules, 0));
     etab = et;
-    for (int t = tid; t < 8 * tab.eni; t += nthreads) et[t] = tab.etab[t];
+    for (int t = tid; t < ERFC_REC * tab.eni; t += nthreads) et[t] = tab.etab[t];
     for (int t = tid; t < tab.nentries; t += nthreads) fastrec[t] = tab.fast[t];
     for (int t = tid; t < tab.nrules; t += nthreads) rules[t] = tab.rules[t];
     for (int t = tid; t <= tab.nentries; t += nthreads) offset[t] = tab.off[t];
@@ -252,7 +256,7 @@ struct FracWave {
                 const PairFast P = fastrec[t];
                 const int hi = __double2hiint(r2);
                 const double tt = r2 - __hiloint2double(hi & (int)(0xffffffffu << ERFC_SHIFT), 0);
-                const double2* rec = reinterpret_cast<const double2*>(etab + 8 * (size_t)(((unsigned)hi >> ERFC_SHIFT) - (unsigned)ebase));
+                const double2* rec = reinterpret_cast<const double2*>(etab + ERFC_REC * (size_t)(((unsigned)hi >> ERFC_SHIFT) - (unsigned)ebase));
                 const double2 a01 = rec[0], a23 = rec[1], a45 = rec[2], a6 = rec[3];
                 double b0 = __builtin_fma(a6.x, tt, a45.y);
                 b0 = __builtin_fma(b0, tt, a45.x);
