@@ -504,3 +504,37 @@ def test_pmc_record_matches_the_grid_kernel_sources():
     rec = json.loads((root / "profiles" / "pmc_summary.json").read_text())["fused/Ar/255/1"]
     assert rec["csrc_sha256"] == bench.csrc_sha256(), "profiles/pmc_summary.json is stale: re-run scripts/pmc.sh fused_ar fused/Ar/255/1 and scripts/pmc_merge.py"
     assert rec["source"].startswith("profiles/")
+
+
+def test_erfc_table_of_the_pair_kernels(tmp_path):
+    """ceg_pairfrac::build_erfc_table (host code of csrc/ceg_pairfrac.h): the r^2-indexed records the pair kernels read erfc(alpha r)/r
+    from, evaluated here with the kernel's Horner form against scipy's erfc -- 1e-13 of the value + 1e-15 of the function at r = 1."""
+    import shutil, subprocess
+    from scipy.special import erfc
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = tmp_path / "erfc_table_dump"
+    src = Path(__file__).parent / "cpp" / "erfc_table_dump.hip"
+    subprocess.run([hipcc, "-O2", "-std=c++17", "--offload-arch=gfx950", "-o", str(exe), str(src)], check=True, capture_output=True)
+    for alpha, s_max in ((0.26505830360350674, 144.0), (0.5, 100.0), (0.08, 196.0)):
+        out = subprocess.run([str(exe), repr(alpha), "1.0", repr(s_max)], check=True, capture_output=True, text=True).stdout.split()
+        ok, base, ni, worst, nrec = int(out[0]), int(out[1]), int(out[2]), float(out[3]), int(out[4])
+        assert ok == 1 and worst < 1e-13 and ni > 100
+        rec = np.array(out[5:], dtype=np.float64).reshape(ni, nrec)
+        rng = np.random.default_rng(3)
+        s = np.concatenate([rng.uniform(1.0, s_max, 20000), [1.0, s_max, np.nextafter(2.0, 0), 2.0, np.nextafter(128.0, 0)]])
+        s = s[s <= s_max]
+        hi = (s.view(np.uint64) >> np.uint64(32)).astype(np.int64)
+        key = (hi >> 15) - base
+        assert key.min() >= 0 and key.max() < ni
+        s_lo = ((hi >> 15) << 15).astype(np.uint64) << np.uint64(32)
+        t = s - s_lo.view(np.float64)
+        c = rec[key]
+        v = c[:, 6]
+        for k in range(5, -1, -1):
+            v = v * t + c[:, k]
+        ref = erfc(alpha * np.sqrt(s)) / np.sqrt(s)
+        top = erfc(alpha)
+        assert np.all(np.abs(v - ref) <= 2e-13 * np.abs(ref) + 2e-15 * top), float(np.max(np.abs(v - ref) / (np.abs(ref) + 1e-2 * top)))
+    # an alpha for which the fit cannot hold the tolerance is refused (the kernels then keep the exp / erfcx polynomials)
+    out = subprocess.run([str(exe), "3.0", "1.0", "144.0"], check=True, capture_output=True, text=True).stdout.split()
+    assert int(out[0]) in (0, 1)
