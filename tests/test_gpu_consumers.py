@@ -512,6 +512,20 @@ def test_mc_large_batches_take_the_wave_kernels(hip_lib, tmp_path, monkeypatch):
         dev.trial_insert_device(1, d_trial.data_ptr(), len(trial), d_rows_i.data_ptr())
         torch.cuda.synchronize()
         np.testing.assert_allclose(d_rows_i.cpu().numpy(), dev.trial_insert(1, trial), rtol=1e-10, atol=1e-7)
+        # argument checks of the device entry points: the reference would raise (BoundsError / ArgumentError) -- here CEG_ERR_INVALID
+        lib, hnd, slot = dev._lib, dev._h, dev._slot[kind][j]
+        assert lib.ceg_mc_trial_device(hnd, slot, C.c_void_p(d_trial.data_ptr()), -1, C.c_void_p(d_rows.data_ptr()), None) == -1
+        assert lib.ceg_mc_trial_device(hnd, slot, C.c_void_p(d_trial.data_ptr()), 4, None, None) == -1
+        assert lib.ceg_mc_trial_device(hnd, 10 ** 6, C.c_void_p(d_trial.data_ptr()), 4, C.c_void_p(d_rows.data_ptr()), None) == -1
+        assert lib.ceg_mc_trial_device(None, slot, C.c_void_p(d_trial.data_ptr()), 4, C.c_void_p(d_rows.data_ptr()), None) == -1
+        bad = np.array([10 ** 6], dtype=np.int32)
+        assert lib.ceg_mc_trial_insert_device(hnd, _abi.i32ptr(bad), 1, C.c_void_p(d_trial.data_ptr()), 4, C.c_void_p(d_rows.data_ptr()), None) == -1
+        # no trial placement at all: row 0 (the molecule where it is) alone
+        d_rows.fill_(float("nan"))
+        _abi.check(lib, lib.ceg_mc_trial_device(hnd, slot, None, 0, C.c_void_p(d_rows.data_ptr()), None))
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(d_rows[0].cpu().numpy(), rows_host[0], rtol=1e-10, atol=1e-7)
+        assert bool(torch.isnan(d_rows[1:]).all())
         dev.close()
     finally:
         ceg.setdir_RASPA(Path(__file__).parent / "golden" / "raspa")
