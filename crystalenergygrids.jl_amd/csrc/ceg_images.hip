@@ -4,7 +4,7 @@
 // (the grid's bounding box grown by the cutoff), bins them on a cartesian lattice and sorts them by bin -- the host-side analogue of
 // the reference's ProbeSystem tiling (src/probes.jl:37-53).  On the host that is 1.0-1.4 ms for the 11 664-atom roofline framework:
 // the whole compute of one rank at N = 8, paid by the FIRST call on a framework (later calls hit the image cache).  Here the same
-// list comes out of five launches on arrays that are already on the device:
+// list comes out of a few launches on arrays that are already on the device (first form; the lean form further down is the default):
 //   k_img_count   per atom: how many of its images fall into the box (the fractional hull of the box corners bounds the lattice loop);
 //   exclusive scan of the counts (hipcub);
 //   k_img_emit    per atom: its images in lattice order at the atom's offset -- the order the host loop emits them in;
@@ -15,7 +15,10 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <chrono>
 #include <cstdint>
+#include <cstdlib>
+#include <initializer_list>
 
 #include "ceg_internal.h"
 
@@ -148,6 +151,128 @@ __global__ void k_bin_start(const int32_t* __restrict__ sorted_bin, int32_t n, i
     bin_start[b] = lo;
 }
 
+// ---- the lean form of the same build: at 11 664 atoms every kernel is a few microseconds, and what the first form spends is launches
+// (thirteen), two sleeps in hipStreamSynchronize and a radix sort of six passes.  Here the counting kernel also counts per BIN (atomics);
+// two exclusive scans (hipcub) give the offsets of the atoms' images in emit order and the starts of the bins (= the bin_start result);
+// the total reaches the host through a polled word of mapped memory; the emitting kernel claims a slot of its bin
+// per image (atomics: any order inside a bin) and records the emit index there; one thread per bin sorts its slots by emit index --
+// the order the host's stable counting sort leaves them in -- and gathers the records.  Byte-identical to the radix-sort form.
+__global__ void k_img_count_bins(ImgBox B, const double4* __restrict__ atoms, const int32_t* __restrict__ kind, const int32_t* __restrict__ has,
+                                 int64_t natoms, int32_t* __restrict__ count, int32_t* __restrict__ bin_count)
+{
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= natoms) return;
+    int n = 0;
+    if (img_atom_listed(B, kind, has, a)) {
+        const double4 A = atoms[a];
+        for_each_image(B, A.x, A.y, A.z, [&](double, double, double, int bin) {
+            ++n;
+            atomicAdd(&bin_count[bin], 1);
+        });
+    }
+    count[a] = n;
+}
+
+// total = offset[natoms] into page-locked host memory the host polls (a stream synchronisation that has gone to sleep wakes up tens of
+// microseconds late: more than every kernel of this build together)
+__global__ void k_img_publish(const int32_t* __restrict__ last_offset, volatile int32_t* __restrict__ mapped)
+{
+    mapped[0] = *last_offset;
+    __threadfence_system();
+    mapped[1] = 1;
+}
+
+__global__ void k_img_emit_slots(ImgBox B, const double4* __restrict__ atoms, const int32_t* __restrict__ kind, const int32_t* __restrict__ has,
+                                 int64_t natoms, const int32_t* __restrict__ offset, const int32_t* __restrict__ bin_start, int32_t* __restrict__ cursor,
+                                 double4* __restrict__ xyzq, int32_t* __restrict__ imgkind, int32_t* __restrict__ imgatom, int32_t* __restrict__ slot_emit)
+{
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= natoms) return;
+    if (!img_atom_listed(B, kind, has, a)) return;
+    const double4 A = atoms[a];
+    int32_t kw = -1;
+    if (B.has_rules) {
+        const int32_t k = kind[a];
+        kw = k < 0 ? -1 : (k | (img_kind_has_rule(B, has, k) ? (1 << 25) : 0));
+    }
+    const double q = B.has_charge ? A.w : 0.0;
+    int32_t at = offset[a];
+    for_each_image(B, A.x, A.y, A.z, [&](double x, double y, double z, int bin) {
+        xyzq[at] = make_double4(x, y, z, q);
+        imgkind[at] = kw;
+        imgatom[at] = (int32_t)a;
+        slot_emit[bin_start[bin] + atomicAdd(&cursor[bin], 1)] = at;
+        ++at;
+    });
+}
+
+// one thread per bin: its slots sorted by emit index (insertion sort: a bin holds a handful of images), records gathered
+__global__ void k_img_sort_gather(const int32_t* __restrict__ bin_start, int64_t nbins, int32_t* __restrict__ slot_emit, const double4* __restrict__ xyzq_in,
+                                  const int32_t* __restrict__ kind_in, const int32_t* __restrict__ atom_in, double4* __restrict__ xyzq,
+                                  int32_t* __restrict__ kind, int32_t* __restrict__ atom, unsigned* __restrict__ done, volatile int32_t* __restrict__ mapped)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int32_t s0 = b < nbins ? bin_start[b] : 0, s1 = b < nbins ? bin_start[b + 1] : 0;
+    for (int32_t i = s0 + 1; i < s1; ++i) {
+        const int32_t v = slot_emit[i];
+        int32_t j = i - 1;
+        while (j >= s0 && slot_emit[j] > v) { slot_emit[j + 1] = slot_emit[j]; --j; }
+        slot_emit[j + 1] = v;
+    }
+    for (int32_t i = s0; i < s1; ++i) {
+        const int32_t src = slot_emit[i];
+        xyzq[i] = xyzq_in[src];
+        kind[i] = kind_in[src];
+        atom[i] = atom_in[src];
+    }
+    // the last workgroup to finish raises the completion word the host polls
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(done, 1u) == gridDim.x - 1) {
+            __threadfence_system();
+            mapped[2] = 1;
+        }
+    }
+}
+
+// three words of page-locked, device-mapped host memory per thread (total, "total is there", "the build is complete"): the host polls
+// them instead of sleeping in hipStreamSynchronize (20 ms without the word: fall back to the stream, which also reports a failed launch)
+struct MappedWords {
+    volatile int32_t* h = nullptr;
+    int32_t* d = nullptr;
+    MappedWords()
+    {
+        struct Slot {
+            int32_t* h = nullptr;
+            int32_t* d = nullptr;
+            int device = -1;          // (64 bytes per thread, never freed: the HIP runtime may be gone when thread-local destructors run)
+        };
+        static thread_local Slot slot;
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) return;
+        if (slot.h && slot.device != dev) { (void)hipHostFree(slot.h); slot.h = nullptr; }
+        if (!slot.h) {
+            if (hipHostMalloc((void**)&slot.h, 64, hipHostMallocMapped) != hipSuccess) { slot.h = nullptr; return; }
+            if (hipHostGetDevicePointer((void**)&slot.d, slot.h, 0) != hipSuccess) { (void)hipHostFree(slot.h); slot.h = nullptr; return; }
+            slot.device = dev;
+        }
+        h = slot.h;
+        d = slot.d;
+    }
+    bool ok() const { return h != nullptr; }
+    bool wait(int word, hipStream_t st) const
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spin = 0;; ++spin) {
+            if (__atomic_load_n(const_cast<const int32_t*>(h) + word, __ATOMIC_ACQUIRE) == 1) return true;
+            if ((spin & 1023u) == 1023u && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 20.0) break;
+            __builtin_ia32_pause();
+        }
+        return hipStreamSynchronize(st) == hipSuccess && __atomic_load_n(const_cast<const int32_t*>(h) + word, __ATOMIC_ACQUIRE) == 1;
+    }
+};
+
 // Returns hipSuccess and the four arrays of an image set (allocated from the plan-table pool; the caller owns them), or an error with
 // nothing allocated.  d_kind: 0-based kind per atom or nullptr; d_has: per kind "has a VdW rule" (with the plan's probe / any probe).
 hipError_t build_images_device(const ImgBox& B, const double4* d_atoms, const int32_t* d_kind, const int32_t* d_has, int64_t natoms,
@@ -175,6 +300,60 @@ hipError_t build_images_device(const ImgBox& B, const double4* d_atoms, const in
     int32_t* d_offset = (int32_t*)get(sizeof(int32_t) * (na + 1));
     if (!d_count || !d_offset) return fail(hipErrorOutOfMemory);
     const unsigned ga = (unsigned)((natoms + 127) / 128);
+    // the lean form (CEG_HIP_IMAGES_SORT=radix keeps the radix-sort form)
+    const char* sort_env = getenv("CEG_HIP_IMAGES_SORT");
+    MappedWords words;
+    if (!(sort_env && sort_env[0] == 'r') && words.ok()) {
+        int32_t* r_start = nullptr;
+        if (ceg_host::pool_malloc((void**)&r_start, sizeof(int32_t) * (size_t)(nbins + 1)) != hipSuccess) return fail(hipErrorOutOfMemory);
+        int32_t* d_bincount = (int32_t*)get(sizeof(int32_t) * (2 * (size_t)nbins + 2));      // per-bin counts (+ 1), per-bin cursors, completion counter
+        auto fail_lean = [&](hipError_t e, std::initializer_list<void*> more) {
+            const hipError_t r = fail(e);
+            ceg_host::pool_free(r_start);
+            for (void* p : more) if (p) ceg_host::pool_free(p);
+            return r;
+        };
+        if (!d_bincount) return fail_lean(hipErrorOutOfMemory, {});
+        int32_t* d_cursor = d_bincount + nbins + 1;
+        unsigned* d_done = reinterpret_cast<unsigned*>(d_cursor + nbins);
+        size_t tmp_a = 0, tmp_b = 0;
+        (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_a, d_count, d_offset, (int)(natoms + 1), st);
+        (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_b, d_bincount, r_start, (int)(nbins + 1), st);
+        void* d_tmp = get(tmp_a > tmp_b ? tmp_a : tmp_b);
+        if (!d_tmp) return fail_lean(hipErrorOutOfMemory, {});
+        words.h[0] = 0; words.h[1] = 0; words.h[2] = 0;
+        if (hipMemsetAsync(d_bincount, 0, sizeof(int32_t) * (2 * (size_t)nbins + 2), st) != hipSuccess ||
+            hipMemsetAsync(d_count + natoms, 0, sizeof(int32_t), st) != hipSuccess)
+            return fail_lean(hipGetLastError(), {});
+        if (natoms > 0) hipLaunchKernelGGL(k_img_count_bins, dim3(ga), dim3(128), 0, st, B, d_atoms, d_kind, d_has, natoms, d_count, d_bincount);
+        if (hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_a, d_count, d_offset, (int)(natoms + 1), st) != hipSuccess) return fail_lean(hipGetLastError(), {});
+        hipLaunchKernelGGL(k_img_publish, dim3(1), dim3(1), 0, st, d_offset + natoms, words.d);
+        if (hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_b, d_bincount, r_start, (int)(nbins + 1), st) != hipSuccess) return fail_lean(hipGetLastError(), {});
+        if (hipGetLastError() != hipSuccess || !words.wait(1, st)) return fail_lean(hipErrorUnknown, {});
+        const int32_t total = words.h[0];
+        if (total < 0 || (int64_t)total > 0x7ffffff0LL) return fail_lean(hipErrorInvalidValue, {});
+        const size_t n = (size_t)(total > 0 ? total : 1);
+        double4* t_xyzq = (double4*)get(sizeof(double4) * n);
+        int32_t* t_kind = (int32_t*)get(sizeof(int32_t) * 3 * n);                      // kind, atom, slot -> emit index
+        if (!t_xyzq || !t_kind) return fail_lean(hipErrorOutOfMemory, {});
+        int32_t *t_atom = t_kind + n, *t_slot = t_kind + 2 * n;
+        double4* r_xyzq = nullptr;
+        int32_t *r_kind = nullptr, *r_atom = nullptr;
+        if (ceg_host::pool_malloc((void**)&r_xyzq, sizeof(double4) * n) != hipSuccess || ceg_host::pool_malloc((void**)&r_kind, sizeof(int32_t) * n) != hipSuccess ||
+            ceg_host::pool_malloc((void**)&r_atom, sizeof(int32_t) * n) != hipSuccess)
+            return fail_lean(hipErrorOutOfMemory, {(void*)r_xyzq, (void*)r_kind, (void*)r_atom});
+        if (natoms > 0 && total > 0) {
+            hipLaunchKernelGGL(k_img_emit_slots, dim3(ga), dim3(128), 0, st, B, d_atoms, d_kind, d_has, natoms, d_offset, r_start, d_cursor, t_xyzq, t_kind, t_atom, t_slot);
+            hipLaunchKernelGGL(k_img_sort_gather, dim3((unsigned)((nbins + 127) / 128)), dim3(128), 0, st, r_start, nbins, t_slot, t_xyzq, t_kind, t_atom, r_xyzq, r_kind, r_atom,
+                               d_done, words.d);
+            if (hipGetLastError() != hipSuccess || !words.wait(2, st)) return fail_lean(hipErrorUnknown, {(void*)r_xyzq, (void*)r_kind, (void*)r_atom});
+        } else if (hipStreamSynchronize(st) != hipSuccess) {
+            return fail_lean(hipErrorUnknown, {(void*)r_xyzq, (void*)r_kind, (void*)r_atom});
+        }
+        for (int i = 0; i < nblocks_held; ++i) ceg_host::pool_free(blocks[i]);
+        *out_xyzq = r_xyzq; *out_kind = r_kind; *out_atom = r_atom; *out_binstart = r_start; *out_n = total;
+        return hipSuccess;
+    }
     if (natoms > 0) hipLaunchKernelGGL(k_img_count, dim3(ga), dim3(128), 0, st, B, d_atoms, d_kind, d_has, natoms, d_count);
     if (hipMemsetAsync(d_count + natoms, 0, sizeof(int32_t), st) != hipSuccess) return fail(hipGetLastError());
     size_t tmp_scan = 0, tmp_sort = 0;

@@ -970,8 +970,8 @@ def _plan_images(hip_lib, plan_handle):
 
 @pytest.mark.parametrize("case", ["roofline-fused", "cit7-vdw-only", "cha-coulomb-only", "skewed-synthetic"])
 def test_image_list_built_on_the_device(hip_lib, monkeypatch, case):
-    """The lattice-image list of a plan is built ON THE DEVICE since round 4 (csrc/ceg_images.hip: count / scan / emit / stable radix
-    sort by bin / gather) instead of by the host loop of build_images (csrc/ceg_api.hip) -- the host-side analogue of the ProbeSystem
+    """The lattice-image list of a plan is built ON THE DEVICE since round 4 (csrc/ceg_images.hip: count / scan / emit / stable sort
+    by bin -- per-bin counting sort, or hipcub's radix sort with CEG_HIP_IMAGES_SORT=radix -- / gather) instead of by the host loop of build_images (csrc/ceg_api.hip) -- the host-side analogue of the ProbeSystem
     tiling, probes.jl:37-53.  The two builds must agree BYTE for byte: positions, charges, kind + rule flags, atom indices, bin
     starts -- for a fused plan (every atom listed), a VdW-only plan (atoms without a rule left out), a Coulomb-only plan (no kinds)
     and a skewed synthetic cell; and a build through each list gives bit-identical grids."""
@@ -996,11 +996,13 @@ def test_image_list_built_on_the_device(hip_lib, monkeypatch, case):
         w = None
         args = (cset, pv, pc, 0.265)
     lists, grids = {}, {}
-    for where in ("device", "host"):
+    for where in ("device", "device-radix", "host"):                # device: the lean form (per-bin counting sort), device-radix: the first form
+        monkeypatch.delenv("CEG_HIP_IMAGES_ON_HOST", raising=False)
+        monkeypatch.delenv("CEG_HIP_IMAGES_SORT", raising=False)
         if where == "host":
             monkeypatch.setenv("CEG_HIP_IMAGES_ON_HOST", "1")
-        else:
-            monkeypatch.delenv("CEG_HIP_IMAGES_ON_HOST", raising=False)
+        elif where == "device-radix":
+            monkeypatch.setenv("CEG_HIP_IMAGES_SORT", "radix")
         plan = GridPlan(*args)
         lists[where] = _plan_images(hip_lib, plan._h)
         cset = args[0]
@@ -1013,6 +1015,10 @@ def test_image_list_built_on_the_device(hip_lib, monkeypatch, case):
         torch.cuda.synchronize()
         grids[where] = out.cpu().numpy()
         plan.close()
+    for other in ("device-radix",):
+        for q in range(4):
+            assert np.array_equal(lists["device"][q].view(np.uint8), lists[other][q].view(np.uint8)), (other, q)
+        assert np.array_equal(grids["device"].view(np.int32), grids[other].view(np.int32))
     d, h = lists["device"], lists["host"]
     assert d[4] == h[4] and len(d[0]) == len(h[0]) > 0
     assert np.array_equal(d[0].view(np.int64), h[0].view(np.int64)), "positions / charges differ"
