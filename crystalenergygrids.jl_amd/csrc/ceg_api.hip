@@ -346,13 +346,49 @@ hipError_t build_images_device(const ImgBox& B, const double4* d_atoms, const in
 
 namespace {
 
+// The tables of a plan are a dozen uploads of a few hundred bytes to a few hundred kilobytes; a synchronous hipMemcpy from pageable memory
+// costs 15-20 us each whatever its size (a fifth of a plan creation on a new framework).  They go through a page-locked staging area of the
+// calling thread instead -- a host memcpy and an asynchronous copy on the null stream each -- and ONE synchronisation at the end of the
+// creation (flush_uploads; also before the staging area wraps around).  Larger arrays keep the synchronous copy.
+struct UploadStaging {
+    char* h = nullptr;                 // (never freed: the HIP runtime may be gone when thread-local destructors run)
+    size_t cap = 0, used = 0;
+    bool pending = false;
+};
+thread_local UploadStaging g_staging;
+constexpr size_t UPLOAD_STAGING_BYTES = 4u << 20, UPLOAD_STAGED_MAX = 1u << 20;
+
+inline hipError_t flush_uploads()
+{
+    UploadStaging& st = g_staging;
+    if (!st.pending) return hipSuccess;
+    st.pending = false;
+    st.used = 0;
+    return hipStreamSynchronize(nullptr);
+}
+
 template <class T>
 int upload(T** dst, const T* src, size_t n)
 {
     *dst = nullptr;
     if (n == 0) n = 1;  // keep pointers valid
     HIP_TRY(cached_malloc((void**)dst, n * sizeof(T)));
-    if (src) HIP_TRY(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    if (!src) return CEG_OK;
+    const size_t bytes = n * sizeof(T);
+    UploadStaging& st = g_staging;
+    if (bytes <= UPLOAD_STAGED_MAX && !std::getenv("CEG_HIP_SYNC_UPLOADS")) {
+        if (!st.h && hipHostMalloc((void**)&st.h, UPLOAD_STAGING_BYTES, hipHostMallocDefault) == hipSuccess) st.cap = UPLOAD_STAGING_BYTES;
+        if (st.h) {
+            if (st.used + bytes > st.cap) HIP_TRY(flush_uploads());
+            memcpy(st.h + st.used, src, bytes);
+            HIP_TRY(hipMemcpyAsync(*dst, st.h + st.used, bytes, hipMemcpyHostToDevice, nullptr));
+            st.used += (bytes + 255) & ~(size_t)255;
+            st.pending = true;
+            return CEG_OK;
+        }
+        (void)hipGetLastError();
+    }
+    HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
     return CEG_OK;
 }
 
@@ -1135,6 +1171,7 @@ static int create_impl(ceg_plan_t** plan, int32_t device,
     } else if (!rc && p->nprobes > 0) {
         rc = fail(CEG_ERR_UNSUPPORTED, "multi-probe plans need every perpendicular cell width >= 2*cutoff (what a ProbeSystem guarantees)");
     }
+    if (flush_uploads() != hipSuccess && !rc) rc = fail(CEG_ERR_HIP, "uploading the plan's tables failed");       // (also before a failed plan's blocks go back to the pool)
     stamp("function tables, constants");
     if (rc) {
         ceg_plan_destroy(p);
