@@ -405,6 +405,40 @@ __device__ __forceinline__ void cell_range(const double* I, const double* pos, i
     n = (int)(span < nb ? span : nb);
 }
 
+
+// Device buffers of a handle's host-array entry point (ceg_interp_points / ceg_recip_energy / ceg_pairs_energy), kept between calls and only
+// ever grown: hipMalloc + hipFree of two arrays per call cost more than a batch of a few thousand rows takes (hipFree synchronises the device).
+struct HostIo {
+    double* d_in = nullptr;
+    double* d_out = nullptr;
+    size_t in_cap = 0, out_cap = 0;
+    bool ensure(size_t in_bytes, size_t out_bytes)
+    {
+        if (in_bytes > in_cap) {
+            if (d_in) (void)hipFree(d_in);
+            d_in = nullptr; in_cap = 0;
+            const size_t cap = in_bytes + in_bytes / 2;
+            if (hipMalloc((void**)&d_in, cap) != hipSuccess) return false;
+            in_cap = cap;
+        }
+        if (out_bytes > out_cap) {
+            if (d_out) (void)hipFree(d_out);
+            d_out = nullptr; out_cap = 0;
+            const size_t cap = out_bytes + out_bytes / 2;
+            if (hipMalloc((void**)&d_out, cap) != hipSuccess) return false;
+            out_cap = cap;
+        }
+        return true;
+    }
+    void release()
+    {
+        if (d_in) (void)hipFree(d_in);
+        if (d_out) (void)hipFree(d_out);
+        d_in = d_out = nullptr;
+        in_cap = out_cap = 0;
+    }
+};
+
 }  // namespace ceg_consumers
 
 // the interpolation handle (ceg_interp.hip owns its life cycle; ceg_mc.hip reads geometry and grid pointer)
@@ -413,5 +447,6 @@ struct ceg_interp {
     ceg_consumers::InterpGeom g{};
     const float* d_grid = nullptr;
     float* owned = nullptr;
+    ceg_consumers::HostIo io;          // ceg_interp_points
 };
 

@@ -143,7 +143,10 @@ extern "C" int ceg_interp_destroy(ceg_interp_t* h)
     if (!h) return CEG_OK;
     int prev = -1;
     (void)hipGetDevice(&prev);
-    if (hipSetDevice(h->device) == hipSuccess && h->owned) (void)hipFree(h->owned);
+    if (hipSetDevice(h->device) == hipSuccess) {
+        if (h->owned) (void)hipFree(h->owned);
+        h->io.release();
+    }
     if (prev >= 0) (void)hipSetDevice(prev);
     delete h;
     return CEG_OK;
@@ -172,16 +175,13 @@ extern "C" int ceg_interp_points(ceg_interp_t* h, const double* points, int64_t 
     int prev = -1;
     (void)hipGetDevice(&prev);
     IHIP(hipSetDevice(h->device));
-    double *d_p = nullptr, *d_o = nullptr;
     int rc = CEG_OK;
-    if (hipMalloc((void**)&d_p, sizeof(double) * 3 * n) != hipSuccess || hipMalloc((void**)&d_o, sizeof(double) * n) != hipSuccess)
-        rc = ierr(CEG_ERR_HIP, "hipMalloc failed");
+    if (!h->io.ensure(sizeof(double) * 3 * (size_t)n, sizeof(double) * (size_t)n)) rc = ierr(CEG_ERR_HIP, "hipMalloc failed");
+    double *d_p = h->io.d_in, *d_o = h->io.d_out;
     if (!rc && hipMemcpy(d_p, points, sizeof(double) * 3 * n, hipMemcpyHostToDevice) != hipSuccess) rc = ierr(CEG_ERR_HIP, "H2D failed");
     if (!rc) rc = ceg_interp_points_device(h, d_p, n, d_o, nullptr);
-    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = ierr(CEG_ERR_HIP, "kernel execution failed");
-    if (!rc && hipMemcpy(out, d_o, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess) rc = ierr(CEG_ERR_HIP, "D2H failed");
-    if (d_p) (void)hipFree(d_p);
-    if (d_o) (void)hipFree(d_o);
+    // (the copy back runs on the null stream behind the kernel and reports its failure)
+    if (!rc && hipMemcpy(out, d_o, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess) rc = ierr(CEG_ERR_HIP, "kernel execution or D2H failed");
     if (prev >= 0) (void)hipSetDevice(prev);
     return rc;
 }

@@ -344,6 +344,7 @@ struct ceg_pairs {
     std::vector<int32_t> h_offset;
     struct Compact { PairFast* d_fast = nullptr; DevRule* d_rules = nullptr; int32_t* d_off = nullptr; int32_t nrules = 0, nentries = 0; };
     std::map<std::vector<int32_t>, Compact> compact;      // by the kinds of the molecule on trial
+    ceg_consumers::HostIo io;           // ceg_pairs_energy
     double* d_etab = nullptr;           // erfc(alpha r)/r records of ceg_pairfrac.h (when the CoulombEwaldDirect rules share one alpha)
     int32_t ebase = 0, eni = 0;
     double4* d_atoms = nullptr;
@@ -440,6 +441,7 @@ extern "C" int ceg_pairs_destroy(ceg_pairs_t* h)
         (void)hipFree(h->d_cell_start);
         (void)hipFree(h->d_geom);
         (void)hipFree(h->d_etab);
+        h->io.release();
     }
     if (prev >= 0) (void)hipSetDevice(prev);
     delete h;
@@ -649,17 +651,14 @@ extern "C" int ceg_pairs_energy(ceg_pairs_t* h, const double* trial, const int32
     int prev = -1;
     (void)hipGetDevice(&prev);
     if (hipSetDevice(h->device) != hipSuccess) return perr(CEG_ERR_HIP, "hipSetDevice failed");
-    double *d_p = nullptr, *d_o = nullptr;
     const size_t np = (size_t)n * m * 3;
     int rc = CEG_OK;
-    if (hipMalloc((void**)&d_p, sizeof(double) * np) != hipSuccess || hipMalloc((void**)&d_o, sizeof(double) * n) != hipSuccess)
-        rc = perr(CEG_ERR_HIP, "hipMalloc failed");
+    if (!h->io.ensure(sizeof(double) * np, sizeof(double) * (size_t)n)) rc = perr(CEG_ERR_HIP, "hipMalloc failed");
+    double *d_p = h->io.d_in, *d_o = h->io.d_out;
     if (!rc && hipMemcpy(d_p, trial, sizeof(double) * np, hipMemcpyHostToDevice) != hipSuccess) rc = perr(CEG_ERR_HIP, "H2D failed");
     if (!rc) rc = ceg_pairs_energy_device(h, d_p, trial_kinds, m, n, exclude_molecule, d_o, nullptr);
-    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = perr(CEG_ERR_HIP, "kernel execution failed");
-    if (!rc && hipMemcpy(out, d_o, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess) rc = perr(CEG_ERR_HIP, "D2H failed");
-    if (d_p) (void)hipFree(d_p);
-    if (d_o) (void)hipFree(d_o);
+    // (the copy back runs on the null stream behind the kernel and reports its failure)
+    if (!rc && hipMemcpy(out, d_o, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess) rc = perr(CEG_ERR_HIP, "kernel execution or D2H failed");
     if (prev >= 0) (void)hipSetDevice(prev);
     return rc;
 }

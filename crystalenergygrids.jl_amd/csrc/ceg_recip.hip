@@ -25,6 +25,7 @@
 
 #include "../../include/ceg_hip.h"
 #include "ceg_math.h"
+#include "ceg_consumers.h"
 #include "ceg_rows.h"
 
 extern "C" void ceg_set_last_error_(const char* msg);
@@ -149,6 +150,7 @@ struct ceg_recip {
     std::vector<double> h_kf;
     int32_t* d_desc = nullptr;
     double* d_c = nullptr;              // planes A, B, kf: [3][ns * 64]
+    ceg_consumers::HostIo io;           // ceg_recip_energy
 };
 
 namespace {
@@ -252,6 +254,7 @@ extern "C" int ceg_recip_destroy(ceg_recip_t* h)
     if (hipSetDevice(h->device) == hipSuccess) {
         (void)hipFree(h->d_desc);
         (void)hipFree(h->d_c);
+        h->io.release();
     }
     if (prev >= 0) (void)hipSetDevice(prev);
     delete h;
@@ -322,17 +325,14 @@ extern "C" int ceg_recip_energy(ceg_recip_t* h, const double* positions, const d
     int prev = -1;
     (void)hipGetDevice(&prev);
     if (hipSetDevice(h->device) != hipSuccess) return rerr(CEG_ERR_HIP, "hipSetDevice failed");
-    double *d_p = nullptr, *d_o = nullptr;
     const size_t np = (size_t)n * natoms * 3;
     int rc = CEG_OK;
-    if (hipMalloc((void**)&d_p, sizeof(double) * np) != hipSuccess || hipMalloc((void**)&d_o, sizeof(double) * n) != hipSuccess)
-        rc = rerr(CEG_ERR_HIP, "hipMalloc failed");
+    if (!h->io.ensure(sizeof(double) * np, sizeof(double) * (size_t)n)) rc = rerr(CEG_ERR_HIP, "hipMalloc failed");
+    double *d_p = h->io.d_in, *d_o = h->io.d_out;
     if (!rc && hipMemcpy(d_p, positions, sizeof(double) * np, hipMemcpyHostToDevice) != hipSuccess) rc = rerr(CEG_ERR_HIP, "H2D failed");
     if (!rc) rc = ceg_recip_energy_device(h, d_p, charges, natoms, n, energy_net_charges, static_contribution, d_o, nullptr);
-    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = rerr(CEG_ERR_HIP, "kernel execution failed");
-    if (!rc && hipMemcpy(out, d_o, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess) rc = rerr(CEG_ERR_HIP, "D2H failed");
-    if (d_p) (void)hipFree(d_p);
-    if (d_o) (void)hipFree(d_o);
+    // (the copy back runs on the null stream behind the kernel and reports its failure)
+    if (!rc && hipMemcpy(out, d_o, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess) rc = rerr(CEG_ERR_HIP, "kernel execution or D2H failed");
     if (prev >= 0) (void)hipSetDevice(prev);
     return rc;
 }
