@@ -941,6 +941,14 @@ def test_consumer_edge_cases(hip_lib, oracle):
     fin = np.isfinite(ref)
     assert np.allclose(got[fin], ref[fin], rtol=1e-10, atol=1e-9)
     assert not np.isfinite(ref[1])                                   # r = 0 pairs: the reference's Inf/NaN, reproduced
+    # batches of growing and shrinking size through ONE handle (it keeps its device buffers between calls and only ever grows them)
+    rng = np.random.default_rng(9)
+    for n in (5, 3000, 7, 40000, 1):
+        tr = (rng.uniform(0, 1, (n, 3)) @ mc.mat.T)[:, None, :] + base[None]
+        got_n = pe.energies(tr, ids, exclude_molecule=1)
+        ref_n = oracle.single_contribution_vdw(mc, (0, 1), tr)
+        fin = np.isfinite(ref_n)
+        assert np.array_equal(np.isfinite(got_n), fin) and np.allclose(got_n[fin], ref_n[fin], rtol=1e-9, atol=1e-9), n
     # every guest excluded
     pe.set_atoms(guests[0], ids, [0, 0, 0])
     assert np.array_equal(pe.energies(trial, ids, exclude_molecule=0), np.zeros(3))
