@@ -49,3 +49,23 @@ print(f"CPU oracle (literal 64x64 COEFF product, {O.max_threads()} threads): {m}
 got = out[:m].cpu().numpy()
 blk = ref == 1e100
 print("blocked pattern equal:", np.array_equal(got == 1e100, blk), " max rel err:", float(np.max(np.abs(got[~blk]-ref[~blk])/np.maximum(np.abs(ref[~blk]), 1e-3*np.median(np.abs(ref[~blk]))))))
+# the same number of positions on a regular fractional lattice of the cell, last index fastest -- the order of energy_grid
+# (grids.jl:394-419: iA, iB, iC nested, iC innermost) and of ceg_hip.energy.GpuEnergySetup.energy_grid: neighbouring threads read
+# neighbouring nodes of the node-major copy
+cell = np.asarray(w.cset.cell.mat, dtype=np.float64)
+na = 256
+fr = (torch.arange(na, dtype=torch.float64, device=dev) + 0.37) / na
+F = torch.stack(torch.meshgrid(fr, fr, fr, indexing="ij"), dim=-1).reshape(-1, 3)
+ptsr = (F @ torch.tensor(cell.T, device=dev)).contiguous()
+it.on_device(ptsr.data_ptr(), n, out.data_ptr(), s); torch.cuda.synchronize()
+e0.record()
+for _ in range(5): it.on_device(ptsr.data_ptr(), n, out.data_ptr(), s)
+e1.record(); torch.cuda.synchronize()
+msr = e0.elapsed_time(e1) / 5
+print(f"GPU interpolate_grid: {n} positions on a regular {na}^3 lattice of the cell (energy_grid order): {msr:.3f} ms -> {n/msr*1e3:.3e} points/s; "
+      f"positions in + energies out alone are {n * 32 / (msr * 1e-3) / 1e12:.2f} TB/s, the 270 MB grid is read ~once ({(n * 32 + d_grid.numel() * 4) / (msr * 1e-3) / 8e12:.2f} of the HBM peak)")
+hp = ptsr[:m].cpu().numpy()
+refr = O.interpolate_points(eg, hp)
+gotr = out[:m].cpu().numpy()
+blk = refr == 1e100
+print("regular lattice: blocked pattern equal:", np.array_equal(gotr == 1e100, blk), " max rel err:", float(np.max(np.abs(gotr[~blk]-refr[~blk])/np.maximum(np.abs(refr[~blk]), 1e-3*np.median(np.abs(refr[~blk]))))))
