@@ -762,6 +762,17 @@ def test_mc_neighbour_cells(hip_lib, oracle, forcefield, monkeypatch):
         compare(rows_i, "insertion batch")
         ref_i = oracle.single_contribution_vdw_raw(mat, inv, *table[1:], pos, kinds, mol, trial_i[::32], ks, -1)
         _assert_energies(rows_i["cells 4 A"][::32], ref_i, "cells vs oracle, insertion batch")
+        # a molecule of five atoms (methane-like: the any-size variant of k_mcw_pairs_frac, four trial atoms at a time) and one of nine
+        t = 1.09 / np.sqrt(3.0)
+        for ks_n, shape_n in (([ff.sdict["C_ch4"] - 1] + [ff.sdict["H_ch4"] - 1] * 4,
+                               np.array([[0, 0, 0], [t, t, t], [t, -t, -t], [-t, t, -t], [-t, -t, t]], dtype=np.float64)),
+                              ([ids[0], ids[1], ids[2]] * 3, rng.uniform(-2.0, 2.0, (9, 3)))):
+            trial_n = (rng.uniform(0, 1, (3000, 3)) @ mat.T)[:, None, :] + shape_n[None]
+            trial_n[:300] = (hot + rng.uniform(-3.0, 3.0, (300, 3)))[:, None, :] + shape_n[None]
+            rows_n = {name: h.trial_insert(ks_n, trial_n) for name, h in handles.items()}
+            compare(rows_n, f"insertion batch, {len(ks_n)} atoms")
+            ref_n = oracle.single_contribution_vdw_raw(mat, inv, *table[1:], pos, kinds, mol, trial_n[::32], ks_n, -1)
+            _assert_energies(rows_n["cells 4 A"][::32], ref_n, f"cells vs oracle, insertion batch of a {len(ks_n)}-atom molecule")
         print(f"neighbour cells: worst deviation from the exhaustive loop {worst:.1e}, from the oracle {worst_oracle:.1e}; capacity {cap0} -> {cap1}")
     finally:
         for h in handles.values():
