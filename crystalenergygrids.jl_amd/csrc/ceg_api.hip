@@ -347,23 +347,57 @@ hipError_t build_images_device(const ImgBox& B, const double4* d_atoms, const in
 namespace {
 
 // The tables of a plan are a dozen uploads of a few hundred bytes to a few hundred kilobytes; a synchronous hipMemcpy from pageable memory
-// costs 15-20 us each whatever its size (a fifth of a plan creation on a new framework).  They go through a page-locked staging area of the
-// calling thread instead -- a host memcpy and an asynchronous copy on the null stream each -- and ONE synchronisation at the end of the
-// creation (flush_uploads; also before the staging area wraps around).  Larger arrays keep the synchronous copy.
+// costs 15-20 us each whatever its size (a fifth of a plan creation on a new framework).  They go through a page-locked staging area
+// instead -- a host memcpy and an asynchronous copy on the null stream each -- and ONE synchronisation at the end of the creation
+// (flush_uploads; also before the staging area wraps around).  Larger arrays keep the synchronous copy.  The areas live in a small
+// process-wide pool: a plan creation borrows one for its duration (StagingLease), so threads that come and go do not each leave
+// page-locked memory behind.
 struct UploadStaging {
-    char* h = nullptr;                 // (never freed: the HIP runtime may be gone when thread-local destructors run)
+    char* h = nullptr;
     size_t cap = 0, used = 0;
     bool pending = false;
 };
-thread_local UploadStaging g_staging;
 constexpr size_t UPLOAD_STAGING_BYTES = 4u << 20, UPLOAD_STAGED_MAX = 1u << 20;
+struct StagingPool {
+    std::mutex m;
+    std::vector<char*> idle;           // (kept until the process ends: the HIP runtime may be gone when static destructors run)
+};
+StagingPool g_staging_pool;
+thread_local UploadStaging* g_staging = nullptr;      // the area of the plan creation running on this thread, if any
+
+struct StagingLease {
+    UploadStaging st;
+    UploadStaging* outer;
+    StagingLease() : outer(g_staging)
+    {
+        if (!std::getenv("CEG_HIP_SYNC_UPLOADS")) {
+            {
+                std::lock_guard<std::mutex> lock(g_staging_pool.m);
+                if (!g_staging_pool.idle.empty()) { st.h = g_staging_pool.idle.back(); g_staging_pool.idle.pop_back(); }
+            }
+            if (!st.h && hipHostMalloc((void**)&st.h, UPLOAD_STAGING_BYTES, hipHostMallocPortable) != hipSuccess) { st.h = nullptr; (void)hipGetLastError(); }
+            if (st.h) st.cap = UPLOAD_STAGING_BYTES;
+        }
+        g_staging = &st;
+    }
+    ~StagingLease()
+    {
+        if (st.pending) (void)hipStreamSynchronize(nullptr);
+        g_staging = outer;
+        if (st.h) {
+            std::lock_guard<std::mutex> lock(g_staging_pool.m);
+            if (g_staging_pool.idle.size() < 8) g_staging_pool.idle.push_back(st.h);
+            else (void)hipHostFree(st.h);
+        }
+    }
+};
 
 inline hipError_t flush_uploads()
 {
-    UploadStaging& st = g_staging;
-    if (!st.pending) return hipSuccess;
-    st.pending = false;
-    st.used = 0;
+    UploadStaging* st = g_staging;
+    if (!st || !st->pending) return hipSuccess;
+    st->pending = false;
+    st->used = 0;
     return hipStreamSynchronize(nullptr);
 }
 
@@ -375,18 +409,14 @@ int upload(T** dst, const T* src, size_t n)
     HIP_TRY(cached_malloc((void**)dst, n * sizeof(T)));
     if (!src) return CEG_OK;
     const size_t bytes = n * sizeof(T);
-    UploadStaging& st = g_staging;
-    if (bytes <= UPLOAD_STAGED_MAX && !std::getenv("CEG_HIP_SYNC_UPLOADS")) {
-        if (!st.h && hipHostMalloc((void**)&st.h, UPLOAD_STAGING_BYTES, hipHostMallocDefault) == hipSuccess) st.cap = UPLOAD_STAGING_BYTES;
-        if (st.h) {
-            if (st.used + bytes > st.cap) HIP_TRY(flush_uploads());
-            memcpy(st.h + st.used, src, bytes);
-            HIP_TRY(hipMemcpyAsync(*dst, st.h + st.used, bytes, hipMemcpyHostToDevice, nullptr));
-            st.used += (bytes + 255) & ~(size_t)255;
-            st.pending = true;
-            return CEG_OK;
-        }
-        (void)hipGetLastError();
+    UploadStaging* st = g_staging;
+    if (st && st->h && bytes <= UPLOAD_STAGED_MAX) {
+        if (st->used + bytes > st->cap) HIP_TRY(flush_uploads());
+        memcpy(st->h + st->used, src, bytes);
+        HIP_TRY(hipMemcpyAsync(*dst, st->h + st->used, bytes, hipMemcpyHostToDevice, nullptr));
+        st->used += (bytes + 255) & ~(size_t)255;
+        st->pending = true;
+        return CEG_OK;
     }
     HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
     return CEG_OK;
@@ -1033,6 +1063,7 @@ static int create_impl(ceg_plan_t** plan, int32_t device,
         delete p;
         return fail(CEG_ERR_HIP, "hipSetDevice(%d) failed", device);
     }
+    StagingLease lease;                 // the page-locked area the uploads below go through
     std::vector<double4> xyzq((size_t)natoms);
     for (int64_t a = 0; a < natoms; ++a)
         xyzq[a] = make_double4(pos[3 * a], pos[3 * a + 1], pos[3 * a + 2], charge ? charge[a] : 0.0);
