@@ -495,12 +495,14 @@ __device__ __forceinline__ void mcw_load_row(const McView& v, int first, int m, 
 }
 
 constexpr int MCW_WAVES = 4;       // waves per workgroup of the frame and pairs kernels (nothing large is staged there)
+constexpr int MCW_FRAME_ROWS = 4;  // placements a wave of k_mcw_frame takes at most (their positions and per-atom values sit in LDS)
 
 template <bool INSERT>
 __global__ __launch_bounds__(64 * MCW_WAVES) void k_mcw_frame(McView v, int32_t molecule, McMolecule nm, const double* __restrict__ trial, int64_t nrows,
                                                              double* __restrict__ out, int per_wave)
 {
-    __shared__ double s_pos[MCW_WAVES][MC_MAX_ATOMS * 3];
+    __shared__ double s_pos[MCW_WAVES][MCW_FRAME_ROWS][MC_MAX_ATOMS * 3];
+    __shared__ double s_val[MCW_WAVES][MCW_FRAME_ROWS][MC_MAX_ATOMS][2];
     __shared__ double s_q[MC_MAX_ATOMS];
     __shared__ int32_t s_kind[MC_MAX_ATOMS];
     __shared__ McGrid s_grid[MC_MAX_ATOMS];        // geometry + pointer of every atom's VdW grid: read per lane from global memory they were a
@@ -525,61 +527,67 @@ __global__ __launch_bounds__(64 * MCW_WAVES) void k_mcw_frame(McView v, int32_t 
     __syncthreads();
     const int64_t p0 = ((int64_t)blockIdx.x * MCW_WAVES + wave) * per_wave;
     const int64_t p1 = p0 + per_wave < nrows ? p0 + per_wave : nrows;
-    double* pos = s_pos[wave];
-    // the coordinates of a placement are fetched one placement ahead
-    auto fetch = [&](int64_t row) -> double {
-        if (lane >= 3 * m || row >= p1) return 0.0;
+    const int np = p1 > p0 ? (int)(p1 - p0) : 0;             // placements of this wave (<= MCW_FRAME_ROWS)
+    // The 16 m corner evaluations of a placement (montecarlo.jl:490-504: lane 16a + 8g + corner, g = 0 the VdW grid of atom a, g = 1 the
+    // Coulomb grid) fill 48 of 64 lanes for a three-atom molecule: the evaluations of ALL placements of the wave are numbered through and
+    // taken 64 at a time (four placements of CO2: three passes instead of four), the per-atom values meet in LDS and are summed per
+    // placement in the order of the atoms.
+    double* pos = s_pos[wave][0];
+    double* val = s_val[wave][0][0];
+    const int per_row = 16 * m;
+    for (int t = lane; t < np * 3 * m; t += 64) {
+        const int r = t / (3 * m), c = t - r * 3 * m;
+        const int64_t row = p0 + r;
+        double x;
         if (!INSERT && row == 0) {
-            const double4 A = v.atoms[first + lane / 3];
-            return (lane % 3 == 0) ? A.x : ((lane % 3 == 1) ? A.y : A.z);
+            const double4 A = v.atoms[first + c / 3];
+            x = (c % 3 == 0) ? A.x : ((c % 3 == 1) ? A.y : A.z);
+        } else {
+            x = trial[(size_t)(INSERT ? row : row - 1) * m * 3 + c];
         }
-        return trial[(size_t)(INSERT ? row : row - 1) * m * 3 + lane];
-    };
-    double next = fetch(p0);
-    for (int64_t row = p0; row < p1; ++row) {
-        if (lane < 3 * m) pos[lane] = next;
-        __builtin_amdgcn_wave_barrier();
-        next = fetch(row + 1);
-        double fv = 0.0, fd = 0.0;
-        // montecarlo.jl:490-504: lane 16a + 8g + corner, g = 0 the VdW grid of atom a, g = 1 the Coulomb grid
-        for (int base = 0; base < 16 * m; base += 64) {
-            const int l = base + lane;
-            const int a = l >> 4, gsel = (l >> 3) & 1, corner = l & 7;
-            double part = 0.0;
-            bool blocked = false, have = false, isvdw = false;
-            if (l < 16 * m) {
-                const double px = pos[3 * a], py = pos[3 * a + 1], pz = pos[3 * a + 2];
-                if (gsel == 0) {
-                    const McGrid* G = s_grid + a;
-                    if (G->grid) { part = ceg_consumers::interp_corner(G->g, G->grid, px, py, pz, corner, blocked); have = true; isvdw = G->g.is_vdw != 0; }
-                } else if (v.coulomb.grid) {
-                    part = ceg_consumers::interp_corner(v.coulomb.g, v.coulomb.grid, px, py, pz, corner, blocked);
-                    have = true;
-                    isvdw = v.coulomb.g.is_vdw != 0;
-                }
+        pos[r * (MC_MAX_ATOMS * 3) + c] = x;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int total = np * per_row;
+    for (int base = 0; base < total; base += 64) {
+        const int l = base + lane;
+        const int r = l / per_row, j = l - r * per_row;
+        const int a = j >> 4, gsel = (j >> 3) & 1, corner = j & 7;
+        double part = 0.0;
+        bool blocked = false, have = false, isvdw = false;
+        if (l < total) {
+            const double* q3 = pos + r * (MC_MAX_ATOMS * 3) + 3 * a;
+            const double px = q3[0], py = q3[1], pz = q3[2];
+            if (gsel == 0) {
+                const McGrid* G = s_grid + a;
+                if (G->grid) { part = ceg_consumers::interp_corner(G->g, G->grid, px, py, pz, corner, blocked); have = true; isvdw = G->g.is_vdw != 0; }
+            } else if (v.coulomb.grid) {
+                part = ceg_consumers::interp_corner(v.coulomb.g, v.coulomb.grid, px, py, pz, corner, blocked);
+                have = true;
+                isvdw = v.coulomb.g.is_vdw != 0;
             }
-            int blk = blocked ? 1 : 0;
+        }
+        int blk = blocked ? 1 : 0;
 #pragma unroll
-            for (int o = 1; o < 8; o <<= 1) {
-                part += __shfl_xor(part, o);
-                blk |= __shfl_xor(blk, o);
+        for (int o = 1; o < 8; o <<= 1) {
+            part += __shfl_xor(part, o);
+            blk |= __shfl_xor(blk, o);
+        }
+        if (l < total && corner == 0) {
+            double out_v = 0.0;
+            if (have) {
+                const double vv = (isvdw && blk) ? 1e100 : part;      // grids.jl:245-248
+                out_v = gsel == 0 ? vv : ((vv == 1e100) ? vv : s_q[a] * vv);        // montecarlo.jl:500
             }
-            if (have && corner == 0) {
-                const double val = (isvdw && blk) ? 1e100 : part;     // grids.jl:245-248
-                if (gsel == 0) fv += val;
-                else fd += (val == 1e100) ? val : s_q[a] * val;        // montecarlo.jl:500
-            }
+            val[(r * MC_MAX_ATOMS + a) * 2 + gsel] = out_v;
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            fv += __shfl_xor(fv, o);
-            fd += __shfl_xor(fd, o);
-        }
-        if (lane == 0) {
-            out[4 * (size_t)row] = fv;
-            out[4 * (size_t)row + 1] = fd;
-        }
-        __builtin_amdgcn_wave_barrier();                           // pos is rewritten for the next placement
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 2 * np) {
+        const int r = lane >> 1, gsel = lane & 1;
+        double sum = 0.0;
+        for (int a = 0; a < m; ++a) sum += val[(r * MC_MAX_ATOMS + a) * 2 + gsel];
+        out[4 * (size_t)(p0 + r) + gsel] = sum;
     }
 }
 
@@ -1543,7 +1551,7 @@ int launch_wave_kernels(ceg_mc* h, bool insert, int32_t molecule, const McMolecu
     const ceg_mc::Compact* ctab = compact_table(h, kinds, m);
     if (!ctab) return merr(CEG_ERR_HIP, "could not upload the pair-table rows of the molecule");
     {   // framework_interactions
-        const int per_wave = rows_per_wave(rows, MCW_WAVES, 4);
+        const int per_wave = rows_per_wave(rows, MCW_WAVES, MCW_FRAME_ROWS);
         const int64_t nb = (rows + (int64_t)MCW_WAVES * per_wave - 1) / ((int64_t)MCW_WAVES * per_wave);
         if (insert) hipLaunchKernelGGL(k_mcw_frame<true>, dim3((unsigned)nb), dim3(64 * MCW_WAVES), 0, h->stream, v, molecule, nm, d_in, rows, d_out, per_wave);
         else hipLaunchKernelGGL(k_mcw_frame<false>, dim3((unsigned)nb), dim3(64 * MCW_WAVES), 0, h->stream, v, molecule, nm, d_in, rows, d_out, per_wave);
