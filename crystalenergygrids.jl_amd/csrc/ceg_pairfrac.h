@@ -236,12 +236,35 @@ struct FracWave {
         a_next = 0;
     }
 
+    // Lennard-Jones + erfc(alpha r)/r of one pair from the r^2-indexed records: no square root, no exp, no erfcx, no branch (the interval
+    // index is clamped to the table: outside [1, cutoff^2] the value is meaningless and the caller does not use it)
+    __device__ __forceinline__ double record_value(const double r2, const PairFast& P) const
+    {
+        const int hi = __double2hiint(r2);
+        const double tt = r2 - __hiloint2double(hi & (int)(0xffffffffu << ERFC_SHIFT), 0);
+        int k = (int)((unsigned)hi >> ERFC_SHIFT) - ebase;
+        k = k < 0 ? 0 : (k > eni - 1 ? eni - 1 : k);
+        const double2* rec = reinterpret_cast<const double2*>(etab + ERFC_REC * (size_t)k);
+        const double2 a01 = rec[0], a23 = rec[1], a45 = rec[2], a6 = rec[3];
+        double b0 = __builtin_fma(a6.x, tt, a45.y);
+        b0 = __builtin_fma(b0, tt, a45.x);
+        b0 = __builtin_fma(b0, tt, a23.y);
+        b0 = __builtin_fma(b0, tt, a23.x);
+        b0 = __builtin_fma(b0, tt, a01.y);
+        b0 = __builtin_fma(b0, tt, a01.x);
+        const double q2 = P.sigma2 * ceg::fast_rcp(r2);
+        const double x6 = q2 * q2 * q2;
+        const double v = __builtin_fma(P.c4eps * x6, x6 - 1.0, -P.shift);
+        return __builtin_fma(P.qq, b0, v);
+    }
+
     // full batches of 64 queued pairs (everything when `all`); the remainder moves to the front
     __device__ __forceinline__ void flush(const bool all)
     {
         __builtin_amdgcn_wave_barrier();
         const int nfull = all ? qn : (qn & ~63);
-        for (int i = lane; i < nfull; i += 64) {
+        // one queued pair, every case: the band around the cutoff re-measured, records / polynomials / rule walk / libm-grade call
+        auto one = [&](const int i) -> double {
             const FracHit H = hq[i];
             double r2 = H.r2;
             const int t = H.t;
@@ -249,26 +272,11 @@ struct FracWave {
                 const int ia = H.ia, a = ia & 15;
                 const double4 A = cart[ia >> 4];
                 r2 = ceg_consumers::pair_distance2_literal_call(geom, t3[3 * a] - A.x, t3[3 * a + 1] - A.y, t3[3 * a + 2] - A.z);
-                if (!(r2 < cutoff2)) continue;                           // energy.jl:422
+                if (!(r2 < cutoff2)) return 0.0;                         // energy.jl:422
             }
+            double acc = 0.0;
             if (eni > 0 && r2 >= 1.0 && fastrec[t].cls) {
-                // Lennard-Jones + erfc(alpha r)/r from the r^2-indexed records: no square root, no exp, no erfcx
-                const PairFast P = fastrec[t];
-                const int hi = __double2hiint(r2);
-                const double tt = r2 - __hiloint2double(hi & (int)(0xffffffffu << ERFC_SHIFT), 0);
-                const double2* rec = reinterpret_cast<const double2*>(etab + ERFC_REC * (size_t)(((unsigned)hi >> ERFC_SHIFT) - (unsigned)ebase));
-                const double2 a01 = rec[0], a23 = rec[1], a45 = rec[2], a6 = rec[3];
-                double b0 = __builtin_fma(a6.x, tt, a45.y);
-                b0 = __builtin_fma(b0, tt, a45.x);
-                b0 = __builtin_fma(b0, tt, a23.y);
-                b0 = __builtin_fma(b0, tt, a23.x);
-                b0 = __builtin_fma(b0, tt, a01.y);
-                b0 = __builtin_fma(b0, tt, a01.x);
-                const double q2 = P.sigma2 * ceg::fast_rcp(r2);
-                const double x6 = q2 * q2 * q2;
-                double v = __builtin_fma(P.c4eps * x6, x6 - 1.0, -P.shift);
-                v = __builtin_fma(P.qq, b0, v);
-                e += v;
+                acc = record_value(r2, fastrec[t]);
             } else if (r2 >= 0.25) {
                 double r, rinv;
                 ceg::fast_sqrt_rsqrt(r2, r, rinv);
@@ -281,14 +289,32 @@ struct FracWave {
                         const double x = P.alpha * r;
                         v = __builtin_fma(P.qq * rinv, ceg::fast_exp_neg(-(x * x)) * ceg::erfcx_poly(x), v);
                     }
-                    e += v;
+                    acc = v;
                 } else {
-                    for (int q = offset[t]; q < offset[t + 1]; ++q) e += ceg_consumers::rule_energy_fast(rules[q], r2, r, rinv, coulombic);
+                    for (int q = offset[t]; q < offset[t + 1]; ++q) acc += ceg_consumers::rule_energy_fast(rules[q], r2, r, rinv, coulombic);
                 }
             } else {
-                for (int q = offset[t]; q < offset[t + 1]; ++q) e += rule_energy_call(&rules[q], r2, coulombic);
+                for (int q = offset[t]; q < offset[t + 1]; ++q) acc += rule_energy_call(&rules[q], r2, coulombic);
+            }
+            return acc;
+        };
+        int i = lane;
+        if (eni > 0) {
+            // two batches at a time: the record arithmetic of both pairs runs unconditionally (two independent chains; the table index is
+            // clamped, so a pair the records do not serve computes a value nobody uses), the exceptions go through `one`
+            const double lim = cutoff2 - band;
+            for (; i + 64 < nfull; i += 128) {
+                const FracHit H0 = hq[i], H1 = hq[i + 64];
+                const PairFast P0 = fastrec[H0.t], P1 = fastrec[H1.t];
+                const bool ok0 = H0.r2 >= 1.0 && H0.r2 < lim && P0.cls != 0, ok1 = H1.r2 >= 1.0 && H1.r2 < lim && P1.cls != 0;
+                const double v0 = record_value(H0.r2, P0), v1 = record_value(H1.r2, P1);
+                e += ok0 ? v0 : 0.0;
+                e += ok1 ? v1 : 0.0;
+                if (__builtin_expect(!ok0, 0)) e += one(i);
+                if (__builtin_expect(!ok1, 0)) e += one(i + 64);
             }
         }
+        for (; i < nfull; i += 64) e += one(i);
         const int rest = qn - nfull;              // < 64
         FracHit Hm{0.0, 0, 0};
         if (lane < rest) Hm = hq[nfull + lane];
